@@ -1,0 +1,220 @@
+"""Oracle (test infrastructure): Qwen2.5-VL forward in plain torch fp32 on CPU.
+
+A restatement of the third-party model arithmetic the reference loads through
+`AutoModelForVision2Seq.from_pretrained` (verl/workers/fsdp_workers.py:193-207) and calls
+in `DataParallelPPOActor._forward_micro_batch` (verl/workers/actor/dp_actor.py:64-153,
+padding-free path).  HF file = transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py
+(5.15.0 in the build container; reference pin transformers>=4.49).
+
+Parameters are a flat dict keyed by the HF state_dict names, so the golden fixtures can be
+produced by HF itself and loaded here unchanged.  Everything is float32; autograd through
+this function is the backward oracle.  Sequences are PACKED (T tokens, `cu_seqlens`), as on
+the reference's padding-free path.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import positions as P
+
+
+@dataclass
+class VLConfig:
+    # text (HF Qwen2_5_VLTextConfig)
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_layers: int = 28
+    num_heads: int = 28
+    num_kv_heads: int = 4
+    vocab_size: int = 152064
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: List[int] = field(default_factory=lambda: [16, 24, 24])
+    tie_word_embeddings: bool = False
+    # vision (HF Qwen2_5_VLVisionConfig)
+    v_depth: int = 32
+    v_hidden: int = 1280
+    v_heads: int = 16
+    v_intermediate: int = 3420
+    v_patch: int = 14
+    v_temporal_patch: int = 2
+    v_merge: int = 2
+    v_window: int = 112
+    v_fullatt: List[int] = field(default_factory=lambda: [7, 15, 23, 31])
+    v_in_channels: int = 3
+    image_token_id: int = 151655
+    vision_start_token_id: int = 151652
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+    @property
+    def v_head_dim(self) -> int:
+        return self.v_hidden // self.v_heads
+
+
+def rms_norm(x, w, eps):
+    """HF :65-79.  fp32 here, so the `.to(input_dtype)` round-trip is the identity."""
+    var = x.pow(2).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(var + eps))
+
+
+def rotate_half(x):
+    """HF :153-157."""
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def mrope_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float, section: List[int]):
+    """HF :525-538 (rotary_emb.forward) + :557-599 (section select): position_ids (3,T) ->
+    cos, sin (T, head_dim) with the frequency band i taking its angle from row
+    [t,h,w][chunk(i) % 3], chunks = section*2 over the duplicated (freqs, freqs) layout."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = position_ids.to(torch.float32)[:, :, None] * inv_freq[None, None, :]   # (3,T,hd/2)
+    emb = torch.cat((freqs, freqs), dim=-1)                                        # (3,T,hd)
+    cos, sin = emb.cos(), emb.sin()
+    sel, parts_c, parts_s, off = section * 2, [], [], 0
+    for i, n in enumerate(sel):
+        parts_c.append(cos[i % 3, :, off:off + n])
+        parts_s.append(sin[i % 3, :, off:off + n])
+        off += n
+    return torch.cat(parts_c, -1), torch.cat(parts_s, -1)
+
+
+def dense_attention(q, k, v, cu_seqlens, causal: bool):
+    """Per-segment softmax attention, fp32.  q (T,Hq,D), k/v (T,Hkv,D) -> (T,Hq,D).
+    Equivalent of flash_attn_varlen_func as called at
+    verl/models/transformers/flash_attention_utils.py:118-130 (causal) and HF :263-279 (ViT)."""
+    T, Hq, D = q.shape
+    rep = Hq // k.shape[1]
+    out = torch.empty_like(q)
+    scale = 1.0 / math.sqrt(D)
+    bounds = [int(x) for x in cu_seqlens]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b == a:
+            continue
+        qs = q[a:b].transpose(0, 1)                                   # (Hq,L,D)
+        ks = k[a:b].transpose(0, 1).repeat_interleave(rep, dim=0)     # HF repeat_kv :174-183
+        vs = v[a:b].transpose(0, 1).repeat_interleave(rep, dim=0)
+        s = torch.matmul(qs, ks.transpose(1, 2)) * scale
+        if causal:
+            L = b - a
+            s = s.masked_fill(torch.ones(L, L, dtype=torch.bool).triu(1), float("-inf"))
+        out[a:b] = torch.matmul(torch.softmax(s, dim=-1), vs).transpose(0, 1)
+    return out
+
+
+def vision_tower(p: Dict[str, torch.Tensor], cfg: VLConfig, pixel_values: torch.Tensor, grid_thw,
+                 taps: Optional[dict] = None) -> torch.Tensor:
+    """HF :408-473 (`Qwen2_5_VisionTransformerPretrainedModel.forward`).
+    pixel_values (N, C*Tp*14*14) -> merged image embeddings (N/4, out_hidden)."""
+    pre = "model.visual."
+    unit = cfg.v_merge ** 2
+    N = pixel_values.shape[0]
+    w_pe = p[pre + "patch_embed.proj.weight"].reshape(cfg.v_hidden, -1)           # Conv3d k=s => GEMM (:99-122)
+    x = pixel_values.to(torch.float32) @ w_pe.t()
+    if taps is not None:
+        taps["patch_embed"] = x.detach().clone()
+    win_idx, cu_win = P.vision_window_index(grid_thw, merge_size=cfg.v_merge, window_size=cfg.v_window,
+                                            patch_size=cfg.v_patch)
+    win_idx_t = torch.from_numpy(win_idx)
+    x = x.reshape(N // unit, unit, -1)[win_idx_t].reshape(N, -1)
+    pos = torch.from_numpy(P.vision_position_ids(grid_thw, cfg.v_merge))           # (N,2)
+    hd = cfg.v_head_dim
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float32) / (hd // 2)))   # :125-135
+    rot = (pos.to(torch.float32)[:, :, None] * inv_freq[None, None, :]).flatten(1)  # (N, hd/2)
+    rot = rot.reshape(N // unit, unit, -1)[win_idx_t].reshape(N, -1)
+    emb = torch.cat((rot, rot), dim=-1)
+    cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]
+    cu_full = P.vision_cu_seqlens(grid_thw)
+    for i in range(cfg.v_depth):
+        b = f"{pre}blocks.{i}."
+        h = rms_norm(x, p[b + "norm1.weight"], 1e-6)
+        qkv = h @ p[b + "attn.qkv.weight"].t() + p[b + "attn.qkv.bias"]
+        q, k, v = qkv.reshape(N, 3, cfg.v_heads, hd).unbind(1)
+        q = q * cos + rotate_half(q) * sin                                          # :160-171
+        k = k * cos + rotate_half(k) * sin
+        cu = cu_full if i in cfg.v_fullatt else cu_win
+        a = dense_attention(q, k, v, cu, causal=False).reshape(N, -1)
+        x = x + a @ p[b + "attn.proj.weight"].t() + p[b + "attn.proj.bias"]
+        h = rms_norm(x, p[b + "norm2.weight"], 1e-6)
+        g = h @ p[b + "mlp.gate_proj.weight"].t() + p[b + "mlp.gate_proj.bias"]
+        u = h @ p[b + "mlp.up_proj.weight"].t() + p[b + "mlp.up_proj.bias"]
+        x = x + (F.silu(g) * u) @ p[b + "mlp.down_proj.weight"].t() + p[b + "mlp.down_proj.bias"]
+        if taps is not None:
+            taps[f"vit_block{i}"] = x.detach().clone()
+    m = pre + "merger."
+    h = rms_norm(x, p[m + "ln_q.weight"], 1e-6).reshape(N // unit, -1)              # :137-150
+    h = F.gelu(h @ p[m + "mlp.0.weight"].t() + p[m + "mlp.0.bias"])
+    h = h @ p[m + "mlp.2.weight"].t() + p[m + "mlp.2.bias"]
+    out = h[torch.argsort(win_idx_t)]
+    if taps is not None:
+        taps["image_embeds"] = out.detach().clone()
+    return out
+
+
+def forward_logits(p: Dict[str, torch.Tensor], cfg: VLConfig, input_ids: torch.Tensor,
+                   position_ids: torch.Tensor, cu_seqlens, pixel_values: Optional[torch.Tensor] = None,
+                   grid_thw=None, taps: Optional[dict] = None, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HF Qwen2_5_VLModel.forward :1185-1255 + TextModel :790-873 + lm_head, on packed input.
+
+    input_ids (T,), position_ids (3,T), cu_seqlens (n+1,) -> logits (T,V) fp32 (or (len(rows),V)
+    when `rows` selects token rows before the final norm / lm_head — both are row-wise)."""
+    lm = "model.language_model."
+    x = p[lm + "embed_tokens.weight"][input_ids]
+    if pixel_values is not None:
+        img = vision_tower(p, cfg, pixel_values, grid_thw, taps)
+        mask = input_ids == cfg.image_token_id
+        assert int(mask.sum()) == img.shape[0], "image tokens != image features"
+        x = x.clone()
+        x[mask] = img.to(x.dtype)                                                   # masked_scatter :1209-1215
+    cos, sin = mrope_cos_sin(position_ids, cfg.head_dim, cfg.rope_theta, cfg.mrope_section)
+    cos, sin = cos[:, None, :], sin[:, None, :]
+    T, D = x.shape[0], cfg.head_dim
+    for i in range(cfg.num_layers):
+        b = f"{lm}layers.{i}."
+        h = rms_norm(x, p[b + "input_layernorm.weight"], cfg.rms_eps)
+        q = (h @ p[b + "self_attn.q_proj.weight"].t() + p[b + "self_attn.q_proj.bias"]).reshape(T, cfg.num_heads, D)
+        k = (h @ p[b + "self_attn.k_proj.weight"].t() + p[b + "self_attn.k_proj.bias"]).reshape(T, cfg.num_kv_heads, D)
+        v = (h @ p[b + "self_attn.v_proj.weight"].t() + p[b + "self_attn.v_proj.bias"]).reshape(T, cfg.num_kv_heads, D)
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        a = dense_attention(q, k, v, cu_seqlens, causal=True).reshape(T, -1)
+        x = x + a @ p[b + "self_attn.o_proj.weight"].t()
+        h = rms_norm(x, p[b + "post_attention_layernorm.weight"], cfg.rms_eps)
+        g = h @ p[b + "mlp.gate_proj.weight"].t()
+        u = h @ p[b + "mlp.up_proj.weight"].t()
+        x = x + (F.silu(g) * u) @ p[b + "mlp.down_proj.weight"].t()
+        if taps is not None:
+            taps[f"lm_layer{i}"] = x.detach().clone()
+    if rows is not None:
+        x = x[rows]
+    x = rms_norm(x, p[lm + "norm.weight"], cfg.rms_eps)
+    head = p[lm + "embed_tokens.weight"] if cfg.tie_word_embeddings else p["lm_head.weight"]
+    return x @ head.t()
+
+
+def response_log_probs(p, cfg: VLConfig, input_ids_2d, attention_mask_2d, position_ids_3d, response_length: int,
+                       temperature: float = 1.0, pixel_values=None, grid_thw=None):
+    """verl/workers/actor/dp_actor.py:64-153, padding-free branch, restated:
+    pack valid tokens -> model -> logits/temperature -> logp of the NEXT token (labels =
+    roll(ids,-1), :104) -> scatter back to (B,S) -> slice [:, -R-1:-1].  Returns (B,R) fp32."""
+    B, S = input_ids_2d.shape
+    valid = attention_mask_2d.bool()
+    flat_idx = valid.reshape(-1).nonzero()[:, 0]
+    ids = input_ids_2d.reshape(-1)[flat_idx]
+    pos = position_ids_3d.permute(1, 0, 2).reshape(3, -1)[:, flat_idx]            # (B,3,S)->(3,B*S)
+    lens = valid.sum(-1)
+    cu = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    logits = forward_logits(p, cfg, ids, pos, cu, pixel_values, grid_thw) / temperature
+    labels = torch.roll(ids, -1)
+    logp = torch.log_softmax(logits, dim=-1).gather(-1, labels[:, None])[:, 0]
+    full = torch.zeros(B * S, dtype=logp.dtype)
+    full[flat_idx] = logp
+    return full.reshape(B, S)[:, -response_length - 1:-1]

@@ -1,0 +1,403 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json in the BUILD CONTAINER (needs /root/reference and HF
+transformers; neither exists on the GPU box — only the outputs travel).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Sources of truth:
+  * the reference's own importable pure functions (verl.trainer.core_algos,
+    verl.utils.torch_functional, verl.models.transformers.qwen2_vl.get_rope_index,
+    verl.utils.seqlen_balancing (tensordict stubbed), reward_score/*.py loaded by path with
+    spacy / mathruler stubbed — the stub similarity is recorded in the fixture);
+  * HF transformers Qwen2_5_VLForConditionalGeneration (fp32, CPU, sdpa) on the tiny config
+    of tests/golden/tiny.py.
+Only inputs + expected outputs are written; no reference source text is stored.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import tiny  # noqa: E402
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items()})
+
+
+# ------------------------------------------------------------------ 1. RL math
+def gen_rl_math():
+    from verl.trainer import core_algos
+    from verl.utils import torch_functional as VF
+
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    # GRPO advantage: groups of 4/8/16 with shuffled uids, one zero-variance group
+    for G in (4, 8, 16):
+        n_prompt, R = 5, 9
+        N = n_prompt * G
+        scores = torch.rand(N, generator=g)
+        uid = np.repeat(np.arange(n_prompt), G)
+        perm = torch.randperm(N, generator=g).numpy()
+        uid = uid[perm]
+        scores[torch.from_numpy(uid == 0)] = 0.7           # zero-variance group -> advantage 0
+        lens = torch.randint(1, R + 1, (N,), generator=g)
+        mask = (torch.arange(R)[None, :] < lens[:, None]).long()
+        rewards = torch.zeros(N, R)
+        rewards[torch.arange(N), lens - 1] = scores
+        adv, ret = core_algos.compute_grpo_outcome_advantage(rewards.clone(), mask, uid.astype(object))
+        out[f"grpo{G}_rewards"], out[f"grpo{G}_mask"], out[f"grpo{G}_uid"] = rewards.numpy(), mask.numpy(), uid
+        out[f"grpo{G}_adv"] = adv.numpy()
+    # policy loss / KL, with forced clip branches
+    B, R = 6, 40
+    old = -torch.rand(B, R, generator=g) * 3
+    new = old + torch.randn(B, R, generator=g) * 0.4
+    new[0, :4] = old[0, :4] + torch.tensor([1.5, -1.5, 2.0, 0.0])      # ratio>3 & ratio<0.8
+    adv = torch.randn(B, R, generator=g)
+    adv[0, :4] = torch.tensor([-1.0, 1.0, -2.0, 0.5])
+    ref = old + torch.randn(B, R, generator=g) * 0.3
+    ref[1, :3] = old[1, :3] + torch.tensor([4.0, -12.0, 0.0])           # clamp edges of low_var_kl / chi2
+    lens = torch.randint(1, R + 1, (B,), generator=g)
+    mask = (torch.arange(R)[None, :] < lens[:, None]).long()
+    new_ = new.clone().requires_grad_(True)
+    pg, fh, fl, pk = core_algos.compute_policy_loss(old, new_, adv, mask, 0.2, 0.3, 3.0)
+    pg.backward()
+    out.update(pl_old=old.numpy(), pl_new=new.numpy(), pl_adv=adv.numpy(), pl_ref=ref.numpy(), pl_mask=mask.numpy(),
+               pl_out=np.array([pg.item(), fh.item(), fl.item(), pk.item()], dtype=np.float32),
+               pl_grad=new_.grad.numpy())
+    for kind in ("kl", "abs", "mse", "low_var_kl", "chi2"):
+        new_ = new.clone().requires_grad_(True)
+        kld = core_algos.compute_kl(new_, ref, kind)
+        VF.masked_mean(kld, mask).backward()
+        out[f"kl_{kind}"] = kld.detach().numpy()
+        out[f"kl_{kind}_mean_grad"] = new_.grad.numpy()
+    # full micro-batch loss as dp_actor.update_policy composes it (dp_actor.py:252-278)
+    new_ = new.clone().requires_grad_(True)
+    pg, fh, fl, pk = core_algos.compute_policy_loss(old, new_, adv, mask, 0.2, 0.3, 3.0)
+    kl_loss = VF.masked_mean(core_algos.compute_kl(new_, ref, "low_var_kl"), mask)
+    loss = (pg + kl_loss * 1e-2) / 4
+    loss.backward()
+    out.update(mb_metrics=np.array([(pg + kl_loss * 1e-2).item(), kl_loss.item(), -VF.masked_mean(new, mask).item()], dtype=np.float32),
+               mb_grad=new_.grad.numpy())
+    # response mask with multi-EOS list; masked_mean
+    resp = torch.randint(0, 20, (5, 16), generator=g)
+    out.update(rm_ids=resp.numpy(), rm_single=VF.get_response_mask(resp, 3).numpy(),
+               rm_multi=VF.get_response_mask(resp, [3, 7]).numpy())
+    # log-probs with flash-attn CE semantics (= -cross_entropy) on bf16-rounded logits
+    for V in (512, 152064):
+        T = 5 if V > 1000 else 33
+        z = (torch.randn(T, V, generator=g) * 3).bfloat16()
+        lab = torch.randint(0, V, (T,), generator=g)
+        lp = -torch.nn.functional.cross_entropy(z.float(), lab, reduction="none")
+        out[f"lp{V}_seed_shape"] = np.array([T, V])
+        out[f"lp{V}_logits_bf16_bits"] = z.view(torch.int16).numpy() if V <= 1000 else np.zeros(0)
+        out[f"lp{V}_labels"], out[f"lp{V}_logp"] = lab.numpy(), lp.numpy()
+        if V > 1000:   # too large to store: regenerate from the numpy stream below
+            rs = np.random.RandomState(V)
+            zz = torch.from_numpy((rs.standard_normal((T, V)) * 3).astype(np.float32)).bfloat16()
+            lab = torch.from_numpy(rs.randint(0, V, size=T))
+            out[f"lp{V}_labels"] = lab.numpy()
+            out[f"lp{V}_logp"] = (-torch.nn.functional.cross_entropy(zz.float(), lab, reduction="none")).numpy()
+    save("rl_math", **out)
+
+
+# ------------------------------------------------------------------ 2. AdamW (bf16 + Kahan)
+def gen_adamw():
+    from verl.utils.torch_functional import AnyPrecisionAdamW, get_constant_schedule_with_warmup
+
+    rs = np.random.RandomState(5)
+    n = 4096
+    p0 = torch.from_numpy((rs.standard_normal(n) * 0.02).astype(np.float32)).bfloat16()
+    p = torch.nn.Parameter(p0.clone())
+    opt = AnyPrecisionAdamW([p], lr=1e-6, betas=(0.9, 0.999), weight_decay=1e-2)
+    sched = get_constant_schedule_with_warmup(opt, num_warmup_steps=0)
+    out = {"p0": p0.float().numpy()}
+    lrs = []
+    for call in range(3):              # three update_actor calls, 2 optimizer steps each
+        for s in range(2):
+            gr = torch.from_numpy((rs.standard_normal(n) * (1e-3 if call < 2 else 1e-1)).astype(np.float32)).bfloat16()
+            p.grad = gr.clone()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            k = call * 2 + s
+            st = opt.state[p]
+            out[f"g{k}"] = gr.float().numpy()
+            out[f"p{k + 1}"] = p.detach().float().numpy()
+            out[f"m{k + 1}"] = st["exp_avg"].float().numpy()
+            out[f"v{k + 1}"] = st["exp_avg_sq"].float().numpy()
+            out[f"c{k + 1}"] = st["compensation"].float().numpy()
+        sched.step()                   # fsdp_workers.py:453 — once per update_actor call
+    out["lrs"] = np.asarray(lrs, dtype=np.float64)
+    save("adamw", **out)
+
+
+# ------------------------------------------------------------------ 3. positions / balancing
+class _FakeTok:
+    def __init__(self, m):
+        self.m = m
+
+    def convert_tokens_to_ids(self, t):
+        return self.m[t]
+
+
+def gen_positions():
+    from verl.models.transformers.qwen2_vl import get_rope_index
+
+    proc = types.SimpleNamespace(
+        tokenizer=_FakeTok({"<|image_pad|>": 990, "<|video_pad|>": 989, "<|vision_start|>": 991}),
+        image_processor=types.SimpleNamespace(merge_size=2))
+    cases, out = [], {}
+    rs = np.random.RandomState(3)
+
+    def seq(text_a, grids, text_b, pad):
+        toks = rs.randint(0, 900, size=text_a).tolist()
+        for (t, h, w), gap in grids:
+            toks += [991] + [990] * (t * h * w // 4) + [992] + rs.randint(0, 900, size=gap).tolist()
+        toks += rs.randint(0, 900, size=text_b).tolist()
+        ids = [993] * pad + toks
+        mask = [0] * pad + [1] * len(toks)
+        return np.asarray(ids), np.asarray(mask)
+
+    specs = [(4, [], 6, 3), (2, [((1, 8, 8), 3)], 5, 0), (5, [((1, 4, 12), 2), ((1, 6, 4), 0)], 4, 7),
+             (0, [((1, 2, 2), 1)], 1, 2)]
+    for i, (a, grids, b, pad) in enumerate(specs):
+        ids, mask = seq(a, grids, b, pad)
+        thw = torch.tensor([g for g, _ in grids], dtype=torch.long) if grids else None
+        pos = get_rope_index(proc, torch.from_numpy(ids), image_grid_thw=thw, attention_mask=torch.from_numpy(mask))
+        out[f"rope{i}_ids"], out[f"rope{i}_mask"] = ids, mask
+        out[f"rope{i}_thw"] = thw.numpy() if thw is not None else np.zeros((0, 3), dtype=np.int64)
+        out[f"rope{i}_pos"] = pos.numpy()
+    # HF vision index helpers
+    from transformers.vision_utils import get_vision_position_ids, get_vision_window_index
+
+    for i, grids in enumerate([[(1, 8, 8)], [(1, 4, 12), (1, 6, 4)], [(1, 32, 42)], [(1, 16, 16), (1, 10, 6)]]):
+        thw = torch.tensor(grids)
+        for win in (56, 112):
+            wi, cu = get_vision_window_index(thw, spatial_merge_size=2, window_size=win, patch_size=14)
+            out[f"vwin{i}_{win}_idx"], out[f"vwin{i}_{win}_cu"] = wi.numpy(), cu.numpy()
+        out[f"vwin{i}_thw"] = thw.numpy()
+        out[f"vwin{i}_pos"] = get_vision_position_ids(thw, 2).numpy()
+    # Karmarkar-Karp (pure-python part of seqlen_balancing; tensordict import stubbed)
+    sys.modules.setdefault("tensordict", types.SimpleNamespace(TensorDict=object))
+    from verl.utils.seqlen_balancing import get_seqlen_balanced_partitions
+
+    kk = []
+    for n, k in ((8, 2), (16, 4), (64, 8), (32, 8), (24, 4)):
+        lens = rs.randint(300, 2200, size=n).tolist()
+        if n == 24:
+            lens = [1000] * 12 + lens[:12]          # many ties
+        kk.append({"lens": lens, "k": k, "parts": get_seqlen_balanced_partitions(lens, k, equal_size=True)})
+    with open(os.path.join(HERE, "balance.json"), "w") as f:
+        json.dump(kk, f)
+    save("positions", **out)
+
+
+# ------------------------------------------------------------------ 4. rewards
+def _stub_similarity_modules():
+    """spaCy `en_core_web_md` and `mathruler` are absent here: stand-ins so the
+    reference files can be loaded by path.  Similarity stub = 1.0 for identical cleaned labels,
+    else 0.0; grade_answer stub = whitespace/case-normalised string equality.  Parity for these
+    two sub-terms is therefore UNPINNED; everything else in the scorers is pinned."""
+    class _Doc:
+        def __init__(self, t):
+            self.t = t
+
+        def similarity(self, o):
+            return 1.0 if self.t == o.t else 0.0
+
+    spacy = types.ModuleType("spacy")
+    spacy.load = lambda *a, **k: (lambda tok: _Doc(tok))
+    sys.modules["spacy"] = spacy
+    mr = types.ModuleType("mathruler")
+    gr = types.ModuleType("mathruler.grader")
+    gr.grade_answer = lambda a, b: a.strip().lower() == b.strip().lower()
+    gr.extract_boxed_content = lambda s: s
+    mr.grader = gr
+    sys.modules["mathruler"], sys.modules["mathruler.grader"] = mr, gr
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reward_cases():
+    gt_scene = {"objects": [{"id": "dog.1", "bbox": [10, 20, 110, 220]}, {"id": "ball.2", "bbox": [200, 210, 260, 270]},
+                            {"id": "tree.3", "bbox": [300, 5, 480, 330]}],
+                "relationships": [{"subject": "dog.1", "predicate": "next to", "object": "ball.2"}]}
+    gt = f"<scene>{json.dumps(gt_scene)}</scene>\n<answer>(B) left of the tree</answer>"
+    gt_norel = f"<scene>{json.dumps({'objects': gt_scene['objects'][:2]})}</scene>\n<answer>(A) yes</answer>"
+    problem = "Describe. Image size: (500 x 375)\nQ. where is the dog?\nOptions: (A) x (B) left of the tree"
+
+    def resp(scene, answer="(B) left of the tree", observe="<observe>a dog</observe>", think="<think>hmm</think>", extra=""):
+        sc = scene if isinstance(scene, str) else json.dumps(scene)
+        return f"{observe}\n<scene>{sc}</scene>\n{think}\n<answer>{answer}</answer>{extra}"
+
+    near = {"objects": [{"id": "dog.1", "bbox": [12, 22, 108, 215]}, {"id": "ball.2", "bbox": [190, 200, 250, 280]},
+                        {"id": "tree.3", "bbox": [310, 0, 470, 300]}],
+            "relationships": [{"subject": "dog.1", "predicate": "beside", "object": "ball.2"}]}
+    cases = [
+        ("exact", resp(gt_scene), gt, problem),
+        ("near", resp(near), gt, problem),
+        ("wrong_answer", resp(near, answer="(A) x"), gt, problem),
+        ("case_answer", resp(near, answer="  (b) LEFT of the tree "), gt, problem),
+        ("fewer_objs", resp({"objects": near["objects"][:1], "relationships": []}), gt, problem),
+        ("more_objs", resp({"objects": near["objects"] + [{"id": "cat.9", "bbox": [1, 2, 3, 4]}], "relationships": near["relationships"]}), gt, problem),
+        ("swapped_labels", resp({"objects": [{"id": "ball.7", "bbox": [12, 22, 108, 215]}, {"id": "dog.4", "bbox": [190, 200, 250, 280]}], "relationships": []}), gt, problem),
+        ("dup_ids", resp({"objects": [near["objects"][0], near["objects"][0]], "relationships": []}), gt, problem),
+        ("bad_json", resp("{not json"), gt, problem),
+        ("scene_list", resp("[1,2]"), gt, problem),
+        ("extra_key", resp({"objects": [{"id": "dog.1", "bbox": [1, 2, 3, 4], "color": "red"}], "relationships": []}), gt, problem),
+        ("rel_extra_key", resp({"objects": near["objects"], "relationships": [{"subject": "dog.1", "predicate": "on", "object": "ball.2", "conf": 1}]}), gt, problem),
+        ("bad_id", resp({"objects": [{"id": "dog1", "bbox": [1, 2, 3, 4]}], "relationships": []}), gt, problem),
+        ("bbox3", resp({"objects": [{"id": "dog.1", "bbox": [1, 2, 3]}], "relationships": []}), gt, problem),
+        ("bbox_str", resp({"objects": [{"id": "dog.1", "bbox": [1, 2, 3, "4"]}], "relationships": []}), gt, problem),
+        ("no_observe", resp(near, observe=""), gt, problem),
+        ("two_think", resp(near, think="<think>a</think><think>b</think>"), gt, problem),
+        ("no_answer_tag", "<observe>x</observe><scene>{}</scene><think>t</think>(B)", gt, problem),
+        ("empty_scene", resp({}), gt, problem),
+        ("no_objects_key", resp({"relationships": []}), gt, problem),
+        ("objs_not_list", resp({"objects": "dog", "relationships": []}), gt, problem),
+        ("norel_gt_match", resp({"objects": near["objects"][:2], "relationships": []}, answer="(A) yes"), gt_norel, problem),
+        ("norel_gt_pred_rel", resp(near, answer="(A) yes"), gt_norel, problem),
+        ("degenerate_box", resp({"objects": [{"id": "dog.1", "bbox": [10, 10, 10, 10]}, {"id": "ball.2", "bbox": [0, 0, 0, 5]}], "relationships": []}), gt, problem),
+        ("float_boxes", resp({"objects": [{"id": "dog_big.1", "bbox": [10.5, 20.25, 110.0, 220.75]}], "relationships": []}), gt, problem),
+        ("hyphen_label", resp({"objects": [{"id": "fire_hydrant.1", "bbox": [10, 20, 110, 220]}], "relationships": []}),
+         f"<scene>{json.dumps({'objects': [{'id': 'fire_hydrant.1', 'bbox': [10, 20, 110, 220]}]})}</scene><answer>(B) left of the tree</answer>", problem),
+        ("multiline", resp(json.dumps(near, indent=2)), gt, problem),
+        ("trailing_text", resp(near, extra=" and more text"), gt, problem),
+        ("other_size", resp(near), gt, "Image size: (1024 x 768) Q."),
+        ("empty", "", gt, problem),
+    ]
+    return cases
+
+
+def gen_rewards():
+    _stub_similarity_modules()
+    sgg = _load(os.path.join(REF, "verl/utils/reward_score/spatial_sgg.py"), "ref_spatial_sgg")
+    r1v = _load(os.path.join(REF, "verl/utils/reward_score/r1v.py"), "ref_r1v")
+    r1vs = _load(os.path.join(REF, "verl/utils/reward_score/r1v_scene.py"), "ref_r1v_scene")
+    rows = []
+    for name, pred, gt, problem in reward_cases():
+        rows.append({"name": name, "predict": pred, "ground_truth": gt, "problem": problem,
+                     "spatial_sgg": sgg.spatial_sgg_compute_score(pred, gt, problem),
+                     "r1v_scene": r1vs.r1v_scene_compute_score(pred, gt)})
+    r1v_rows = []
+    for pred, gt in [("<think>a</think> <answer>(B) cat</answer>", "(B) cat"), ("<think>a</think><answer>dog</answer>", "<answer>Dog</answer>"),
+                     ("<answer>x</answer>", "x"), ("<think>t</think>\n\n<answer>3</answer> tail", "3"), ("junk", "junk"),
+                     ("<think>multi\nline</think>\n<answer>a\nb</answer>", "a\nb")]:
+        r1v_rows.append({"predict": pred, "ground_truth": gt, "r1v": r1v.r1v_compute_score(pred, gt)})
+    boxes = []
+    rs = np.random.RandomState(11)
+    for _ in range(24):
+        a = np.sort(rs.rand(2, 2), axis=0).T.reshape(-1)[[0, 2, 1, 3]].tolist()   # x1,y1,x2,y2
+        b = np.sort(rs.rand(2, 2), axis=0).T.reshape(-1)[[0, 2, 1, 3]].tolist()
+        boxes.append({"a": a, "b": b, "ciou": sgg.compute_ciou(a, b)})
+    boxes.append({"a": [0.1, 0.1, 0.1, 0.1], "b": [0.2, 0.2, 0.2, 0.2], "ciou": sgg.compute_ciou([0.1] * 4, [0.2] * 4)})
+    err = None
+    try:
+        sgg.spatial_sgg_compute_score("x", "y", "no size here")
+    except ValueError as e:
+        err = str(e)
+    with open(os.path.join(HERE, "rewards.json"), "w") as f:
+        json.dump({"similarity_stub": "1.0 iff cleaned labels identical else 0.0 (spaCy vectors absent: UNPINNED)",
+                   "grade_answer_stub": "strip().lower() equality (mathruler absent: UNPINNED)",
+                   "cases": rows, "r1v": r1v_rows, "ciou": boxes, "missing_size_error": err}, f, indent=1)
+    print("wrote rewards.json", len(rows))
+
+
+# ------------------------------------------------------------------ 5. HF tiny model
+def gen_model():
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    from verl.models.transformers.qwen2_vl import get_rope_index
+
+    c = tiny.TINY
+    cfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+                         num_hidden_layers=c["num_layers"], num_attention_heads=c["num_heads"],
+                         num_key_value_heads=c["num_kv_heads"], vocab_size=c["vocab_size"], rms_norm_eps=c["rms_eps"],
+                         rope_parameters=dict(rope_type="default", rope_theta=c["rope_theta"], mrope_section=c["mrope_section"]),
+                         tie_word_embeddings=False, max_position_embeddings=4096, bos_token_id=None, eos_token_id=tiny.EOS_ID,
+                         pad_token_id=tiny.PAD_ID),
+        vision_config=dict(depth=c["v_depth"], hidden_size=c["v_hidden"], num_heads=c["v_heads"],
+                           intermediate_size=c["v_intermediate"], out_hidden_size=c["hidden_size"], patch_size=c["v_patch"],
+                           spatial_merge_size=c["v_merge"], temporal_patch_size=c["v_temporal_patch"],
+                           window_size=c["v_window"], fullatt_block_indexes=c["v_fullatt"], in_channels=c["v_in_channels"]),
+        image_token_id=c["image_token_id"], video_token_id=989, vision_start_token_id=c["vision_start_token_id"],
+        vision_end_token_id=tiny.VISION_END, tie_word_embeddings=False, bos_token_id=None, eos_token_id=tiny.EOS_ID,
+        pad_token_id=tiny.PAD_ID)
+    cfg._attn_implementation = "sdpa"
+    model = Qwen2_5_VLForConditionalGeneration(cfg).float().eval()
+    params = tiny.make_params(c)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("inv_freq" in m for m in missing), (missing, unexpected)
+
+    proc = types.SimpleNamespace(
+        tokenizer=_FakeTok({"<|image_pad|>": c["image_token_id"], "<|video_pad|>": 989, "<|vision_start|>": c["vision_start_token_id"]}),
+        image_processor=types.SimpleNamespace(merge_size=2))
+    batch = tiny.make_batch(c)
+    ids, mask, P, R = batch["input_ids"], batch["attention_mask"], batch["P"], batch["R"]
+    B = ids.shape[0]
+    # position ids exactly as the dataset + rollout build them (dataset.py:233-238, vllm_rollout_spmd.py:159-170)
+    pos = np.zeros((B, 3, P + R), dtype=np.int64)
+    for b in range(B):
+        pp = get_rope_index(proc, torch.from_numpy(ids[b, :P]), image_grid_thw=torch.from_numpy(batch["image_grid_thw"][b:b + 1]),
+                            attention_mask=torch.from_numpy(mask[b, :P])).numpy()
+        pp[:, mask[b, :P] == 0] = 0                         # postprocess_data left-pads position ids with 0 (torch_functional.py:150-184)
+        pos[b, :, :P] = pp
+        pos[b, :, P:] = pp[:, -1:] + np.arange(1, R + 1)
+    # run HF per sample, un-padded (the padded-vs-packed equivalence is the build's own invariant)
+    logps, logits_rows, hid = [], [], []
+    taps = {}
+    off = 0
+    for b in range(B):
+        sel = mask[b] == 1
+        n_patch = int(batch["patch_counts"][b])
+        px = torch.from_numpy(batch["pixel_values"][off:off + n_patch])
+        off += n_patch
+        with torch.no_grad():
+            o = model(input_ids=torch.from_numpy(ids[b][sel])[None], attention_mask=None,
+                      position_ids=torch.from_numpy(pos[b][:, sel])[:, None, :], pixel_values=px,
+                      image_grid_thw=torch.from_numpy(batch["image_grid_thw"][b:b + 1]), use_cache=False,
+                      output_hidden_states=True)
+            vis = model.model.visual(px, grid_thw=torch.from_numpy(batch["image_grid_thw"][b:b + 1]))
+        lg = o.logits[0]
+        labels = torch.roll(torch.from_numpy(ids[b][sel]), -1)
+        lp = torch.log_softmax(lg, -1).gather(-1, labels[:, None])[:, 0]
+        full = np.zeros(P + R, dtype=np.float32)
+        full[sel] = lp.numpy()
+        logps.append(full[-R - 1:-1])
+        logits_rows.append(lg[-3:].numpy())
+        hid.append(np.stack([h[0, -1].numpy() for h in o.hidden_states]))
+        taps[f"image_embeds{b}"] = vis.pooler_output.numpy()
+        taps[f"vit_last{b}"] = vis.last_hidden_state.numpy()
+    save("model_tiny", position_ids=pos, logp=np.stack(logps), logits_last3=np.stack(logits_rows),
+         hidden_last_token=np.stack(hid), **taps)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model"]
+    if "rl" in which:
+        gen_rl_math()
+    if "adamw" in which:
+        gen_adamw()
+    if "pos" in which:
+        gen_positions()
+    if "rewards" in which:
+        gen_rewards()
+    if "model" in which:
+        gen_model()

@@ -66,4 +66,4 @@ def test_packed_logprobs_and_logits(setup):
     # temperature and row-selection are row-wise identities
     rows = torch.tensor([3, 10, int(cu[1]) + 2])
     sub = Q.forward_logits(params, cfg, ids, pos, cu, torch.from_numpy(batch["pixel_values"]), batch["image_grid_thw"], rows=rows)
-    np.testing.assert_allclose(sub.numpy(), logits[rows].numpy(), atol=1e-6)
+    np.testing.assert_allclose(sub.numpy(), logits[rows].numpy(), atol=5e-6)

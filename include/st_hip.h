@@ -1,0 +1,185 @@
+/* st_hip.h — C ABI of libst_hip.so: the MI355X (gfx950 / CDNA4) kernels of the GRPO hot path.
+ *
+ * The reference (hunarbatra/SpatialThinker) is 100 % Python and has no FFI of its own; every GPU
+ * kernel it runs lives in a pip dependency (flash-attn, torch, vLLM — SURVEY.md §2.3).  Each entry
+ * point below therefore cites the reference CALL SITE whose third-party kernel it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all pointers are DEVICE pointers unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
+ *     never synchronise, never allocate; the caller owns every buffer;
+ *   - bf16 tensors are `uint16_t` bit patterns; row-major; "ld*" = leading dimension in ELEMENTS;
+ *   - return 0 on success, a positive hipError_t on a launch error, ST_EINVAL on bad arguments;
+ *   - thread-compatible: concurrent calls must use distinct streams and distinct outputs.
+ */
+#ifndef ST_HIP_H
+#define ST_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_EINVAL (-22)
+typedef void* st_stream_t;
+typedef uint16_t st_bf16;
+
+int st_version(void);                 /* ABI version, currently 1 */
+const char* st_arch(void);            /* "gfx950" */
+
+/* ---- profiling hooks (used by bench.py for the live `roofline.achieved` figure) ------------
+ * When enabled for kernel-class `klass` (ST_K_*), every launch of that class is bracketed by
+ * hipEventRecord on the launch stream; st_prof_read() synchronises those events and returns
+ * the number of launches and their summed duration in milliseconds. */
+enum { ST_K_GEMM = 0, ST_K_ATTN_FWD = 1, ST_K_ATTN_BWD = 2, ST_K_LOGPROB = 3, ST_K_ADAMW = 4,
+       ST_K_RMSNORM = 5, ST_K_VIT_ATTN = 6, ST_K_DECODE_ATTN = 7, ST_K_COUNT = 8 };
+int st_prof_enable(int klass, int max_events);
+int st_prof_read(int klass, int* launches, double* total_ms, double* total_units);
+int st_prof_disable(int klass);
+
+/* ---- fused log-prob (replaces flash_attn.ops.triton.cross_entropy, called from
+ *      verl/utils/torch_functional.py:34-42 via verl/workers/actor/dp_actor.py:125-128) --------
+ * logits (T, V) bf16 with row stride ldl; labels (T,) int64.  z = logits * inv_temperature
+ * (dp_actor.py:126 `logits.div_(temperature)`), logp[t] = z[label] - logsumexp(z), fp32.
+ * lse (T,) is saved for the backward.  Rows with label < 0 or >= V produce logp = 0. */
+int st_logprob_fwd(const st_bf16* logits, int64_t ldl, const int64_t* labels, float inv_temperature,
+                   float* logp, float* lse, int T, int V, st_stream_t stream);
+/* in-place backward: logits[t, v] <- g[t] * inv_temperature * (onehot(label) - exp(z - lse)) (bf16). */
+int st_logprob_bwd(st_bf16* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* g,
+                   float inv_temperature, int T, int V, st_stream_t stream);
+
+/* ---- GRPO token-level loss (verl/trainer/core_algos.py:291-353 compute_policy_loss, :394-436
+ *      compute_kl, verl/utils/torch_functional.py:69-71 masked_mean, composed as in
+ *      verl/workers/actor/dp_actor.py:252-278) -------------------------------------------------
+ * All inputs (n,) fp32 except mask (n,) int64 (the reference's response_mask dtype).  ref may be NULL
+ * (no KL term).  kl_kind: 0 kl, 1 abs, 2 mse, 3 low_var_kl, 4 chi2.  Writes
+ *   g[i]     = d( (pg_loss + kl_coef*kl_loss) / grad_accum ) / d logp[i]
+ *   metrics  = { pg_loss(+kl term), pg_clipfrac_higher, pg_clipfrac_lower, ppo_kl, entropy_loss,
+ *                kl_loss, sum(mask), 0 }  (8 floats, overwritten). One deterministic workgroup. */
+int st_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp, const float* adv,
+                 const int64_t* mask, int n, double clip_low, double clip_high, double clip_dual,
+                 int kl_kind, double kl_coef, double grad_accum, float* g, float* metrics, st_stream_t stream);
+
+/* ---- GRPO outcome advantage (verl/trainer/core_algos.py:137-175) ------------------------------
+ * rewards (N, R) fp32, mask (N, R) int64, group (N,) int32 dense group index in [0, n_groups)
+ * (the host maps uid strings to it).  score_i = sum_t rewards[i,t]; per group, members visited in
+ * row order: mean = (sequential fp32 sum)/n, std = unbiased (Welford, fp64 accumulate, as torch's
+ * CPU std); adv[i,t] = (score_i-mean)/(std+eps) * mask[i,t].  Groups with < 2 rows -> returns -1
+ * through *status (device int, may be NULL). */
+int st_grpo_advantage(const float* rewards, const int64_t* mask, const int32_t* group, int N, int R,
+                      int n_groups, double eps, float* adv, float* scratch /* N + 2*n_groups floats */,
+                      int32_t* status, st_stream_t stream);
+
+/* ---- RMSNorm (HF Qwen2_5_VLRMSNorm modeling_qwen2_5_vl.py:65-79; 2 per LM layer + final + ViT) --
+ * y = w * bf16(x * rsqrt(mean(x^2)+eps)) with the HF rounding points (normalised value rounded to
+ * bf16 BEFORE the weight multiply).  rstd (T,) fp32 optional output for the backward. */
+int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, st_bf16* y, int64_t ldy,
+                   float* rstd, int T, int H, st_stream_t stream);
+/* dx = rstd * (w*dy - xhat * mean(w*dy*xhat)); dw_accum (H,) fp32 += sum_t dy*bf16(xhat) (fp32 atomics, may be
+ * NULL).  dx may alias dy.  If dres != NULL, dx += dres (residual-stream gradient). */
+int st_rmsnorm_bwd(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy,
+                   int64_t lddy, const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx,
+                   float* dw_accum, int T, int H, st_stream_t stream);
+
+/* ---- rotary embeddings ------------------------------------------------------------------------
+ * M-RoPE (HF rotary_emb :525-538 + apply_multimodal_rotary_pos_emb :557-599, called from
+ * verl/models/transformers/qwen2_vl.py:157-163).  The cos/sin table depends only on the positions,
+ * so it is built ONCE per packed micro-batch and reused by every layer, forward and backward:
+ *   pos (3, T) int32 (t,h,w rows); inv_freq (D/2,) fp32 = theta^(-2i/D) (host-computed as HF does);
+ *   band i takes its angle from row 0 if i < s0, row 1 if i < s0+s1, else row 2 (s = 16,24,24);
+ *   cos_out/sin_out (T, D/2) fp32, angle = fp32(pos) * inv_freq in fp32. */
+int st_mrope_table(const int32_t* pos, const float* inv_freq, int T, int D, int s0, int s1, int s2, float* cos_out,
+                   float* sin_out, st_stream_t stream);
+/* Rotate, IN PLACE, the first n_rot_heads heads (head_dim D, D % 16 == 0) of every row of x (T, ld):
+ *   y[i] = x[i]*c[i] - x[i+D/2]*s[i];  y[i+D/2] = x[i+D/2]*c[i] + x[i]*s[i]   (rotate_half, HF :153-157).
+ * LM: x = qkv buffer, n_rot_heads = n_q + n_kv.  ViT (HF apply_rotary_pos_emb_vision :160-171): x =
+ * (N, 3*heads*D) [q|k|v], n_rot_heads = 2*heads, tables (N, D/2) in the window-reordered row order.
+ * inverse != 0 applies the transposed rotation (= backward). */
+int st_rope_apply(st_bf16* x, int64_t ld, const float* cos_tab, const float* sin_tab, int T, int n_rot_heads, int D,
+                  int inverse, st_stream_t stream);
+
+/* ---- SwiGLU (HF Qwen2MLP :541-554 / Qwen2_5_VLMLP :82-96): gu (T, 2I) = [gate | up] ------------ */
+int st_swiglu_fwd(const st_bf16* gu, int64_t ldgu, st_bf16* out, int64_t ldo, int T, int I, st_stream_t stream);
+/* dgu = [dout*up*silu'(gate) | dout*silu(gate)], may alias gu. */
+int st_swiglu_bwd(const st_bf16* gu, int64_t ldgu, const st_bf16* dout, int64_t lddo, st_bf16* dgu,
+                  int64_t lddgu, int T, int I, st_stream_t stream);
+/* exact (erf) GELU of the patch merger (HF :137-150), fwd and bwd (dx = dy * gelu'(x)). */
+int st_gelu_fwd(const st_bf16* x, st_bf16* y, int64_t n, st_stream_t stream);
+int st_gelu_bwd(const st_bf16* x, const st_bf16* dy, st_bf16* dx, int64_t n, st_stream_t stream);
+
+/* ---- bf16 MFMA GEMM (replaces the cuBLAS/hipBLASLt calls behind every nn.Linear of the model) ---
+ * C[M,N] = A[M,K] * B[N,K]^T  (both operands K-contiguous: y = x W^T with W as stored by HF).
+ *   bias (N,) bf16 or NULL; residual (M,N) bf16 or NULL is added after bias;
+ *   out_bf16 (M,N) bf16 or NULL; out_f32 (M,N) fp32 or NULL; if accumulate != 0 the fp32 output
+ *   is C += result (gradient accumulation across micro-batches).  K % 64 == 0 required. */
+int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
+               const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
+               int accumulate, int M, int N, int K, st_stream_t stream);
+/* out (C, R) = in (R, C)^T, bf16 (operand re-layout for the backward GEMMs). */
+int st_transpose(const st_bf16* in, int64_t ldin, st_bf16* out, int64_t ldout, int R, int C, st_stream_t stream);
+/* column sums: out_f32 (C,) (+)= sum_r in[r, c]  (bias gradients). */
+int st_colsum(const st_bf16* in, int64_t ldin, float* out_f32, int accumulate, int R, int C, st_stream_t stream);
+
+/* ---- attention ---------------------------------------------------------------------------------
+ * Causal varlen GQA flash attention over packed sequences (replaces flash_attn_varlen_func at
+ * verl/models/transformers/flash_attention_utils.py:118-130; `repeat_kv` of qwen2_vl.py:165-166 is
+ * never materialised).  q (T, n_q, D) / k,v (T, n_kv, D) given as base pointers + row strides (they
+ * may live inside one qkv buffer).  cu_seqlens (n_seq+1,) int32.  D = 128.  out (T, n_q*D) bf16,
+ * lse (n_q, T) fp32 (natural log, scaled scores); max_seqlen = longest sequence (sizes the grid).  causal=0 gives the bidirectional form used by
+ * the ViT (HF :225-291) where D = 80 is supported as well. */
+int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
+                st_bf16* out, int64_t ldo, float* lse, int max_seqlen, st_stream_t stream);
+/* backward: dq/dk/dv with the same layouts/strides as q/k/v (dk, dv summed over the q heads of a
+ * group); delta (n_q, T) fp32 scratch. */
+int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
+                const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
+                st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv,
+                float* delta, int max_seqlen, st_stream_t stream);
+/* single-token decode attention against a KV cache (rollout generator; replaces vLLM paged attention,
+ * verl/workers/rollout/vllm_rollout_spmd.py:141-143).  For sample b: keys = prompt part
+ * [kv_prompt + prompt_off[b] .. + prompt_len[b]) (shared by the G samples of a prompt) followed by the
+ * sample's own generated part kv_gen[b, 0..gen_len[b]).  Cache rows are (n_kv, D) bf16. */
+int st_decode_attn(const st_bf16* q, int64_t ldq, const st_bf16* kp, const st_bf16* vp, const int64_t* prompt_off,
+                   const int32_t* prompt_len, const st_bf16* kg, const st_bf16* vg, int64_t gen_stride,
+                   const int32_t* gen_len, int B, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo,
+                   st_stream_t stream);
+
+/* ---- optimizer: AnyPrecisionAdamW with bf16 states + Kahan compensation, one fused pass
+ *      (verl/utils/torch_functional.py:253-329; ~10 eager passes in the reference) ---------------
+ * p, m, v, c (n,) bf16 in place; grad fp32 (the fp32 accumulation buffer; rounded to bf16 first, the
+ * dtype AnyPrecisionAdamW sees) scaled by grad_scale (clip coefficient, device scalar pointer or NULL).
+ * lr..weight_decay are the python (double) hyper-parameters; 1-lr*wd, 1-b1, 1-b2 are formed in double and
+ * cast once to fp32, as torch does with python scalars.  step_size = lr/(1-b1^t), denom_corr = sqrt(1-b2^t)
+ * are host-computed in fp32 (torch computes them on a float32 0-d `step` tensor). */
+int st_adamw_kahan_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, st_bf16* c, int64_t n,
+                        double lr, double beta1, double beta2, double eps, double weight_decay, float step_size,
+                        float denom_corr, const float* grad_scale, st_stream_t stream);
+/* sum of squares of an fp32 buffer into out[0] (+= if accumulate) — global grad-norm for clipping
+ * (verl/workers/actor/dp_actor.py:155-167). Deterministic two-stage reduction, scratch >= 1024 floats. */
+int st_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, int accumulate, st_stream_t stream);
+
+/* ---- gather / scatter plumbing of the packed layout (flash_attn.bert_padding at
+ *      verl/workers/actor/dp_actor.py:86-101,136-138; embed + masked_scatter HF :1205-1215) --------*/
+int st_embed_gather(const st_bf16* table, int64_t ldt, const int32_t* ids, st_bf16* out, int64_t ldo, int T,
+                    int H, st_stream_t stream);
+int st_rows_gather(const st_bf16* src, int64_t lds, const int32_t* rows, st_bf16* dst, int64_t ldd, int n_rows,
+                   int H, st_stream_t stream);                     /* dst[i] = src[rows[i]] */
+int st_rows_scatter(const st_bf16* src, int64_t lds, const int32_t* rows, st_bf16* dst, int64_t ldd, int n_rows,
+                    int H, int add, st_stream_t stream);           /* dst[rows[i]] (+)= src[i], rows unique */
+int st_embed_grad(const st_bf16* dx, int64_t ldx, const int32_t* ids, float* dtable, int64_t ldt, int T, int H,
+                  st_stream_t stream);                             /* dtable[ids[t]] += dx[t] (fp32 atomics) */
+int st_cast_pad_f32_bf16(const float* in, int64_t ldin, st_bf16* out, int64_t ldout, int R, int C_in, int C_out,
+                         st_stream_t stream);                      /* pixel_values fp32 -> bf16, zero-padded cols */
+int st_add_bf16(const st_bf16* a, const st_bf16* b, st_bf16* out, int64_t n, st_stream_t stream);
+
+/* ---- sampling (vLLM sampler: temperature / top-k / top-p; rollout/config.py:25-32) ------------
+ * logits (B, V) bf16; one token per row into out_ids; Philox-style counter RNG keyed by
+ * (seed, row, step).  temperature == 0 -> argmax.  top_k <= 0 and top_p >= 1 -> plain multinomial. */
+int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p,
+              uint64_t seed, uint64_t step, int32_t* out_ids, float* scratch, st_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST_HIP_H */

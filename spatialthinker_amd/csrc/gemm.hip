@@ -1,0 +1,192 @@
+// gemm.hip — bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * B[N,K]^T  (+bias, +residual), fp32 accumulate.
+//
+// Both operands are K-contiguous (y = x W^T with W stored (out,in) as HF does), so every MFMA fragment is
+// one 16-byte LDS read.  Structure (cdna_hip_programming.md §5, "step-3" + the 2-phase T3/T4 recipe):
+//   * 128x128 output tile, BK = 64, 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 MFMA 16x16x32 tiles;
+//   * operands staged HBM -> LDS by `global_load_lds` 16 B/lane (no VGPR round trip), two LDS stages
+//     (2 x 32 KiB) so the loads of K-tile t+1 fly while tile t is multiplied; one barrier per K-tile;
+//   * LDS image is lane-linear (what the LDS-DMA writes); bank conflicts are removed by XOR-swizzling the
+//     16-byte chunk index with (row>>1)&7 on the SOURCE address and on the fragment read (rule 21);
+//   * the MFMA is issued with swapped operands (D = Bfrag x Afrag^T) so each lane ends up with 4 consecutive
+//     output columns of one row -> 8-byte bf16 / 16-byte fp32 stores;
+//   * workgroup -> tile map is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous range of tiles,
+//     walked in groups of 8 tile-rows so the A and B panels of neighbours stay L2-resident.
+// Roofline: MFMA-bound, 2*M*N*K flop per launch.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_BYTES (BM * BK * 2 + BN * BK * 2)   // 32 KiB
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+// stage one 128x64 operand tile: 16 KiB = 16 wave-instructions of 1 KiB; wave w issues 4 of them.
+__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ X, int64_t ldx, int row0, int nrows, int k0,
+                                           char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int inst = wave * 4 + j;
+        const int p = inst * 64 + lane;          // 16-byte chunk index inside the tile
+        const int r = p >> 3, cpos = p & 7;
+        const int kc = cpos ^ ((r >> 1) & 7);    // which global chunk lands at this LDS position
+        int gr = row0 + r;
+        gr = gr < nrows ? gr : nrows - 1;        // clamp: tail rows compute garbage that is never stored
+        glds16(X + (int64_t)gr * ldx + k0 + kc * 8, lds_tile + inst * 1024);
+    }
+}
+
+template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool OUT_F32, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                        const uint16_t* __restrict__ B, int64_t ldb,
+                                                        const uint16_t* __restrict__ bias,
+                                                        const uint16_t* __restrict__ res, int64_t ldr,
+                                                        uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc,
+                                                        int M, int N, int K, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap + grouped tile order
+    const int nb = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = bid / per_group, in_g = bid % per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage_tile(A, lda, m0, M, 0, smem, wave, lane);
+    stage_tile(B, ldb, n0, N, 0, smem + BM * BK * 2, wave, lane);
+
+    // per-lane fragment addressing (constant over the K loop)
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // tile kt landed; everyone is done with the other stage
+        if (kt + 1 < nk) {
+            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            stage_tile(A, lda, m0, M, (kt + 1) * BK, nxt, wave, lane);
+            stage_tile(B, ldb, n0, N, (kt + 1) * BK, nxt + BM * BK * 2, wave, lane);
+        }
+        const char* la = cur;
+        const char* lb = cur + BM * BK * 2;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + frow;
+                const int rb = wn * 64 + i * 16 + frow;
+                const int kc = s * 4 + fk;
+                af[i] = *reinterpret_cast<const bf16x8*>(la + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(lb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds D[n = (lane>>4)*4 + r][m = lane&15] for each (ni, mi)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            const bool full = (n + 3 < N);
+            if (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (full || n + r < N) v[r] += bf2f(bias[n + r]);
+            }
+            if (HAS_RES) {
+                const uint16_t* rp = res + (int64_t)m * ldr + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (full || n + r < N) v[r] += bf2f(rp[r]);
+            }
+            if (OUT_F32) {
+                float* cp = Cf + (int64_t)m * ldc + n;
+                if (full && ((ldc & 3) == 0)) {
+                    float4 o = ACCUM ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = (ACCUM ? cp[r] : 0.f) + v[r];
+                }
+            }
+            if (OUT_BF16) {
+                uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                if (full && ((ldc & 3) == 0)) {
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <bool HB, bool HR, bool OB, bool OF, bool AC>
+static int launch_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
+                       const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K,
+                       hipStream_t s) {
+    const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<HB, HR, OB, OF, AC>), dim3(tiles_m * tiles_n), dim3(256), 0, s, A, lda, B, ldb, bias, res,
+                       ldr, Cb, Cf, ldc, M, N, K, tiles_m, tiles_n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
+                          const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
+                          int accumulate, int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || M < 0 || N < 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return ST_EINVAL;
+    if ((out_bf16 == nullptr) == (out_f32 == nullptr)) return ST_EINVAL;      // exactly one output
+    if (out_bf16 && accumulate) return ST_EINVAL;
+    if ((((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return ST_EINVAL;
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
+    const bool hb = bias != nullptr, hr = residual != nullptr;
+#define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
+    if (out_bf16) {
+        if (hb && hr) GO(true, true, true, false, false);
+        if (hb) GO(true, false, true, false, false);
+        if (hr) GO(false, true, true, false, false);
+        GO(false, false, true, false, false);
+    } else {
+        if (hb || hr) return ST_EINVAL;
+        if (accumulate) GO(false, false, false, true, true);
+        GO(false, false, false, true, false);
+    }
+#undef GO
+}

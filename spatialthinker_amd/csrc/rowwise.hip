@@ -1,0 +1,257 @@
+// rowwise.hip — HBM-bound row kernels of the GRPO hot path for gfx950:
+// fused log-prob forward/backward over the vocabulary, RMSNorm forward/backward.
+// All reductions use 64-lane wave shuffles; global access is 16 B per lane.
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// ------------------------------------------------------------------------------------------
+// log-prob forward: one 256-thread workgroup per token row, online (max, sum) in base 2.
+// Algorithmic bytes: 2*V per row read once.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logprob_fwd_kernel(const uint16_t* __restrict__ logits, int64_t ldl,
+                                                         const int64_t* __restrict__ labels, float inv_temp,
+                                                         float* __restrict__ logp, float* __restrict__ lse_out, int V) {
+    const int row = blockIdx.x;
+    const uint16_t* x = logits + (int64_t)row * ldl;
+    const float sc = inv_temp * LOG2E;                  // z2 = x * sc  (base-2 scaled logit)
+    float m = -INFINITY, s = 0.f;
+    const bool vec_ok = ((ldl & 7) == 0) && ((((uintptr_t)logits) & 15) == 0);
+    const int V8 = vec_ok ? (V & ~7) : 0;
+    for (int i = threadIdx.x * 8; i < V8; i += 256 * 8) {
+        const uint4 r = *reinterpret_cast<const uint4*>(x + i);
+        float f[8];
+        unpack8(r, f);
+        float vm = f[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) vm = fmaxf(vm, f[j]);
+        vm *= sc;                                        // sc > 0
+        if (vm > m) { s *= exp2f(m - vm); m = vm; }
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += exp2f(f[j] * sc - m);
+        s += a;
+    }
+    for (int i = V8 + threadIdx.x; i < V; i += 256) {   // scalar tail / unaligned fallback
+        const float z = bf2f(x[i]) * sc;
+        if (z > m) { s *= exp2f(m - z); m = z; }
+        s += exp2f(z - m);
+    }
+    // wave then workgroup combine of (m, s)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, mo);
+        s = (m == -INFINITY ? 0.f : s * exp2f(m - mn)) + (mo == -INFINITY ? 0.f : so * exp2f(mo - mn));
+        m = mn;
+    }
+    __shared__ float sm[4], ss[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = m; ss[w] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float M = sm[0], S = ss[0];
+        for (int k = 1; k < 4; ++k) {
+            const float mn = fmaxf(M, sm[k]);
+            S = (M == -INFINITY ? 0.f : S * exp2f(M - mn)) + (sm[k] == -INFINITY ? 0.f : ss[k] * exp2f(sm[k] - mn));
+            M = mn;
+        }
+        const float lse = (M + log2f(S)) * LN2;          // natural-log logsumexp of z
+        const int64_t lab = labels[row];
+        float lp = 0.f;
+        if (lab >= 0 && lab < V) lp = bf2f(x[lab]) * inv_temp - lse;
+        logp[row] = lp;
+        lse_out[row] = lse;
+    }
+}
+
+// in-place backward: dlogits = g * inv_temp * (onehot - exp(z - lse)); rows with g == 0 are zero-filled
+// without being read.  Algorithmic bytes: 2*V read + 2*V written per live row.
+__global__ __launch_bounds__(256) void logprob_bwd_kernel(uint16_t* __restrict__ logits, int64_t ldl,
+                                                         const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ lse, const float* __restrict__ g,
+                                                         float inv_temp, int V) {
+    const int row = blockIdx.x;
+    uint16_t* x = logits + (int64_t)row * ldl;
+    const float gr = g[row] * inv_temp;
+    const float sc = inv_temp * LOG2E;
+    const float l2 = lse[row] * LOG2E;
+    const int64_t lab = labels[row];
+    const bool vec_ok = ((ldl & 7) == 0) && ((((uintptr_t)logits) & 15) == 0);
+    const int V8 = vec_ok ? (V & ~7) : 0;
+    if (gr == 0.f) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x * 8; i < V8; i += 256 * 8) *reinterpret_cast<uint4*>(x + i) = z;
+        for (int i = V8 + threadIdx.x; i < V; i += 256) x[i] = 0;
+        return;
+    }
+    for (int i = threadIdx.x * 8; i < V8; i += 256 * 8) {
+        const uint4 r = *reinterpret_cast<const uint4*>(x + i);
+        float f[8];
+        unpack8(r, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = exp2f(f[j] * sc - l2);
+            f[j] = gr * (((int64_t)(i + j) == lab ? 1.f : 0.f) - p);
+        }
+        *reinterpret_cast<uint4*>(x + i) = pack8(f);
+    }
+    for (int i = V8 + threadIdx.x; i < V; i += 256) {
+        const float p = exp2f(bf2f(x[i]) * sc - l2);
+        x[i] = f2bf(gr * (((int64_t)i == lab ? 1.f : 0.f) - p));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm forward: one wave per row, 4 rows per 256-thread workgroup.
+// y = w * bf16(x * rstd)  (HF rounding points, modeling_qwen2_5_vl.py:74-79)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                         const uint16_t* __restrict__ w, float eps,
+                                                         uint16_t* __restrict__ y, int64_t ldy,
+                                                         float* __restrict__ rstd_out, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    uint16_t* yr = y + (int64_t)row * ldy;
+    float ss = 0.f;
+    for (int i = lane * 8; i < H; i += 512) {
+        const uint4 r = *reinterpret_cast<const uint4*>(xr + i);
+        float f[8];
+        unpack8(r, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+    for (int i = lane * 8; i < H; i += 512) {
+        const uint4 r = *reinterpret_cast<const uint4*>(xr + i);
+        const uint4 wr = *reinterpret_cast<const uint4*>(w + i);
+        float f[8], wf[8];
+        unpack8(r, f);
+        unpack8(wr, wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = wf[j] * bfround(f[j] * rstd);
+        *reinterpret_cast<uint4*>(yr + i) = pack8(f);
+    }
+}
+
+// RMSNorm backward.  Workgroup = 4 waves x ROWS_PER_WAVE rows.  Phase 1: per-row dot = sum(dy*w*xhat)
+// (wave shuffles) into LDS.  Phase 2: column-chunk major — each lane owns 8 columns of a 512-column
+// chunk, walks its wave's rows writing dx and accumulating dw in registers; one fp32 atomicAdd per
+// column per workgroup at the end.
+#define RN_ROWS_PER_WAVE 8
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                         const uint16_t* __restrict__ w,
+                                                         const float* __restrict__ rstd,
+                                                         const uint16_t* __restrict__ dy, int64_t lddy,
+                                                         const uint16_t* __restrict__ dres, int64_t lddres,
+                                                         uint16_t* __restrict__ dx, int64_t lddx,
+                                                         float* __restrict__ dw_accum, int T, int H) {
+    __shared__ float s_dot[4 * RN_ROWS_PER_WAVE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wv) * RN_ROWS_PER_WAVE;
+    for (int r = 0; r < RN_ROWS_PER_WAVE; ++r) {
+        const int row = row0 + r;
+        float acc = 0.f;
+        if (row < T) {
+            const float rs = rstd[row];
+            const uint16_t* xr = x + (int64_t)row * ldx;
+            const uint16_t* dyr = dy + (int64_t)row * lddy;
+            for (int i = lane * 8; i < H; i += 512) {
+                float xf[8], df[8], wf[8];
+                unpack8(*reinterpret_cast<const uint4*>(xr + i), xf);
+                unpack8(*reinterpret_cast<const uint4*>(dyr + i), df);
+                unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += df[j] * wf[j] * (xf[j] * rs);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_dot[wv * RN_ROWS_PER_WAVE + r] = acc;
+    }
+    __syncthreads();
+    const float invH = 1.f / (float)H;
+    for (int c0 = lane * 8; c0 < H; c0 += 512) {
+        float wf[8], dwl[8];
+        unpack8(*reinterpret_cast<const uint4*>(w + c0), wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwl[j] = 0.f;
+        for (int r = 0; r < RN_ROWS_PER_WAVE; ++r) {
+            const int row = row0 + r;
+            if (row >= T) break;
+            const float rs = rstd[row];
+            const float mdot = s_dot[wv * RN_ROWS_PER_WAVE + r] * invH;
+            float xf[8], df[8], o[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * ldx + c0), xf);
+            unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)row * lddy + c0), df);
+            if (dres) unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * lddres + c0), o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = xf[j] * rs;
+                const float d = rs * (df[j] * wf[j] - xh * mdot);
+                dwl[j] += df[j] * bfround(xh);
+                o[j] = dres ? (o[j] + d) : d;
+            }
+            *reinterpret_cast<uint4*>(dx + (int64_t)row * lddx + c0) = pack8(o);
+        }
+        if (dw_accum) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(dw_accum + c0 + j, dwl[j]);
+        }
+    }
+}
+
+extern "C" {
+
+int st_logprob_fwd(const st_bf16* logits, int64_t ldl, const int64_t* labels, float inv_temperature, float* logp,
+                   float* lse, int T, int V, st_stream_t stream) {
+    if (!logits || !labels || !logp || !lse || T < 0 || V <= 0 || ldl < V || !(inv_temperature > 0.f)) return ST_EINVAL;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_LOGPROB, s, 2.0 * (double)T * (double)V);
+    hipLaunchKernelGGL(logprob_fwd_kernel, dim3(T), dim3(256), 0, s, logits, ldl, labels, inv_temperature, logp, lse, V);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_logprob_bwd(st_bf16* logits, int64_t ldl, const int64_t* labels, const float* lse, const float* g,
+                   float inv_temperature, int T, int V, st_stream_t stream) {
+    if (!logits || !labels || !lse || !g || T < 0 || V <= 0 || ldl < V || !(inv_temperature > 0.f)) return ST_EINVAL;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_LOGPROB, s, 4.0 * (double)T * (double)V);
+    hipLaunchKernelGGL(logprob_bwd_kernel, dim3(T), dim3(256), 0, s, logits, ldl, labels, lse, g, inv_temperature, V);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, st_bf16* y, int64_t ldy, float* rstd,
+                   int T, int H, st_stream_t stream) {
+    if (!x || !w || !y || T < 0 || H <= 0 || (H & 7) || (ldx & 7) || (ldy & 7)) return ST_EINVAL;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_RMSNORM, s, 4.0 * (double)T * (double)H);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_rmsnorm_bwd(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy, int64_t lddy,
+                   const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx, float* dw_accum, int T, int H,
+                   st_stream_t stream) {
+    if (!x || !w || !rstd || !dy || !dx || T < 0 || H <= 0 || (H & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7) ||
+        (dres && (lddres & 7)))
+        return ST_EINVAL;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(st_cdiv(T, 4 * RN_ROWS_PER_WAVE)), dim3(256), 0, s, x, ldx, w, rstd, dy,
+                       lddy, dres, lddres, dx, lddx, dw_accum, T, H);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+"""Thin torch-tensor front-end over the C ABI (include/st_hip.h).
+
+torch is plumbing here: device memory, streams.  Every function enqueues exactly the HIP
+kernels of libst_hip.so on torch's current stream and raises if a tensor is not on a GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from .lib import lib
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+KL_KINDS = {"kl": 0, "abs": 1, "mse": 2, "low_var_kl": 3, "chi2": 4}
+K_GEMM, K_ATTN_FWD, K_ATTN_BWD, K_LOGPROB, K_ADAMW, K_RMSNORM, K_VIT_ATTN, K_DECODE_ATTN = range(8)
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("spatialthinker_amd.ops: tensor is not on a GPU (there is no CPU path)")
+    return t.data_ptr()
+
+
+def _chk(t, dtype, what):
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{what}: last dim must be contiguous")
+    return t
+
+
+# ------------------------------------------------------------------ log-prob / GRPO
+def logprob_fwd(logits: torch.Tensor, labels: torch.Tensor, temperature: float = 1.0):
+    """logits (T,V) bf16, labels (T,) int64 -> (logp (T,) f32, lse (T,) f32)."""
+    _chk(logits, BF16, "logits"); _chk(labels, I64, "labels")
+    T, V = logits.shape
+    logp = torch.empty(T, dtype=F32, device=logits.device)
+    lse = torch.empty(T, dtype=F32, device=logits.device)
+    lib().st_logprob_fwd(_p(logits), logits.stride(0), _p(labels), 1.0 / temperature, _p(logp), _p(lse), T, V, _s())
+    return logp, lse
+
+
+def logprob_bwd_(logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, g: torch.Tensor, temperature: float = 1.0):
+    """In place: logits <- d(sum g*logp)/dlogits."""
+    _chk(logits, BF16, "logits"); _chk(g, F32, "g"); _chk(lse, F32, "lse")
+    T, V = logits.shape
+    lib().st_logprob_bwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(g), 1.0 / temperature, T, V, _s())
+    return logits
+
+
+def grpo_loss(logp, old_logp, ref_logp, adv, mask, *, clip_low=0.2, clip_high=0.3, clip_dual=3.0,
+              kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0):
+    """Flattened (n,) fp32 inputs, mask int64 -> (g (n,) f32, metrics (8,) f32 on device)."""
+    for t, nm in ((logp, "logp"), (old_logp, "old"), (adv, "adv")):
+        _chk(t, F32, nm)
+    _chk(mask, I64, "mask")
+    n = logp.numel()
+    g = torch.empty(n, dtype=F32, device=logp.device)
+    met = torch.empty(8, dtype=F32, device=logp.device)
+    lib().st_grpo_loss(_p(logp), _p(old_logp), _p(ref_logp), _p(adv), _p(mask), n, clip_low, clip_high, clip_dual,
+                       KL_KINDS[kl_kind], kl_coef, grad_accum, _p(g), _p(met), _s())
+    return g, met
+
+
+def grpo_advantage(rewards, mask, group, n_groups: int, eps: float = 1e-6):
+    _chk(rewards, F32, "rewards"); _chk(mask, I64, "mask"); _chk(group, I32, "group")
+    N, R = rewards.shape
+    adv = torch.empty_like(rewards)
+    scratch = torch.empty(N + 2 * n_groups, dtype=F32, device=rewards.device)
+    status = torch.zeros(1, dtype=I32, device=rewards.device)
+    lib().st_grpo_advantage(_p(rewards), _p(mask), _p(group), N, R, n_groups, eps, _p(adv), _p(scratch), _p(status), _s())
+    return adv, status
+
+
+# ------------------------------------------------------------------ norms / rope / activations
+def rmsnorm_fwd(x, w, eps, want_rstd=True, out=None):
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    T, H = x.shape
+    y = torch.empty(T, H, dtype=BF16, device=x.device) if out is None else out
+    rstd = torch.empty(T, dtype=F32, device=x.device) if want_rstd else None
+    lib().st_rmsnorm_fwd(_p(x), x.stride(0), _p(w), eps, _p(y), y.stride(0), _p(rstd), T, H, _s())
+    return y, rstd
+
+
+def rmsnorm_bwd(x, w, rstd, dy, dres=None, dw_accum=None, out=None):
+    T, H = x.shape
+    dx = torch.empty(T, H, dtype=BF16, device=x.device) if out is None else out
+    lib().st_rmsnorm_bwd(_p(x), x.stride(0), _p(w), _p(rstd), _p(dy), dy.stride(0), _p(dres),
+                         dres.stride(0) if dres is not None else 0, _p(dx), dx.stride(0), _p(dw_accum), T, H, _s())
+    return dx
+
+
+def mrope_table(pos_3T: torch.Tensor, inv_freq: torch.Tensor, D: int, section):
+    _chk(pos_3T, I32, "pos"); _chk(inv_freq, F32, "inv_freq")
+    T = pos_3T.shape[1]
+    cos = torch.empty(T, D // 2, dtype=F32, device=pos_3T.device)
+    sin = torch.empty_like(cos)
+    lib().st_mrope_table(_p(pos_3T), _p(inv_freq), T, D, section[0], section[1], section[2], _p(cos), _p(sin), _s())
+    return cos, sin
+
+
+def rope_apply_(x, cos, sin, n_rot_heads: int, D: int, inverse: bool = False):
+    _chk(x, BF16, "x"); _chk(cos, F32, "cos")
+    lib().st_rope_apply(_p(x), x.stride(0), _p(cos), _p(sin), x.shape[0], n_rot_heads, D, int(inverse), _s())
+    return x
+
+
+def swiglu_fwd(gu, out=None):
+    T, I2 = gu.shape
+    o = torch.empty(T, I2 // 2, dtype=BF16, device=gu.device) if out is None else out
+    lib().st_swiglu_fwd(_p(gu), gu.stride(0), _p(o), o.stride(0), T, I2 // 2, _s())
+    return o
+
+
+def swiglu_bwd(gu, dout, out=None):
+    T, I2 = gu.shape
+    d = torch.empty_like(gu) if out is None else out
+    lib().st_swiglu_bwd(_p(gu), gu.stride(0), _p(dout), dout.stride(0), _p(d), d.stride(0), T, I2 // 2, _s())
+    return d
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    lib().st_gelu_fwd(_p(x), _p(y), x.numel(), _s())
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    lib().st_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _s())
+    return dx
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulate=False):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(+residual).  Returns bf16 `out` (allocated if needed) unless `out_f32` given."""
+    _chk(a, BF16, "A"); _chk(b, BF16, "B")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K, (a.shape, b.shape)
+    if out_f32 is None and out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    c = out if out_f32 is None else out_f32
+    lib().st_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
+                     residual.stride(0) if residual is not None else 0, _p(out) if out_f32 is None else None,
+                     _p(out_f32), c.stride(0), int(accumulate), M, N, K, _s())
+    return c
+
+
+def transpose(x, out=None):
+    R, C = x.shape
+    o = torch.empty(C, R, dtype=BF16, device=x.device) if out is None else out
+    lib().st_transpose(_p(x), x.stride(0), _p(o), o.stride(0), R, C, _s())
+    return o
+
+
+def colsum(x, out_f32=None, accumulate=False):
+    R, C = x.shape
+    o = torch.empty(C, dtype=F32, device=x.device) if out_f32 is None else out_f32
+    lib().st_colsum(_p(x), x.stride(0), _p(o), int(accumulate and out_f32 is not None), R, C, _s())
+    return o
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=None):
+    """q (T, >=n_q*D) view, k/v (T, >=n_kv*D) views (row strides may exceed the width: qkv buffer slices)."""
+    T = q.shape[0]
+    o = torch.empty(T, n_q * D, dtype=BF16, device=q.device) if out is None else out
+    lse = torch.empty(n_q, T, dtype=F32, device=q.device)
+    lib().st_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(cu_seqlens), cu_seqlens.numel() - 1,
+                      T, n_q, n_kv, D, scale, int(causal), _p(o), o.stride(0), _p(lse), int(max_seqlen), _s())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, dq, dk, dv):
+    T = q.shape[0]
+    delta = torch.empty(n_q, T, dtype=F32, device=q.device)
+    lib().st_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), _p(do), do.stride(0),
+                      _p(lse), _p(cu_seqlens), cu_seqlens.numel() - 1, T, n_q, n_kv, D, scale, int(causal),
+                      _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(delta), int(max_seqlen), _s())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------ optimizer
+def adamw_scalars(t: int, lr: float, beta1: float, beta2: float):
+    """step_size and denom-correction exactly as torch forms them on a float32 0-d `step` tensor
+    (verl/utils/torch_functional.py:306-309)."""
+    step = torch.tensor(float(t), dtype=torch.float32)
+    bc1 = 1 - beta1 ** step
+    return float(lr / bc1), float((1 - beta2 ** step) ** 0.5)
+
+
+def adamw_kahan_step_(p, grad_f32, m, v, c, *, t: int, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=None):
+    _chk(p, BF16, "p"); _chk(grad_f32, F32, "grad")
+    step_size, dc = adamw_scalars(t, lr, betas[0], betas[1])
+    lib().st_adamw_kahan_step(_p(p), _p(grad_f32), _p(m), _p(v), _p(c), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                              step_size, dc, _p(grad_scale), _s())
+
+
+def sumsq(x_f32, out=None, accumulate=False):
+    scratch = torch.empty(1024, dtype=F32, device=x_f32.device)
+    o = torch.zeros(1, dtype=F32, device=x_f32.device) if out is None else out
+    lib().st_sumsq_f32(_p(x_f32), x_f32.numel(), _p(scratch), _p(o), int(accumulate), _s())
+    return o
+
+
+# ------------------------------------------------------------------ gather / scatter
+def embed_gather(table, ids_i32, out=None):
+    T, H = ids_i32.numel(), table.shape[1]
+    o = torch.empty(T, H, dtype=BF16, device=table.device) if out is None else out
+    lib().st_embed_gather(_p(table), table.stride(0), _p(ids_i32), _p(o), o.stride(0), T, H, _s())
+    return o
+
+
+def rows_gather(src, rows_i32, out=None):
+    n, H = rows_i32.numel(), src.shape[1]
+    o = torch.empty(n, H, dtype=BF16, device=src.device) if out is None else out
+    lib().st_rows_gather(_p(src), src.stride(0), _p(rows_i32), _p(o), o.stride(0), n, H, _s())
+    return o
+
+
+def rows_scatter_(dst, rows_i32, src, add=False):
+    lib().st_rows_scatter(_p(src), src.stride(0), _p(rows_i32), _p(dst), dst.stride(0), rows_i32.numel(), src.shape[1], int(add), _s())
+    return dst
+
+
+def embed_grad_(dtable_f32, ids_i32, dx):
+    lib().st_embed_grad(_p(dx), dx.stride(0), _p(ids_i32), _p(dtable_f32), dtable_f32.stride(0), ids_i32.numel(), dx.shape[1], _s())
+
+
+def cast_pad(x_f32, c_out: int):
+    R, C = x_f32.shape
+    o = torch.empty(R, c_out, dtype=BF16, device=x_f32.device)
+    lib().st_cast_pad_f32_bf16(_p(x_f32), x_f32.stride(0), _p(o), o.stride(0), R, C, c_out, _s())
+    return o
+
+
+def add_(a, b, out=None):
+    o = torch.empty_like(a) if out is None else out
+    lib().st_add_bf16(_p(a), _p(b), _p(o), a.numel(), _s())
+    return o
+
+
+# ------------------------------------------------------------------ profiling hooks
+def prof_enable(klass: int, max_events: int = 200000):
+    lib().st_prof_enable(klass, max_events)
+
+
+def prof_read(klass: int):
+    import ctypes
+    n, ms, units = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    lib().st_prof_read(klass, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(units))
+    return n.value, ms.value, units.value

@@ -270,7 +270,10 @@ class AdamWKahanBF16:
         if self.wd:
             p = bf16_round(p * f(1 - lr * self.wd))
         self.m = bf16_round(_fma32(A, g, bf16_round(self.m * f(b1))))
-        self.v = bf16_round(_fma32(f(1 - b2) * g, g, bf16_round(self.v * f(b2))))
+        if self.scalar_mode == "cpu":      # CPU addcmul: fma(value*t1, t2, self)
+            self.v = bf16_round(_fma32(f(1 - b2) * g, g, bf16_round(self.v * f(b2))))
+        else:                              # GPU addcmul: fma(value, t1*t2, self)   (probed on MI355X, tools/probe_adamw.py)
+            self.v = bf16_round(_fma32(f(1 - b2), g * g, bf16_round(self.v * f(b2))))
         cv = bf16_round(bf16_round(bf16_round(np.sqrt(self.v)) / f(dc)) + E)
         if self.scalar_mode == "cpu":      # CPU kernel: self + (value*t1)/t2
             self.c = bf16_round(self.c + (f(-step_size) * self.m) / cv)

@@ -2,11 +2,6 @@
 #include "common.h"
 
 extern "C" {
-int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
-                const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
-                const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
-                st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv,
-                float* delta, int max_seqlen, st_stream_t stream) { return -38; }
 int st_decode_attn(const st_bf16* q, int64_t ldq, const st_bf16* kp, const st_bf16* vp, const int64_t* prompt_off,
                    const int32_t* prompt_len, const st_bf16* kg, const st_bf16* vg, int64_t gen_stride,
                    const int32_t* gen_len, int B, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo,

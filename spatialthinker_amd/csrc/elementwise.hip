@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void adamw_kahan_kernel(uint16_t* __restrict__
             const float g = bfround(gf[j] * gs);
             float pw = wd_mul != 1.f ? bfround(pf[j] * wd_mul) : pf[j];
             const float mn = bfround(__fmaf_rn(one_m_b1, g, bfround(mf[j] * b1)));
-            const float vn = bfround(__fmaf_rn(one_m_b2 * g, g, bfround(vf[j] * b2)));
+            const float vn = bfround(__fmaf_rn(one_m_b2, g * g, bfround(vf[j] * b2)));
             const float cv = bfround(bfround(bfround(__fsqrt_rn(vn)) / dc) + eps);
             const float cn = bfround(__fmaf_rn(neg_step, mn / cv, cf[j]));
             const float pn = bfround(pw + cn);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void adamw_kahan_kernel(uint16_t* __restrict__
             const float pf0 = bf2f(p[i]);
             const float pw = wd_mul != 1.f ? bfround(pf0 * wd_mul) : pf0;
             const float mn = bfround(__fmaf_rn(one_m_b1, g, bfround(bf2f(m[i]) * b1)));
-            const float vn = bfround(__fmaf_rn(one_m_b2 * g, g, bfround(bf2f(v[i]) * b2)));
+            const float vn = bfround(__fmaf_rn(one_m_b2, g * g, bfround(bf2f(v[i]) * b2)));
             const float cv = bfround(bfround(bfround(__fsqrt_rn(vn)) / dc) + eps);
             const float cn = bfround(__fmaf_rn(neg_step, mn / cv, bf2f(c[i])));
             const float pn = bfround(pw + cn);

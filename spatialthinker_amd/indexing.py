@@ -1,0 +1,182 @@
+"""Host-side integer bookkeeping of the packed (padding-free) Qwen2.5-VL layout.
+
+Product code (numpy, runs on the driver / dataloader side like the reference's
+`get_rope_index` does — verl/models/transformers/qwen2_vl.py:36-136).  The GPU never sees
+padded (B, S) tensors: everything is converted here into row indices of the packed stream.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------ M-RoPE position ids
+def get_rope_index(input_ids: np.ndarray, image_grid_thw: Optional[np.ndarray], attention_mask: Optional[np.ndarray], *,
+                   image_token_id: int, vision_start_token_id: int, spatial_merge_size: int = 2) -> np.ndarray:
+    """(3, S) M-RoPE ids of ONE sequence; same contract as the reference function
+    (verl/models/transformers/qwen2_vl.py:36-136, images only): text tokens advance all three
+    rows together, an image contributes a (t=0, h, w) grid shifted by the running offset, the
+    text after it resumes at max+1, masked positions hold 1."""
+    ids = np.asarray(input_ids).astype(np.int64)
+    S = ids.shape[0]
+    mask = np.ones(S, dtype=np.int64) if attention_mask is None else np.asarray(attention_mask).astype(np.int64)
+    if image_grid_thw is None or len(image_grid_thw) == 0:
+        pos = np.cumsum(mask) - 1
+        pos[mask == 0] = 1
+        return np.tile(pos, (3, 1))
+    keep = np.nonzero(mask == 1)[0]
+    toks = ids[keep]
+    is_img = toks == image_token_id
+    # an image block = maximal run of image tokens that follows a vision-start token
+    starts = np.nonzero(is_img & np.concatenate([[False], toks[:-1] == vision_start_token_id]))[0]
+    packed = np.empty((3, toks.shape[0]), dtype=np.int64)
+    cursor, nxt = 0, 0                     # cursor: token index, nxt: next position value
+    for img, st in enumerate(starts):
+        t, h, w = (int(v) for v in image_grid_thw[img])
+        gh, gw = h // spatial_merge_size, w // spatial_merge_size
+        n_txt = int(st) - cursor
+        packed[:, cursor:st] = nxt + np.arange(n_txt)
+        base = nxt + n_txt
+        n_img = t * gh * gw
+        grid = np.indices((t, gh, gw)).reshape(3, -1)
+        grid[0] = 0                         # images: temporal index scaled by second_per_grid_t = 0
+        packed[:, st:st + n_img] = grid + base
+        nxt = int(packed[:, st:st + n_img].max()) + 1
+        cursor = int(st) + n_img
+    packed[:, cursor:] = nxt + np.arange(toks.shape[0] - cursor)
+    out = np.ones((3, S), dtype=np.int64)
+    out[:, keep] = packed
+    return out
+
+
+# ------------------------------------------------------------------ vision tower indices
+def vision_window_index(grid_thw: np.ndarray, merge: int, window: int, patch: int):
+    """Window-major order of merged tokens + cumulative window lengths in patches (duplicates
+    dropped) — HF get_vision_window_index (transformers/vision_utils.py:124-188)."""
+    side = window // merge // patch
+    unit = merge * merge
+    order: List[np.ndarray] = []
+    cu = [0]
+    offset = 0
+    for t, h, w in np.asarray(grid_thw).tolist():
+        gh, gw = h // merge, w // merge
+        # HF pads by a FULL window when the size is already a multiple (side - x % side)
+        ph, pw = side - gh % side, side - gw % side
+        canvas = -np.ones((t, gh + ph, gw + pw), dtype=np.int64)
+        canvas[:, :gh, :gw] = np.arange(t * gh * gw).reshape(t, gh, gw)
+        nh, nw = (gh + ph) // side, (gw + pw) // side
+        tiles = canvas.reshape(t, nh, side, nw, side).swapaxes(2, 3).reshape(t * nh * nw, side * side)
+        for tile in tiles:
+            members = tile[tile >= 0]
+            if members.size:
+                order.append(members + offset)
+                cu.append(cu[-1] + members.size * unit)
+        offset += t * gh * gw
+    return np.concatenate(order).astype(np.int64), np.asarray(cu, dtype=np.int32)
+
+
+def vision_position_ids(grid_thw: np.ndarray, merge: int) -> np.ndarray:
+    """(N, 2) (h, w) coordinates in pixel_values row order (merge-block-major) — HF
+    get_vision_position_ids (transformers/vision_utils.py:81-121)."""
+    out = []
+    for t, h, w in np.asarray(grid_thw).tolist():
+        hh = np.arange(h)[:, None].repeat(w, 1)
+        ww = np.arange(w)[None, :].repeat(h, 0)
+        blk = lambda a: a.reshape(h // merge, merge, w // merge, merge).swapaxes(1, 2).reshape(-1)
+        out.append(np.tile(np.stack([blk(hh), blk(ww)], -1), (t, 1)))
+    return np.concatenate(out, 0).astype(np.int64)
+
+
+@dataclass
+class VisionPlan:
+    n_patches: int
+    patch_gather: np.ndarray        # (N,) int32: window-ordered row -> pixel_values row
+    merged_inverse: np.ndarray      # (N/4,) int32: original merged token -> window-ordered merged row
+    cu_window: np.ndarray           # int32
+    cu_image: np.ndarray            # int32 (per frame)
+    max_window: int
+    max_image: int
+    cos: np.ndarray                 # (N, hd/2) fp32, window-ordered
+    sin: np.ndarray
+
+
+def plan_vision(grid_thw: np.ndarray, *, merge: int, window: int, patch: int, head_dim: int) -> VisionPlan:
+    import torch
+    g = np.asarray(grid_thw).reshape(-1, 3)
+    unit = merge * merge
+    widx, cu_win = vision_window_index(g, merge, window, patch)
+    n = int((g[:, 0] * g[:, 1] * g[:, 2]).sum())
+    patch_gather = (widx[:, None] * unit + np.arange(unit)[None, :]).reshape(-1)
+    inv = np.empty_like(widx)
+    inv[widx] = np.arange(widx.shape[0])                # == argsort(widx)
+    lens = np.repeat(g[:, 1] * g[:, 2], g[:, 0])
+    cu_img = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    # rotary table: HF Qwen2_5_VisionRotaryEmbedding (modeling_qwen2_5_vl.py:125-135), dim = head_dim/2, theta 1e4
+    dim = head_dim // 2
+    inv_freq = (1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))).numpy()
+    pos = vision_position_ids(g, merge)[patch_gather]                                    # window order
+    ang = torch.from_numpy((pos.astype(np.float32)[:, :, None] * inv_freq[None, None, :]).reshape(n, -1))
+    return VisionPlan(n, patch_gather.astype(np.int32), inv.astype(np.int32), cu_win, cu_img,
+                      int(np.diff(cu_win).max()), int(lens.max()), ang.cos().numpy(), ang.sin().numpy())
+
+
+# ------------------------------------------------------------------ packing of (B, S) batches
+@dataclass
+class PackedBatch:
+    T: int                          # valid tokens
+    T_pad: int
+    ids: np.ndarray                 # (T_pad,) int32, pad rows = 0
+    pos: np.ndarray                 # (3, T_pad) int32
+    cu_seqlens: np.ndarray          # (B+1,) int32
+    max_seqlen: int
+    image_rows: np.ndarray          # (n_img_tokens,) int32 rows of the packed stream holding image features
+    embed_ids: np.ndarray           # (T_pad,) int32: token id, or -1 on image rows / pad rows (no embedding grad)
+    logit_rows: np.ndarray          # (Tr,) int32 packed rows whose NEXT token is a valid response token
+    labels: np.ndarray              # (Tr,) int64
+    out_index: np.ndarray           # (Tr,) int64 flat index into (B, R) where each log-prob lands
+    B: int
+    R: int
+
+
+def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: np.ndarray, response_length: int, *,
+               image_token_id: int, pad_multiple: int = 128) -> PackedBatch:
+    """The padding-free transformation of verl/workers/actor/dp_actor.py:86-104,136-139 done once on
+    the host: valid tokens are concatenated; log-probs are only needed at [:, -R-1:-1] of every row,
+    and only where the response mask is set, so the lm_head runs on exactly those rows."""
+    ids = np.asarray(input_ids)
+    mask = np.asarray(attention_mask).astype(bool)
+    B, S = ids.shape
+    R = response_length
+    pos = np.asarray(position_ids)
+    if pos.ndim == 2:                                   # text-only (B, S) -> replicate on the 3 rows
+        pos = np.repeat(pos[:, None, :], 3, axis=1)
+    lens = mask.sum(1)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    T_pad = max(round_up(T, pad_multiple), pad_multiple)
+    flat = np.nonzero(mask.reshape(-1))[0]
+    p_ids = np.zeros(T_pad, dtype=np.int32)
+    p_ids[:T] = ids.reshape(-1)[flat]
+    p_pos = np.zeros((3, T_pad), dtype=np.int32)
+    p_pos[:, :T] = pos.transpose(1, 0, 2).reshape(3, -1)[:, flat]
+    packed_row = -np.ones(B * S, dtype=np.int64)
+    packed_row[flat] = np.arange(T)
+    packed_row = packed_row.reshape(B, S)
+    # response slot j of row b sits at column S-R+j; its log-prob comes from the logits of column S-R+j-1
+    cols = np.arange(S - R, S)
+    valid = mask[:, cols] & mask[:, cols - 1]
+    bb, jj = np.nonzero(valid)
+    logit_rows = packed_row[bb, cols[jj] - 1]
+    labels = ids[bb, cols[jj]].astype(np.int64)
+    img_rows = np.nonzero(p_ids[:T] == image_token_id)[0].astype(np.int32)
+    embed_ids = p_ids.copy()
+    embed_ids[img_rows] = -1
+    embed_ids[T:] = -1
+    return PackedBatch(T, T_pad, p_ids, p_pos, cu, int(lens.max()) if B else 0, img_rows, embed_ids,
+                       logit_rows.astype(np.int32), labels, (bb * R + jj).astype(np.int64), B, R)

@@ -1,0 +1,546 @@
+"""Qwen2.5-VL on MI355X: explicit forward / backward over flat parameter buffers.
+
+No autograd, no tracing compiler: every layer is a fixed sequence of launches of the hand-written
+HIP kernels in libst_hip.so (through `ops`), with the activations a backward needs kept in HBM
+(288 GB per GPU makes per-layer recomputation — the reference's gradient checkpointing,
+verl/workers/fsdp_workers.py:220-221 — unnecessary: training costs 3x a forward instead of 4x).
+
+What this replaces in the reference: the HF `Qwen2_5_VLForConditionalGeneration` module loaded at
+verl/workers/fsdp_workers.py:193-207 and called at verl/workers/actor/dp_actor.py:118-124, plus the
+attention monkey-patch verl/models/transformers/qwen2_vl.py:139-189.
+
+HBM layout
+  * all weights live in ONE flat bf16 buffer (`ParamStore.flat`); gradients are a flat fp32 buffer with
+    identical offsets (one fused AdamW launch, bucketed all-reduce = slices of one tensor);
+  * q/k/v and gate/up projections are stored fused ([q|k|v] rows, [gate|up] rows) so each is one GEMM;
+  * the ViT MLP width 3420 is zero-padded to 3456 and the patch-embed K 1176 to 1216 (multiples of 64 for
+    the MFMA K loop); the pads stay exactly zero under training (zero gradient, decay of zero);
+  * every weight used in a backward dX GEMM also has a transposed copy (refreshed after each optimizer
+    step) so that all GEMMs are the K-contiguous "NT" form the kernel implements.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import indexing as ix
+from . import ops
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+@dataclass
+class VLConfig:
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_layers: int = 28
+    num_heads: int = 28
+    num_kv_heads: int = 4
+    vocab_size: int = 152064
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: List[int] = field(default_factory=lambda: [16, 24, 24])
+    tie_word_embeddings: bool = False
+    v_depth: int = 32
+    v_hidden: int = 1280
+    v_heads: int = 16
+    v_intermediate: int = 3420
+    v_patch: int = 14
+    v_temporal_patch: int = 2
+    v_merge: int = 2
+    v_window: int = 112
+    v_fullatt: List[int] = field(default_factory=lambda: [7, 15, 23, 31])
+    v_in_channels: int = 3
+    image_token_id: int = 151655
+    vision_start_token_id: int = 151652
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads
+
+    @property
+    def v_head_dim(self):
+        return self.v_hidden // self.v_heads
+
+    @property
+    def qkv_width(self):
+        return (self.num_heads + 2 * self.num_kv_heads) * self.head_dim
+
+    @property
+    def v_inter_pad(self):
+        return ix.round_up(self.v_intermediate, 64)
+
+    @property
+    def patch_k(self):
+        return self.v_in_channels * self.v_temporal_patch * self.v_patch * self.v_patch
+
+    @property
+    def patch_k_pad(self):
+        return ix.round_up(self.patch_k, 64)
+
+    @staticmethod
+    def qwen2_5_vl_7b():
+        return VLConfig()
+
+    @staticmethod
+    def qwen2_5_vl_3b():
+        return VLConfig(hidden_size=2048, intermediate_size=11008, num_layers=36, num_heads=16, num_kv_heads=2,
+                        vocab_size=151936, tie_word_embeddings=True)
+
+    @staticmethod
+    def from_hf_dict(d: dict) -> "VLConfig":
+        t = d.get("text_config", d)
+        v = d["vision_config"]
+        rope = t.get("rope_parameters") or t.get("rope_scaling") or {}
+        return VLConfig(hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"], num_layers=t["num_hidden_layers"],
+                        num_heads=t["num_attention_heads"], num_kv_heads=t["num_key_value_heads"], vocab_size=t["vocab_size"],
+                        rms_eps=t.get("rms_norm_eps", 1e-6), rope_theta=rope.get("rope_theta", t.get("rope_theta", 1e6)),
+                        mrope_section=list(rope.get("mrope_section", [16, 24, 24])),
+                        tie_word_embeddings=bool(d.get("tie_word_embeddings", t.get("tie_word_embeddings", False))),
+                        v_depth=v["depth"], v_hidden=v["hidden_size"], v_heads=v["num_heads"], v_intermediate=v["intermediate_size"],
+                        v_patch=v.get("patch_size", 14), v_temporal_patch=v.get("temporal_patch_size", 2),
+                        v_merge=v.get("spatial_merge_size", 2), v_window=v.get("window_size", 112),
+                        v_fullatt=list(v.get("fullatt_block_indexes", [7, 15, 23, 31])), v_in_channels=v.get("in_channels", 3),
+                        image_token_id=d.get("image_token_id", 151655), vision_start_token_id=d.get("vision_start_token_id", 151652))
+
+    def n_params(self) -> int:
+        return sum(int(np.prod(s)) for s in param_layout(self).values())
+
+    def flops_forward(self, seqlens: List[int], patches_per_image: List[int], logit_rows: Optional[int] = None) -> float:
+        """Algorithmic forward FLOPs (matmul 2MNK, causal attention at half) — SURVEY.md §8(d), ViT included."""
+        H, I, D = self.hidden_size, self.intermediate_size, self.head_dim
+        T = sum(seqlens)
+        per_tok = 2 * (H * self.qkv_width + H * H + 3 * H * I)
+        fl = per_tok * T * self.num_layers
+        fl += sum(2 * D * self.num_heads * s * s for s in seqlens) * self.num_layers            # QK^T + PV, causal half
+        rows = T if logit_rows is None else logit_rows
+        fl += 2 * H * self.vocab_size * rows
+        vh, vi, hd = self.v_hidden, self.v_intermediate, self.v_head_dim
+        N = sum(patches_per_image)
+        fl += N * self.v_depth * 2 * (vh * 3 * vh + vh * vh + 3 * vh * vi) + N * 2 * self.patch_k * vh
+        fl += (N // 4) * 2 * (4 * vh * 4 * vh + 4 * vh * H)
+        n_full = len(self.v_fullatt)
+        fl += sum(4 * hd * self.v_heads * (n_full * n * n + (self.v_depth - n_full) * n * 64) for n in patches_per_image)
+        return float(fl)
+
+
+# ------------------------------------------------------------------------------------------
+def param_layout(c: VLConfig) -> "Dict[str, Tuple[int, ...]]":
+    """name -> shape of the engine's own (fused / padded) parameter tensors, in flat-buffer order."""
+    H, I, V = c.hidden_size, c.intermediate_size, c.vocab_size
+    vh, vi = c.v_hidden, c.v_inter_pad
+    m = c.v_merge ** 2 * vh
+    L: Dict[str, Tuple[int, ...]] = {"v.patch_embed": (vh, c.patch_k_pad)}
+    for i in range(c.v_depth):
+        p = f"v.{i}."
+        L.update({p + "norm1": (vh,), p + "qkv_w": (3 * vh, vh), p + "qkv_b": (3 * vh,), p + "proj_w": (vh, vh), p + "proj_b": (vh,),
+                  p + "norm2": (vh,), p + "gu_w": (2 * vi, vh), p + "gu_b": (2 * vi,), p + "down_w": (vh, vi), p + "down_b": (vh,)})
+    L.update({"v.merger.ln_q": (vh,), "v.merger.fc1_w": (m, m), "v.merger.fc1_b": (m,), "v.merger.fc2_w": (H, m), "v.merger.fc2_b": (H,)})
+    L["embed"] = (V, H)
+    for i in range(c.num_layers):
+        p = f"l.{i}."
+        L.update({p + "in_norm": (H,), p + "qkv_w": (c.qkv_width, H), p + "qkv_b": (c.qkv_width,), p + "o_w": (H, H),
+                  p + "post_norm": (H,), p + "gu_w": (2 * I, H), p + "down_w": (H, I)})
+    L["final_norm"] = (H,)
+    if not c.tie_word_embeddings:
+        L["lm_head"] = (V, H)
+    return L
+
+
+def _needs_transpose(name: str) -> bool:
+    return name.endswith(("qkv_w", "proj_w", "gu_w", "down_w", "o_w", "fc1_w", "fc2_w")) or name in ("lm_head", "embed")
+
+
+class ParamStore:
+    """Flat bf16 weights (+ optional fp32 grads, bf16 AdamW states, transposed copies)."""
+
+    def __init__(self, cfg: VLConfig, device="cuda", trainable: bool = False):
+        self.cfg, self.device, self.trainable = cfg, device, trainable
+        self.layout = param_layout(cfg)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for name, shape in self.layout.items():
+            self.offsets[name] = off
+            off += ix.round_up(int(np.prod(shape)), 64)          # 128-byte aligned slices
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=BF16, device=device)
+        self.w = {n: self._view(self.flat, n) for n in self.layout}
+        self.grad = self.g = None
+        self.m = self.v = self.c = None
+        self.wT: Dict[str, torch.Tensor] = {}
+        if trainable:
+            self.grad = torch.zeros(off, dtype=F32, device=device)
+            self.g = {n: self._view(self.grad, n) for n in self.layout}
+            self.m = torch.zeros(off, dtype=BF16, device=device)
+            self.v = torch.zeros(off, dtype=BF16, device=device)
+            self.c = torch.zeros(off, dtype=BF16, device=device)
+            for n, shape in self.layout.items():
+                if _needs_transpose(n) and not (n == "embed" and not cfg.tie_word_embeddings):
+                    self.wT[n] = torch.empty(shape[1], shape[0], dtype=BF16, device=device)
+
+    def _view(self, flat, name):
+        shape = self.layout[name]
+        o = self.offsets[name]
+        return flat[o:o + int(np.prod(shape))].view(*shape)
+
+    def refresh_transposes(self):
+        for n, t in self.wT.items():
+            ops.transpose(self.w[n], out=t)
+
+    # ---- HF state_dict interop (names of transformers Qwen2_5_VLForConditionalGeneration) -------------
+    def load_hf_state_dict(self, sd: Dict[str, torch.Tensor]):
+        c = self.cfg
+
+        def put(name, t):
+            t = t.to(dtype=BF16, device=self.device)
+            dst = self.w[name]
+            if dst.shape == t.shape:
+                dst.copy_(t)
+            elif dst.dim() == 2:
+                dst.zero_()
+                dst[:t.shape[0], :t.shape[1]].copy_(t)
+            else:
+                dst.zero_()
+                dst[:t.shape[0]].copy_(t)
+
+        vi, vip = c.v_intermediate, c.v_inter_pad
+        put("v.patch_embed", sd["model.visual.patch_embed.proj.weight"].reshape(c.v_hidden, -1))
+        for i in range(c.v_depth):
+            s, p = f"model.visual.blocks.{i}.", f"v.{i}."
+            put(p + "norm1", sd[s + "norm1.weight"]); put(p + "norm2", sd[s + "norm2.weight"])
+            put(p + "qkv_w", sd[s + "attn.qkv.weight"]); put(p + "qkv_b", sd[s + "attn.qkv.bias"])
+            put(p + "proj_w", sd[s + "attn.proj.weight"]); put(p + "proj_b", sd[s + "attn.proj.bias"])
+            gu = torch.zeros(2 * vip, c.v_hidden); gb = torch.zeros(2 * vip)
+            gu[:vi] = sd[s + "mlp.gate_proj.weight"].float(); gu[vip:vip + vi] = sd[s + "mlp.up_proj.weight"].float()
+            gb[:vi] = sd[s + "mlp.gate_proj.bias"].float(); gb[vip:vip + vi] = sd[s + "mlp.up_proj.bias"].float()
+            put(p + "gu_w", gu); put(p + "gu_b", gb)
+            put(p + "down_w", sd[s + "mlp.down_proj.weight"]); put(p + "down_b", sd[s + "mlp.down_proj.bias"])
+        put("v.merger.ln_q", sd["model.visual.merger.ln_q.weight"])
+        put("v.merger.fc1_w", sd["model.visual.merger.mlp.0.weight"]); put("v.merger.fc1_b", sd["model.visual.merger.mlp.0.bias"])
+        put("v.merger.fc2_w", sd["model.visual.merger.mlp.2.weight"]); put("v.merger.fc2_b", sd["model.visual.merger.mlp.2.bias"])
+        put("embed", sd["model.language_model.embed_tokens.weight"])
+        for i in range(c.num_layers):
+            s, p = f"model.language_model.layers.{i}.", f"l.{i}."
+            put(p + "in_norm", sd[s + "input_layernorm.weight"]); put(p + "post_norm", sd[s + "post_attention_layernorm.weight"])
+            put(p + "qkv_w", torch.cat([sd[s + f"self_attn.{x}_proj.weight"].float() for x in "qkv"], 0))
+            put(p + "qkv_b", torch.cat([sd[s + f"self_attn.{x}_proj.bias"].float() for x in "qkv"], 0))
+            put(p + "o_w", sd[s + "self_attn.o_proj.weight"])
+            put(p + "gu_w", torch.cat([sd[s + "mlp.gate_proj.weight"].float(), sd[s + "mlp.up_proj.weight"].float()], 0))
+            put(p + "down_w", sd[s + "mlp.down_proj.weight"])
+        put("final_norm", sd["model.language_model.norm.weight"])
+        if not c.tie_word_embeddings:
+            put("lm_head", sd["lm_head.weight"])
+        if self.trainable:
+            self.refresh_transposes()
+
+    def export_hf(self, source: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Un-fuse / un-pad `source` (default: the weights; pass self.g for gradients) back to HF names."""
+        c = self.cfg
+        src = self.w if source is None else source
+        H, D = c.hidden_size, c.head_dim
+        nq, nkv = c.num_heads * D, c.num_kv_heads * D
+        vi, vip, I = c.v_intermediate, c.v_inter_pad, c.intermediate_size
+        out = {"model.visual.patch_embed.proj.weight": src["v.patch_embed"][:, :c.patch_k].reshape(
+            c.v_hidden, c.v_in_channels, c.v_temporal_patch, c.v_patch, c.v_patch)}
+        for i in range(c.v_depth):
+            s, p = f"model.visual.blocks.{i}.", f"v.{i}."
+            out.update({s + "norm1.weight": src[p + "norm1"], s + "norm2.weight": src[p + "norm2"],
+                        s + "attn.qkv.weight": src[p + "qkv_w"], s + "attn.qkv.bias": src[p + "qkv_b"],
+                        s + "attn.proj.weight": src[p + "proj_w"], s + "attn.proj.bias": src[p + "proj_b"],
+                        s + "mlp.gate_proj.weight": src[p + "gu_w"][:vi], s + "mlp.up_proj.weight": src[p + "gu_w"][vip:vip + vi],
+                        s + "mlp.gate_proj.bias": src[p + "gu_b"][:vi], s + "mlp.up_proj.bias": src[p + "gu_b"][vip:vip + vi],
+                        s + "mlp.down_proj.weight": src[p + "down_w"][:, :vi], s + "mlp.down_proj.bias": src[p + "down_b"]})
+        out.update({"model.visual.merger.ln_q.weight": src["v.merger.ln_q"], "model.visual.merger.mlp.0.weight": src["v.merger.fc1_w"],
+                    "model.visual.merger.mlp.0.bias": src["v.merger.fc1_b"], "model.visual.merger.mlp.2.weight": src["v.merger.fc2_w"],
+                    "model.visual.merger.mlp.2.bias": src["v.merger.fc2_b"], "model.language_model.embed_tokens.weight": src["embed"]})
+        for i in range(c.num_layers):
+            s, p = f"model.language_model.layers.{i}.", f"l.{i}."
+            qw, qb = src[p + "qkv_w"], src[p + "qkv_b"]
+            out.update({s + "input_layernorm.weight": src[p + "in_norm"], s + "post_attention_layernorm.weight": src[p + "post_norm"],
+                        s + "self_attn.q_proj.weight": qw[:nq], s + "self_attn.k_proj.weight": qw[nq:nq + nkv],
+                        s + "self_attn.v_proj.weight": qw[nq + nkv:], s + "self_attn.q_proj.bias": qb[:nq],
+                        s + "self_attn.k_proj.bias": qb[nq:nq + nkv], s + "self_attn.v_proj.bias": qb[nq + nkv:],
+                        s + "self_attn.o_proj.weight": src[p + "o_w"], s + "mlp.gate_proj.weight": src[p + "gu_w"][:I],
+                        s + "mlp.up_proj.weight": src[p + "gu_w"][I:], s + "mlp.down_proj.weight": src[p + "down_w"]})
+        out["model.language_model.norm.weight"] = src["final_norm"]
+        if not c.tie_word_embeddings:
+            out["lm_head.weight"] = src["lm_head"]
+        return out
+
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        """normal(0, std) matrices, unit norm weights, zero biases (synthetic benchmarks: SURVEY.md §8d)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        c = self.cfg
+        for n, t in self.w.items():
+            if n.endswith(("norm", "norm1", "norm2", "ln_q")):
+                t.fill_(1.0)
+            elif n.endswith("_b"):
+                t.zero_()
+            else:
+                t.copy_((torch.randn(t.shape, generator=g, device=self.device, dtype=F32) * std).to(BF16))
+        vi, vip = c.v_intermediate, c.v_inter_pad
+        if vip != vi:
+            for i in range(c.v_depth):
+                self.w[f"v.{i}.gu_w"][vi:vip].zero_(); self.w[f"v.{i}.gu_w"][vip + vi:].zero_()
+                self.w[f"v.{i}.down_w"][:, vi:].zero_()
+        if c.patch_k_pad != c.patch_k:
+            self.w["v.patch_embed"][:, c.patch_k:].zero_()
+        if self.trainable:
+            self.refresh_transposes()
+
+
+# ------------------------------------------------------------------------------------------
+@dataclass
+class DeviceBatch:
+    """A packed micro-batch resident in HBM (built from indexing.PackedBatch + VisionPlan)."""
+    pk: ix.PackedBatch
+    ids: torch.Tensor
+    embed_ids: torch.Tensor
+    cu: torch.Tensor
+    cos: torch.Tensor
+    sin: torch.Tensor
+    image_rows: torch.Tensor
+    logit_rows: torch.Tensor
+    labels: torch.Tensor
+    out_index: torch.Tensor
+    Tr_pad: int
+    vis: Optional[dict] = None
+
+
+class Qwen25VL:
+    def __init__(self, cfg: VLConfig, params: ParamStore):
+        self.cfg, self.p = cfg, params
+        D = cfg.head_dim
+        self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=F32) / D))).to(params.device)   # HF :523
+        self.scale = D ** -0.5
+        self.v_scale = cfg.v_head_dim ** -0.5
+
+    # ---------------------------------------------------------------- batch staging
+    def stage(self, input_ids, attention_mask, position_ids, response_length: int, pixel_values=None, image_grid_thw=None) -> DeviceBatch:
+        c, dev = self.cfg, self.p.device
+        pk = ix.pack_batch(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, image_token_id=c.image_token_id)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
+        pos = t(pk.pos, I32)
+        cos, sin = ops.mrope_table(pos, self.inv_freq, c.head_dim, c.mrope_section)
+        Tr = len(pk.logit_rows)
+        Tr_pad = max(ix.round_up(Tr, 128), 128)
+        rows = np.zeros(Tr_pad, dtype=np.int32); rows[:Tr] = pk.logit_rows
+        labels = np.full(Tr_pad, -1, dtype=np.int64); labels[:Tr] = pk.labels
+        vis = None
+        if pixel_values is not None and len(pk.image_rows):
+            plan = ix.plan_vision(_np(image_grid_thw), merge=c.v_merge, window=c.v_window, patch=c.v_patch, head_dim=c.v_head_dim)
+            assert plan.n_patches // (c.v_merge ** 2) == len(pk.image_rows), "image tokens != image features"
+            N_pad = ix.round_up(plan.n_patches, 256)      # N_pad/4 (merger rows) stays a multiple of 64
+            gather = np.zeros(N_pad, dtype=np.int32); gather[:plan.n_patches] = plan.patch_gather
+            vcos = np.zeros((N_pad, c.v_head_dim // 2), np.float32); vcos[:plan.n_patches] = plan.cos
+            vsin = np.zeros_like(vcos); vsin[:plan.n_patches] = plan.sin
+            px = pixel_values if torch.is_tensor(pixel_values) else torch.from_numpy(np.asarray(pixel_values))
+            vis = dict(N=plan.n_patches, N_pad=N_pad, px=px.to(device=dev, dtype=F32, non_blocking=True), gather=t(gather, I32),
+                       inverse=t(plan.merged_inverse, I32), cu_win=t(plan.cu_window, I32), cu_img=t(plan.cu_image, I32),
+                       max_win=plan.max_window, max_img=plan.max_image, cos=t(vcos, F32), sin=t(vsin, F32))
+        return DeviceBatch(pk, t(pk.ids, I32), t(pk.embed_ids, I32), t(pk.cu_seqlens, I32), cos, sin, t(pk.image_rows, I32),
+                           t(rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, vis)
+
+    # ---------------------------------------------------------------- vision tower
+    def _vit_forward(self, b: DeviceBatch, save: Optional[list]):
+        c, w, v = self.cfg, self.p.w, b.vis
+        N, Np = v["N"], v["N_pad"]
+        heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
+        px = ops.cast_pad(v["px"], c.patch_k_pad)                                    # (N, Kpad) bf16, pixel order
+        pxw = torch.zeros(Np, c.patch_k_pad, dtype=BF16, device=px.device)
+        ops.rows_gather(px, v["gather"][:N], out=pxw[:N])                            # window order (row gather commutes with the GEMM)
+        x = ops.gemm_nt(pxw, w["v.patch_embed"])                                     # HF patch_embed :99-122
+        if save is not None:
+            save.append(("pe", pxw))
+        for i in range(c.v_depth):
+            p = f"v.{i}."
+            h1, r1 = ops.rmsnorm_fwd(x, w[p + "norm1"], 1e-6)
+            qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+            ops.rope_apply_(qkv, v["cos"], v["sin"], 2 * heads, hd)
+            full = i in c.v_fullatt
+            cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
+            a = torch.zeros(Np, vh, dtype=BF16, device=x.device)
+            _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a)
+            x1 = ops.gemm_nt(a, w[p + "proj_w"], bias=w[p + "proj_b"], residual=x)
+            h2, r2 = ops.rmsnorm_fwd(x1, w[p + "norm2"], 1e-6)
+            gu = ops.gemm_nt(h2, w[p + "gu_w"], bias=w[p + "gu_b"])
+            m = ops.swiglu_fwd(gu)
+            x2 = ops.gemm_nt(m, w[p + "down_w"], bias=w[p + "down_b"], residual=x1)
+            if save is not None:
+                save.append((x, r1, h1, qkv, a, lse, x1, r2, h2, gu, m))
+            x = x2
+        hq, rq = ops.rmsnorm_fwd(x, w["v.merger.ln_q"], 1e-6)
+        hm = hq.view(Np // 4, 4 * vh)
+        f1 = ops.gemm_nt(hm, w["v.merger.fc1_w"], bias=w["v.merger.fc1_b"])
+        ge = ops.gelu_fwd(f1)
+        f2 = ops.gemm_nt(ge, w["v.merger.fc2_w"], bias=w["v.merger.fc2_b"])          # (Np/4, H) window order
+        img = ops.rows_gather(f2, v["inverse"])                                       # back to image order (HF :468-470)
+        if save is not None:
+            save.append((x, rq, hq, f1, ge))
+        return img
+
+    def _vit_backward(self, b: DeviceBatch, saved: list, d_img: torch.Tensor):
+        c, w, g, wT, v = self.cfg, self.p.w, self.p.g, self.p.wT, b.vis
+        N, Np = v["N"], v["N_pad"]
+        heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
+        x, rq, hq, f1, ge = saved.pop()
+        df2 = torch.zeros(Np // 4, c.hidden_size, dtype=BF16, device=d_img.device)
+        ops.rows_scatter_(df2, v["inverse"], d_img)
+        self._dw(g["v.merger.fc2_w"], df2, ge, g["v.merger.fc2_b"])
+        dge = ops.gemm_nt(df2, wT["v.merger.fc2_w"])
+        df1 = ops.gelu_bwd(f1, dge)
+        self._dw(g["v.merger.fc1_w"], df1, hq.view(Np // 4, 4 * vh), g["v.merger.fc1_b"])
+        dhq = ops.gemm_nt(df1, wT["v.merger.fc1_w"]).view(Np, vh)
+        dx = ops.rmsnorm_bwd(x, w["v.merger.ln_q"], rq, dhq, dw_accum=g["v.merger.ln_q"])
+        for i in reversed(range(c.v_depth)):
+            p = f"v.{i}."
+            x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved.pop()
+            self._dw(g[p + "down_w"], dx, m, g[p + "down_b"])
+            dm = ops.gemm_nt(dx, wT[p + "down_w"])
+            dgu = ops.swiglu_bwd(gu, dm)
+            self._dw(g[p + "gu_w"], dgu, h2, g[p + "gu_b"])
+            dh2 = ops.gemm_nt(dgu, wT[p + "gu_w"])
+            dx1 = ops.rmsnorm_bwd(x1, w[p + "norm2"], r2, dh2, dres=dx, dw_accum=g[p + "norm2"])
+            self._dw(g[p + "proj_w"], dx1, a, g[p + "proj_b"])
+            da = ops.gemm_nt(dx1, wT[p + "proj_w"])
+            full = i in c.v_fullatt
+            cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
+            dqkv = torch.zeros_like(qkv)
+            ops.attn_bwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], a, da, lse, cu, mx, heads, heads, hd, self.v_scale, False,
+                         dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:])
+            ops.rope_apply_(dqkv, v["cos"], v["sin"], 2 * heads, hd, inverse=True)
+            self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
+            dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
+            dx = ops.rmsnorm_bwd(x0, w[p + "norm1"], r1, dh1, dres=dx1, dw_accum=g[p + "norm1"])
+        (_, pxw) = saved.pop()
+        self._dw(g["v.patch_embed"], dx, pxw, None)
+
+    # ---------------------------------------------------------------- helpers
+    def _dw(self, gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gb: Optional[torch.Tensor]):
+        """gw (N,K) fp32 += dy(M,N)^T x(M,K); gb (N,) += column sums of dy.  M is a multiple of 64 (padded rows are zero)."""
+        ops.gemm_nt(ops.transpose(dy), ops.transpose(x), out_f32=gw, accumulate=True)
+        if gb is not None:
+            ops.colsum(dy, out_f32=gb, accumulate=True)
+
+    def _embed(self, b: DeviceBatch, save_vit: Optional[list]):
+        x = ops.embed_gather(self.p.w["embed"], b.ids)
+        if b.vis is not None:
+            img = self._vit_forward(b, save_vit)
+            ops.rows_scatter_(x, b.image_rows, img)                                   # masked_scatter, HF :1209-1215
+        if b.pk.T_pad > b.pk.T:
+            x[b.pk.T:].zero_()
+        return x
+
+    # ---------------------------------------------------------------- language model
+    def _lm_layer_fwd(self, i: int, x0: torch.Tensor, b: DeviceBatch, save: Optional[list], kv_out=None):
+        c, w = self.cfg, self.p.w
+        p = f"l.{i}."
+        D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
+        h1, r1 = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps)
+        qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+        ops.rope_apply_(qkv, b.cos, b.sin, nq + nkv, D)
+        q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
+        if kv_out is not None:
+            kv_out(i, k, v)
+        a = torch.zeros(x0.shape[0], nq * D, dtype=BF16, device=x0.device)
+        _, lse = ops.attn_fwd(q, k, v, b.cu, b.pk.max_seqlen, nq, nkv, D, self.scale, True, out=a)
+        x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x0)
+        h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
+        gu = ops.gemm_nt(h2, w[p + "gu_w"])
+        m = ops.swiglu_fwd(gu)
+        x2 = ops.gemm_nt(m, w[p + "down_w"], residual=x1)
+        if save is not None:
+            save.append((x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m))
+        return x2
+
+    def _lm_layer_bwd(self, i: int, dx2: torch.Tensor, b: DeviceBatch, saved):
+        c, w, g, wT = self.cfg, self.p.w, self.p.g, self.p.wT
+        p = f"l.{i}."
+        D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
+        x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved
+        self._dw(g[p + "down_w"], dx2, m, None)
+        dm = ops.gemm_nt(dx2, wT[p + "down_w"])
+        dgu = ops.swiglu_bwd(gu, dm)
+        self._dw(g[p + "gu_w"], dgu, h2, None)
+        dh2 = ops.gemm_nt(dgu, wT[p + "gu_w"])
+        dx1 = ops.rmsnorm_bwd(x1, w[p + "post_norm"], r2, dh2, dres=dx2, dw_accum=g[p + "post_norm"])
+        self._dw(g[p + "o_w"], dx1, a, None)
+        da = ops.gemm_nt(dx1, wT[p + "o_w"])
+        dqkv = torch.zeros_like(qkv)
+        q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
+        ops.attn_bwd(q, k, v, a, da, lse, b.cu, b.pk.max_seqlen, nq, nkv, D, self.scale, True,
+                     dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:])
+        ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
+        self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
+        dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
+        return ops.rmsnorm_bwd(x0, w[p + "in_norm"], r1, dh1, dres=dx1, dw_accum=g[p + "in_norm"])
+
+    def _head_fwd(self, x: torch.Tensor, b: DeviceBatch, temperature: float):
+        c, w = self.cfg, self.p.w
+        xr = ops.rows_gather(x, b.logit_rows)                       # only rows that predict a response token
+        hn, rn = ops.rmsnorm_fwd(xr, w["final_norm"], c.rms_eps)
+        head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
+        logits = ops.gemm_nt(hn, head)
+        logp, lse = ops.logprob_fwd(logits, b.labels, temperature)
+        return xr, hn, rn, logits, logp, lse
+
+    # ---------------------------------------------------------------- public entry points
+    @torch.no_grad()
+    def log_probs(self, b: DeviceBatch, temperature: float = 1.0) -> torch.Tensor:
+        """(B, R) fp32 log-probs of the response tokens — DataParallelPPOActor._forward_micro_batch
+        (verl/workers/actor/dp_actor.py:64-153), no-grad use."""
+        x = self._embed(b, None)
+        for i in range(self.cfg.num_layers):
+            x = self._lm_layer_fwd(i, x, b, None)
+        *_, logp, _ = self._head_fwd(x, b, temperature)
+        out = torch.zeros(b.pk.B * b.pk.R, dtype=F32, device=x.device)
+        out.index_copy_(0, b.out_index, logp[:len(b.out_index)])
+        return out.view(b.pk.B, b.pk.R)
+
+    @torch.no_grad()
+    def forward_backward(self, b: DeviceBatch, loss_inputs: dict, temperature: float = 1.0, **loss_kw):
+        """One micro-batch of update_policy (dp_actor.py:240-278): forward, GRPO loss, backward into the
+        flat fp32 gradient buffer (accumulating).  loss_inputs: old_log_probs, advantages, [ref_log_probs],
+        response_mask — all (B, R) device tensors.  Returns (log_probs (B,R), metrics (8,) device)."""
+        c, g, wT = self.cfg, self.p.g, self.p.wT
+        vit_saved: list = []
+        x = self._embed(b, vit_saved)
+        saved = []
+        for i in range(c.num_layers):
+            x = self._lm_layer_fwd(i, x, b, saved)
+        xr, hn, rn, logits, logp, lse = self._head_fwd(x, b, temperature)
+        Tr, n = len(b.out_index), b.pk.B * b.pk.R
+        lp_full = torch.zeros(n, dtype=F32, device=x.device)
+        lp_full.index_copy_(0, b.out_index, logp[:Tr])
+        flat = lambda k: loss_inputs[k].reshape(-1).contiguous()
+        ref = flat("ref_log_probs") if loss_inputs.get("ref_log_probs") is not None else None
+        gfull, metrics = ops.grpo_loss(lp_full, flat("old_log_probs").float(), ref.float() if ref is not None else None,
+                                       flat("advantages").float(), flat("response_mask").to(I64), **loss_kw)
+        grow = torch.zeros(b.Tr_pad, dtype=F32, device=x.device)
+        grow[:Tr] = gfull.index_select(0, b.out_index)
+        ops.logprob_bwd_(logits, b.labels, lse, grow, temperature)                       # logits buffer now holds dlogits
+        head_name = "embed" if c.tie_word_embeddings else "lm_head"
+        self._dw(g[head_name], logits, hn, None)
+        dhn = ops.gemm_nt(logits, wT[head_name])
+        dxr = ops.rmsnorm_bwd(xr, self.p.w["final_norm"], rn, dhn, dw_accum=g["final_norm"])
+        dx = torch.zeros_like(x)
+        ops.rows_scatter_(dx, b.logit_rows[:Tr], dxr[:Tr])
+        for i in reversed(range(c.num_layers)):
+            dx = self._lm_layer_bwd(i, dx, b, saved.pop())
+        ops.embed_grad_(g["embed"], b.embed_ids, dx)
+        if b.vis is not None:
+            d_img = ops.rows_gather(dx, b.image_rows)
+            self._vit_backward(b, vit_saved, d_img)
+        return lp_full.view(b.pk.B, b.pk.R), metrics
+
+
+def _np(x):
+    if x is None:
+        return None
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)

@@ -336,7 +336,7 @@ def gen_model():
                            intermediate_size=c["v_intermediate"], out_hidden_size=c["hidden_size"], patch_size=c["v_patch"],
                            spatial_merge_size=c["v_merge"], temporal_patch_size=c["v_temporal_patch"],
                            window_size=c["v_window"], fullatt_block_indexes=c["v_fullatt"], in_channels=c["v_in_channels"]),
-        image_token_id=c["image_token_id"], video_token_id=989, vision_start_token_id=c["vision_start_token_id"],
+        image_token_id=c["image_token_id"], video_token_id=1009, vision_start_token_id=c["vision_start_token_id"],
         vision_end_token_id=tiny.VISION_END, tie_word_embeddings=False, bos_token_id=None, eos_token_id=tiny.EOS_ID,
         pad_token_id=tiny.PAD_ID)
     cfg._attn_implementation = "sdpa"
@@ -347,7 +347,7 @@ def gen_model():
     assert not unexpected and all("inv_freq" in m for m in missing), (missing, unexpected)
 
     proc = types.SimpleNamespace(
-        tokenizer=_FakeTok({"<|image_pad|>": c["image_token_id"], "<|video_pad|>": 989, "<|vision_start|>": c["vision_start_token_id"]}),
+        tokenizer=_FakeTok({"<|image_pad|>": c["image_token_id"], "<|video_pad|>": 1009, "<|vision_start|>": c["vision_start_token_id"]}),
         image_processor=types.SimpleNamespace(merge_size=2))
     batch = tiny.make_batch(c)
     ids, mask, P, R = batch["input_ids"], batch["attention_mask"], batch["P"], batch["R"]

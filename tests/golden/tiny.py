@@ -10,11 +10,11 @@ import numpy as np
 
 TINY = dict(
     hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1,
-    vocab_size=1000, rms_eps=1e-6, rope_theta=1e6, mrope_section=[16, 24, 24], tie_word_embeddings=False,
+    vocab_size=1024, rms_eps=1e-6, rope_theta=1e6, mrope_section=[16, 24, 24], tie_word_embeddings=False,
     v_depth=3, v_hidden=320, v_heads=4, v_intermediate=200, v_patch=14, v_temporal_patch=2, v_merge=2,
-    v_window=56, v_fullatt=[1], v_in_channels=3, image_token_id=990, vision_start_token_id=991,
+    v_window=56, v_fullatt=[1], v_in_channels=3, image_token_id=1010, vision_start_token_id=1011,
 )
-VISION_END, PAD_ID, EOS_ID = 992, 993, 994
+VISION_END, PAD_ID, EOS_ID = 1012, 1013, 1014
 
 
 def param_shapes(c: dict) -> "dict[str, tuple]":

@@ -352,3 +352,28 @@ def test_attn_fwd(ops, lens, n_q, n_kv, D, causal):
     want2 = Q.dense_attention(xf2[:, :n_q * D].reshape(T, n_q, D), xf2[:, n_q * D:(n_q + n_kv) * D].reshape(T, n_kv, D),
                               xf2[:, (n_q + n_kv) * D:].reshape(T, n_kv, D), cu, causal).reshape(T, n_q * D)
     assert np.abs(out2.float().cpu().numpy() - want2.numpy()).max() < 2e-2
+
+
+@pytest.mark.parametrize("lens,n_q,n_kv,D,causal", [
+    ([5], 2, 1, 128, True), ([130, 64, 1, 257], 4, 2, 128, True), ([200, 77], 7, 1, 128, True),
+    ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False)])
+def test_attn_bwd(ops, lens, n_q, n_kv, D, causal):
+    rs = np.random.RandomState(sum(lens) + D + 1)
+    qkv, cu = _attn_case(rs, lens, n_q, n_kv, D)
+    T = qkv.shape[0]
+    x = qkv.cuda()
+    q, k, v = x[:, :n_q * D], x[:, n_q * D:(n_q + n_kv) * D], x[:, (n_q + n_kv) * D:]
+    scale = D ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, dev(cu), max(lens), n_q, n_kv, D, scale, causal)
+    do = bf(rs.standard_normal((T, n_q * D)))
+    dqkv = torch.zeros_like(x)
+    dq, dk, dv = dqkv[:, :n_q * D], dqkv[:, n_q * D:(n_q + n_kv) * D], dqkv[:, (n_q + n_kv) * D:]
+    ops.attn_bwd(q, k, v, out, do.cuda(), lse, dev(cu), max(lens), n_q, n_kv, D, scale, causal, dq, dk, dv)
+    xf = qkv.float().clone().requires_grad_(True)
+    o = Q.dense_attention(xf[:, :n_q * D].reshape(T, n_q, D), xf[:, n_q * D:(n_q + n_kv) * D].reshape(T, n_kv, D),
+                          xf[:, (n_q + n_kv) * D:].reshape(T, n_kv, D), cu, causal).reshape(T, n_q * D)
+    o.backward(do.float())
+    got, want = dqkv.float().cpu().numpy(), xf.grad.numpy()
+    for name, sl in (("dq", slice(0, n_q * D)), ("dk", slice(n_q * D, (n_q + n_kv) * D)), ("dv", slice((n_q + n_kv) * D, None))):
+        err = np.abs(got[:, sl] - want[:, sl]).max() / (np.abs(want[:, sl]).max() + 1e-9)
+        assert err < 2e-2, (name, err)

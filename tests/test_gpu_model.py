@@ -1,0 +1,139 @@
+"""End-to-end parity of the HIP engine (bf16, spatialthinker_amd.model) on the tiny Qwen2.5-VL config:
+  * log-probs vs the fp32 oracle AND vs the HF-derived golden fixture (tests/golden/model_tiny.npz);
+    criterion: the engine's error against fp32 is no larger than a bf16 evaluation's
+    own error — measured here by running HF transformers itself in bf16 on the GPU next to it;
+  * gradients of the GRPO micro-batch loss vs autograd through the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tiny  # noqa: E402
+from oracle import qwen25vl as Q  # noqa: E402
+from oracle import rl_math as M  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir):
+    from spatialthinker_amd import model as mdl
+    z = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+    cfg = mdl.VLConfig(**tiny.TINY)
+    params = tiny.make_params()
+    store = mdl.ParamStore(cfg, trainable=True)
+    store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = mdl.Qwen25VL(cfg, store)
+    batch = tiny.make_batch()
+    return z, cfg, params, store, eng, batch
+
+
+def _stage(eng, z, batch):
+    return eng.stage(batch["input_ids"], batch["attention_mask"], z["position_ids"], batch["R"], batch["pixel_values"], batch["image_grid_thw"])
+
+
+def test_hf_roundtrip_of_param_layout(env):
+    z, cfg, params, store, eng, batch = env
+    back = store.export_hf()
+    for k, v in params.items():
+        assert torch.equal(back[k].float().cpu(), torch.from_numpy(v)), k
+
+
+def test_log_probs_vs_fp32_oracle_and_hf_golden(env):
+    z, cfg, params, store, eng, batch = env
+    b = _stage(eng, z, batch)
+    lp = eng.log_probs(b, temperature=1.0).cpu().numpy()
+    mask = batch["attention_mask"][:, -batch["R"]:].astype(bool)
+    err_golden = np.abs(lp[mask] - z["logp"][mask]).max()
+    # HF itself in bf16 on this GPU: the size of a bf16 evaluation's own error
+    err_hf = _hf_bf16_error(z, cfg, params, batch)
+    print(f"engine max|dlogp| vs HF-fp32 golden: {err_golden:.4f}; HF-bf16 vs HF-fp32: {err_hf:.4f}")
+    assert err_golden <= max(1.5 * err_hf, 2e-2)
+    assert np.all(lp[~mask] == 0)
+    # temperature is applied to the logits (dp_actor.py:126)
+    lp2 = eng.log_probs(b, temperature=0.5).cpu().numpy()
+    orc = Q.response_log_probs({k: torch.from_numpy(v) for k, v in params.items()}, Q.VLConfig(**tiny.TINY),
+                               torch.from_numpy(batch["input_ids"]), torch.from_numpy(batch["attention_mask"]),
+                               torch.from_numpy(z["position_ids"]), batch["R"], 0.5, torch.from_numpy(batch["pixel_values"]),
+                               batch["image_grid_thw"]).numpy()
+    assert np.abs(lp2[mask] - orc[mask]).max() <= max(3 * err_hf, 4e-2)
+
+
+def _hf_bf16_error(z, cfg, params, batch):
+    try:
+        from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    except Exception:                                                    # pragma: no cover
+        return 2e-2
+    c = tiny.TINY
+    hc = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_layers"],
+                         num_attention_heads=c["num_heads"], num_key_value_heads=c["num_kv_heads"], vocab_size=c["vocab_size"],
+                         rms_norm_eps=c["rms_eps"], rope_parameters=dict(rope_type="default", rope_theta=c["rope_theta"], mrope_section=c["mrope_section"]),
+                         tie_word_embeddings=False, max_position_embeddings=4096, bos_token_id=None, eos_token_id=tiny.EOS_ID, pad_token_id=tiny.PAD_ID),
+        vision_config=dict(depth=c["v_depth"], hidden_size=c["v_hidden"], num_heads=c["v_heads"], intermediate_size=c["v_intermediate"],
+                           out_hidden_size=c["hidden_size"], patch_size=c["v_patch"], spatial_merge_size=c["v_merge"],
+                           temporal_patch_size=c["v_temporal_patch"], window_size=c["v_window"], fullatt_block_indexes=c["v_fullatt"],
+                           in_channels=c["v_in_channels"]),
+        image_token_id=c["image_token_id"], video_token_id=1009, vision_start_token_id=c["vision_start_token_id"],
+        vision_end_token_id=tiny.VISION_END, tie_word_embeddings=False, bos_token_id=None, eos_token_id=tiny.EOS_ID, pad_token_id=tiny.PAD_ID)
+    hc._attn_implementation = "sdpa"
+    m = Qwen2_5_VLForConditionalGeneration(hc)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    m = m.to(torch.bfloat16).cuda().eval()
+    ids, mask, P, R = batch["input_ids"], batch["attention_mask"], batch["P"], batch["R"]
+    errs, off = [], 0
+    for bidx in range(ids.shape[0]):
+        sel = mask[bidx] == 1
+        n = int(batch["patch_counts"][bidx])
+        with torch.no_grad():
+            o = m(input_ids=torch.from_numpy(ids[bidx][sel])[None].cuda(), attention_mask=None,
+                  position_ids=torch.from_numpy(z["position_ids"][bidx][:, sel])[:, None, :].cuda(),
+                  pixel_values=torch.from_numpy(batch["pixel_values"][off:off + n]).cuda(),
+                  image_grid_thw=torch.from_numpy(batch["image_grid_thw"][bidx:bidx + 1]).cuda(), use_cache=False)
+        off += n
+        lg = o.logits[0].float().cpu()
+        labels = torch.roll(torch.from_numpy(ids[bidx][sel]), -1)
+        lp = torch.log_softmax(lg, -1).gather(-1, labels[:, None])[:, 0].numpy()
+        full = np.zeros(P + R, dtype=np.float32); full[sel] = lp
+        rm = mask[bidx, -R:].astype(bool)
+        errs.append(np.abs(full[-R - 1:-1][rm] - z["logp"][bidx][rm]).max())
+    return float(max(errs))
+
+
+def test_grpo_micro_batch_gradients_vs_oracle_autograd(env):
+    z, cfg, params, store, eng, batch = env
+    rs = np.random.RandomState(21)
+    B, R = batch["input_ids"].shape[0], batch["R"]
+    rmask = batch["attention_mask"][:, -R:]
+    p32 = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = Q.VLConfig(**tiny.TINY)
+    lp = Q.response_log_probs(p32, ocfg, torch.from_numpy(batch["input_ids"]), torch.from_numpy(batch["attention_mask"]),
+                              torch.from_numpy(z["position_ids"]), R, 1.0, torch.from_numpy(batch["pixel_values"]), batch["image_grid_thw"])
+    old = (lp.detach().numpy() + 0.3 * rs.standard_normal((B, R))).astype(np.float32)
+    ref = (lp.detach().numpy() + 0.2 * rs.standard_normal((B, R))).astype(np.float32)
+    adv = rs.standard_normal((B, 1)).astype(np.float32).repeat(R, 1) * rmask
+    met, g = M.actor_micro_batch_loss(lp.detach().numpy(), old, ref, adv, rmask, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=2)
+    lp.backward(torch.from_numpy(g))
+    store.grad.zero_()
+    b = _stage(eng, z, batch)
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    lp_eng, metrics = eng.forward_backward(b, dict(old_log_probs=dv(old), ref_log_probs=dv(ref), advantages=dv(adv),
+                                                   response_mask=dv(rmask, torch.int64)), 1.0,
+                                           clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=2.0)
+    mask = rmask.astype(bool)
+    assert np.abs(lp_eng.cpu().numpy()[mask] - lp.detach().numpy()[mask]).max() < 5e-2
+    grads = store.export_hf(store.g)
+    worst = []
+    for k, t in p32.items():
+        want = t.grad.numpy()
+        got = grads[k].float().cpu().numpy()
+        rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-12)
+        worst.append((rel, k))
+    worst.sort(reverse=True)
+    print("worst gradient relative errors:", worst[:6])
+    assert worst[0][0] < 6e-2, worst[:5]
+    # padded parameter regions must receive exactly zero gradient
+    vi, vip = cfg.v_intermediate, cfg.v_inter_pad
+    assert float(store.g["v.0.gu_w"][vi:vip].abs().max()) == 0 and float(store.g["v.0.down_w"][:, vi:].abs().max()) == 0
+    assert float(store.g["v.patch_embed"][:, cfg.patch_k:].abs().max()) == 0

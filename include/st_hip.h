@@ -114,6 +114,12 @@ int st_gelu_bwd(const st_bf16* x, const st_bf16* dy, st_bf16* dx, int64_t n, st_
 int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
                int accumulate, int M, int N, int K, st_stream_t stream);
+/* Decode-shaped variant (M <= 256, the rollout's one-token-per-sequence GEMMs: a weight stream bound by HBM,
+ * 2*N*K bytes).  scratch (scratch_elems floats, contents irrelevant) receives the split-K partial slabs
+ * [split][M][N], summed in a fixed order by a finish kernel; NULL disables split-K. */
+int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
+                      const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc, float* scratch,
+                      int64_t scratch_elems, int M, int N, int K, st_stream_t stream);
 /* out (C, R) = in (R, C)^T, bf16 (operand re-layout for the backward GEMMs). */
 int st_transpose(const st_bf16* in, int64_t ldin, st_bf16* out, int64_t ldout, int R, int C, st_stream_t stream);
 /* column sums: out_f32 (C,) (+)= sum_r in[r, c]  (bias gradients). */
@@ -136,14 +142,27 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                 st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv,
                 float* delta, int max_seqlen, st_stream_t stream);
-/* single-token decode attention against a KV cache (rollout generator; replaces vLLM paged attention,
- * verl/workers/rollout/vllm_rollout_spmd.py:141-143).  For sample b: keys = prompt part
- * [kv_prompt + prompt_off[b] .. + prompt_len[b]) (shared by the G samples of a prompt) followed by the
- * sample's own generated part kv_gen[b, 0..gen_len[b]).  Cache rows are (n_kv, D) bf16. */
-int st_decode_attn(const st_bf16* q, int64_t ldq, const st_bf16* kp, const st_bf16* vp, const int64_t* prompt_off,
-                   const int32_t* prompt_len, const st_bf16* kg, const st_bf16* vg, int64_t gen_stride,
-                   const int32_t* gen_len, int B, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo,
-                   st_stream_t stream);
+/* Attention over explicit row ranges (rollout decode; replaces vLLM paged attention,
+ * verl/workers/rollout/vllm_rollout_spmd.py:141-143): sequence s has query rows [q_beg[s], q_end[s]) of q and key
+ * rows [k_beg[s], k_end[s]) of k/v (device int32 arrays, read at run time so a captured hipGraph replays with
+ * growing caches).  Non-causal.  Used twice per decode step: (i) per PROMPT — the G rollouts x (n_q/n_kv) heads
+ * of a KV head form one query tile against the shared prompt keys (q laid out (B*g, n_kv*D), n_q = n_kv here);
+ * (ii) per SAMPLE against its own generated keys.  Long prompts are split into key chunks (one "sequence" per
+ * chunk, flash-decoding) whose partial outputs go to separate row slabs via o_beg.  Empty key ranges give out = 0,
+ * lse = -inf. */
+int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                       const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
+                       const int32_t* o_beg /* output row base per sequence, NULL = q_beg */, int n_seq, int T_out, int n_q,
+                       int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse /* (n_q, T_out) */, int max_q,
+                       st_stream_t stream);
+/* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
+ * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
+int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows,
+                  int heads, int D, st_stream_t stream);
+/* KV-cache append: for each sample b (active[b] != 0 or active NULL) copy the K and V column slices of qkv row b
+ * into kg/vg[b, gen_len[b], :width]; if increment, gen_len[b] += 1 afterwards. */
+int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width, st_bf16* kg, st_bf16* vg,
+                 int64_t gen_stride, int32_t* gen_len, const int32_t* active, int B, int increment, st_stream_t stream);
 
 /* ---- optimizer: AnyPrecisionAdamW with bf16 states + Kahan compensation, one fused pass
  *      (verl/utils/torch_functional.py:253-329; ~10 eager passes in the reference) ---------------
@@ -173,11 +192,14 @@ int st_cast_pad_f32_bf16(const float* in, int64_t ldin, st_bf16* out, int64_t ld
                          st_stream_t stream);                      /* pixel_values fp32 -> bf16, zero-padded cols */
 int st_add_bf16(const st_bf16* a, const st_bf16* b, st_bf16* out, int64_t n, st_stream_t stream);
 
-/* ---- sampling (vLLM sampler: temperature / top-k / top-p; rollout/config.py:25-32) ------------
- * logits (B, V) bf16; one token per row into out_ids; Philox-style counter RNG keyed by
- * (seed, row, step).  temperature == 0 -> argmax.  top_k <= 0 and top_p >= 1 -> plain multinomial. */
+/* ---- sampling (vLLM sampler semantics of rollout/config.py:25-32: temperature, top_k = -1, top_p = 1) ------
+ * logits (B, V) bf16 -> one token per row.  temperature > 0: exact multinomial sampling of softmax(z/T) by the
+ * Gumbel-max trick with a counter-based RNG keyed by (seed, step, row, index) — reproducible, no state;
+ * temperature == 0: argmax.  forced (B,) int32 or NULL: entries >= 0 override the sampled token (EOS forcing
+ * of the synthetic benchmark / max-length handling).  top_k > 0 or top_p < 1 return -38 (not built yet). */
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p,
-              uint64_t seed, uint64_t step, int32_t* out_ids, float* scratch, st_stream_t stream);
+              uint64_t seed, uint64_t step, const int64_t* step_dev /* device counter overriding `step`, or NULL */,
+              const int32_t* forced, int32_t* out_ids, st_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,162 @@
+"""Actor / reference-policy compute on one MI355X: the counterpart of DataParallelPPOActor
+(verl/workers/actor/dp_actor.py:45-292) + AnyPrecisionAdamW + the constant-with-warmup schedule
+(verl/utils/torch_functional.py:187-329), built on the explicit engine in model.py.
+
+Data-parallel semantics: weights are replicated; each rank accumulates fp32 gradients over
+its micro-batches and ONE sum all-reduce over RCCL/xGMI (bucketed slices of the flat buffer) + division by
+the world size reproduces FSDP's averaged reduce-scatter; the optimizer then runs identically on every rank.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .model import F32, I64, ParamStore, Qwen25VL, VLConfig
+
+
+@dataclass
+class ActorHyper:
+    """Mirror of the fields of verl/workers/actor/config.py ActorConfig / OptimConfig that the path reads."""
+    micro_batch_size_per_device_for_update: int = 4
+    micro_batch_size_per_device_for_experience: int = 16
+    global_batch_size_per_device: int = 16
+    max_grad_norm: float = 1.0
+    clip_ratio_low: float = 0.2
+    clip_ratio_high: float = 0.3
+    clip_ratio_dual: float = 3.0
+    ppo_epochs: int = 1
+    use_kl_loss: bool = True
+    disable_kl: bool = False
+    kl_penalty: str = "low_var_kl"
+    kl_coef: float = 1e-2
+    lr: float = 1e-6
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    weight_decay: float = 1e-2
+    lr_warmup_steps: int = 0
+    allreduce_bucket_mb: int = 512
+
+
+def _rows(x, sl):
+    return x[sl] if x is not None else None
+
+
+class PolicyEngine:
+    """Holds one model replica (actor with optimizer, or frozen reference when hyper is None)."""
+
+    def __init__(self, cfg: VLConfig, store: ParamStore, hyper: Optional[ActorHyper] = None, process_group=None):
+        self.cfg, self.store, self.h = cfg, store, hyper
+        self.model = Qwen25VL(cfg, store)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.opt_steps = 0            # t of AdamW (state["step"])
+        self.sched_steps = 0          # lr_scheduler.step() calls so far: once per update_policy call (fsdp_workers.py:453)
+        self._norm_buf = torch.zeros(1, dtype=F32, device=store.device) if hyper is not None else None
+        self._coef = torch.ones(1, dtype=F32, device=store.device) if hyper is not None else None
+
+    # ------------------------------------------------------------------ schedule
+    def current_lr(self) -> float:
+        """get_constant_schedule_with_warmup (torch_functional.py:187-197): lr * min(1, s / max(1, warmup)); s = 0 on
+        the first update call, so that call trains at lr = 0 — reproduced on purpose."""
+        return self.h.lr * min(1.0, float(self.sched_steps) / float(max(1, self.h.lr_warmup_steps)))
+
+    # ------------------------------------------------------------------ micro-batch plumbing
+    def _stage(self, data: Dict[str, Any], sl: slice):
+        mm = data.get("multi_modal_inputs")
+        px = gr = None
+        if mm is not None:
+            items = mm[sl]
+            pxs = [torch.as_tensor(it["pixel_values"]) for it in items if it is not None and "pixel_values" in it]
+            if pxs:                                              # dp_actor.py:78-83 — concatenate over the samples
+                px = torch.cat(pxs, 0)
+                gr = np.concatenate([np.asarray(it["image_grid_thw"]).reshape(-1, 3) for it in items if it is not None and "image_grid_thw" in it], 0)
+        R = data["responses"].shape[1]
+        return self.model.stage(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R, px, gr)
+
+    @torch.no_grad()
+    def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None) -> torch.Tensor:
+        """dp_actor.py:169-210: (N, R) fp32 log-probs of the responses, micro-batched."""
+        N = data["input_ids"].shape[0]
+        mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
+        outs = []
+        for s in range(0, N, mb):
+            b = self._stage(data, slice(s, min(N, s + mb)))
+            outs.append(self.model.log_probs(b, temperature))
+        return torch.cat(outs, 0)
+
+    # ------------------------------------------------------------------ optimizer
+    def zero_grad(self):
+        self.store.grad.zero_()
+
+    def all_reduce_grads(self):
+        if self.world == 1:
+            return
+        g = self.store.grad
+        chunk = self.h.allreduce_bucket_mb * (1 << 20) // 4
+        for o in range(0, g.numel(), chunk):
+            dist.all_reduce(g[o:o + chunk], op=dist.ReduceOp.SUM, group=self.pg)
+        g.mul_(1.0 / self.world)                                  # FSDP reduce-scatter averages over ranks
+
+    def optimizer_step(self) -> float:
+        """dp_actor.py:155-167: global grad-norm clip (max_grad_norm), skip on a non-finite norm, AdamW-Kahan step."""
+        h, st = self.h, self.store
+        self.all_reduce_grads()
+        ops.sumsq(st.grad, out=self._norm_buf)
+        norm = float(self._norm_buf.sqrt().item())                # one host sync per optimizer step
+        if not np.isfinite(norm):
+            print("Gradient norm is not finite. Skip update.")
+            self.zero_grad()
+            return norm
+        self._coef.fill_(min(1.0, h.max_grad_norm / (norm + 1e-6)))   # clip_grad_norm_: coef = max_norm/(norm+1e-6), clamped to 1
+        self.opt_steps += 1
+        ops.adamw_kahan_step_(st.flat, st.grad, st.m, st.v, st.c, t=self.opt_steps, lr=self.current_lr(), betas=h.betas, eps=h.eps,
+                              weight_decay=h.weight_decay, grad_scale=self._coef)
+        st.refresh_transposes()
+        self.zero_grad()
+        return norm
+
+    # ------------------------------------------------------------------ update
+    def update_policy(self, data: Dict[str, Any], temperature: float) -> Dict[str, List[float]]:
+        """dp_actor.py:212-292.  data: input_ids, attention_mask, position_ids, responses, old_log_probs, advantages,
+        [ref_log_probs], [multi_modal_inputs]; rows = this rank's share of the rollout batch."""
+        h = self.h
+        N = data["input_ids"].shape[0]
+        R = data["responses"].shape[1]
+        dev = self.store.device
+        use_ref = h.use_kl_loss and not h.disable_kl and data.get("ref_log_probs") is not None
+        metrics: Dict[str, List[float]] = defaultdict(list)
+        pending = []
+        mini, micro = h.global_batch_size_per_device, h.micro_batch_size_per_device_for_update
+        assert N % mini == 0 and mini % micro == 0, (N, mini, micro)
+        accum = mini // micro
+        for _ in range(h.ppo_epochs):
+            for m0 in range(0, N, mini):
+                for s in range(m0, m0 + mini, micro):
+                    sl = slice(s, s + micro)
+                    b = self._stage(data, sl)
+                    to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
+                    loss_in = dict(old_log_probs=to("old_log_probs"), advantages=to("advantages"),
+                                   ref_log_probs=to("ref_log_probs") if use_ref else None,
+                                   response_mask=torch.as_tensor(data["attention_mask"][sl])[:, -R:].to(dev, I64))
+                    _, met = self.model.forward_backward(b, loss_in, temperature, clip_low=h.clip_ratio_low, clip_high=h.clip_ratio_high,
+                                                         clip_dual=h.clip_ratio_dual, kl_kind=h.kl_penalty, kl_coef=h.kl_coef,
+                                                         grad_accum=float(accum))
+                    pending.append(met)
+                norm = self.optimizer_step()
+                metrics["actor/grad_norm"].append(norm)
+        for met in torch.stack(pending).cpu().tolist():           # one device->host transfer for all micro-batches
+            metrics["actor/pg_loss"].append(met[0]); metrics["actor/pg_clipfrac_higher"].append(met[1])
+            metrics["actor/pg_clipfrac_lower"].append(met[2]); metrics["actor/ppo_kl"].append(met[3])
+            metrics["actor/entropy_loss"].append(met[4])
+            if use_ref:
+                metrics["actor/kl_loss"] = met[5]                 # the reference overwrites these two (dp_actor.py:273-274)
+                metrics["actor/kl_coef"] = h.kl_coef
+        self.sched_steps += 1
+        metrics["actor/lr"] = self.current_lr()                   # lr AFTER scheduler.step(), as fsdp_workers.py:453-455
+        return dict(metrics)

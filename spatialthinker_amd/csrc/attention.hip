@@ -63,7 +63,9 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ q, int64_t ldq,
                                                       const uint16_t* __restrict__ k, int64_t ldk,
                                                       const uint16_t* __restrict__ v, int64_t ldv,
-                                                      const int32_t* __restrict__ cu, int T, int n_q, int n_kv,
+                                                      const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end,
+                                                      const int32_t* __restrict__ k_beg, const int32_t* __restrict__ k_end,
+                                                      const int32_t* __restrict__ o_beg, int T, int n_q, int n_kv,
                                                       float scale_log2, uint16_t* __restrict__ out, int64_t ldo,
                                                       float* __restrict__ lse) {
     using C = AttnCfg<D>;
@@ -71,15 +73,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     char* ks = smem;
     char* vt = smem + C::K_BYTES;
 
+    // sequence `seq`: query rows [q_beg, q_end) of the q tensor attend to key rows [k_beg, k_end) of k/v.
+    // Prefill/training: both ranges are cu_seqlens[seq], cu_seqlens[seq+1]; decode: Lq = group rows, Lk = cache length.
     const int seq = blockIdx.z, h = blockIdx.y;
-    const int s0 = cu[seq], L = cu[seq + 1] - s0;
+    const int s0 = q_beg[seq], Lq = q_end[seq] - s0;
+    const int sk = k_beg[seq], L = k_end[seq] - sk;
     const int q_base = blockIdx.x * Q_TILE;
-    if (q_base >= L) return;
+    if (q_base >= Lq) return;
     const int kvh = h / (n_q / n_kv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qc = lane & 31, half = lane >> 5;
     const int q_idx = q_base + wave * 32 + qc;           // row inside the sequence
-    const bool q_ok = q_idx < L;
+    const bool q_ok = q_idx < Lq;
 
     // Q fragments (MFMA B operand: n = q row, k = 8 contiguous d), resident for the whole kernel
     bf16x8 qf[C::KS];
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
     for (int kt0 = 0; kt0 < kv_end; kt0 += KV_TILE) {
         __syncthreads();
-        stage_kv<D>(k, ldk, v, ldv, (int64_t)s0, kt0, L, kvh * D, ks, vt);
+        stage_kv<D>(k, ldk, v, ldv, (int64_t)sk, kt0, L, kvh * D, ks, vt);
         __syncthreads();
         // wave-uniform skip of tiles entirely above this wave's diagonal
         if (CAUSAL && kt0 > q_base + wave * 32 + 31) continue;
@@ -176,7 +181,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     }
     if (!q_ok) return;
     const float inv_l = l_i > 0.f ? 1.f / l_i : 0.f;
-    uint16_t* op = out + (int64_t)(s0 + q_idx) * ldo + (int64_t)h * D;
+    const int64_t orow = (o_beg ? o_beg[seq] : s0) + q_idx;     // decode partials land in their own slab
+    uint16_t* op = out + orow * ldo + (int64_t)h * D;
 #pragma unroll
     for (int b = 0; b < C::DP / 32; ++b)
 #pragma unroll
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                 *reinterpret_cast<uint2*>(op + d) = w;
             }
         }
-    if (half == 0) lse[(int64_t)h * T + s0 + q_idx] = (m_i + log2f(l_i)) * LN2;
+    if (half == 0) lse[(int64_t)h * T + orow] = l_i > 0.f ? (m_i + log2f(l_i)) * LN2 : -INFINITY;
 }
 
 
@@ -495,23 +501,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
 
 extern "C" {
 
+static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                           const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
+                           const int32_t* o_beg, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal, st_bf16* out,
+                           int64_t ldo, float* lse, int max_q, int klass, st_stream_t stream) {
+    if (!q || !k || !v || !q_beg || !q_end || !k_beg || !k_end || !out || !lse || n_seq <= 0 || T <= 0 || n_q <= 0 || n_kv <= 0 ||
+        (n_q % n_kv) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || max_q <= 0)
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(st_cdiv(max_q, Q_TILE), n_q, n_seq);
+    const float sl2 = scale * LOG2E;
+    StProfScope ps(klass, s, 0.0);
+#define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, T, n_q, n_kv, sl2, out, ldo, lse)
+    if (D == 128 && causal) ST_FWD(128, true);
+    else if (D == 128) ST_FWD(128, false);
+    else if (D == 80 && !causal) ST_FWD(80, false);
+    else if (D == 80) ST_FWD(80, true);
+    else return ST_EINVAL;
+#undef ST_FWD
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
 int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal, st_bf16* out,
                 int64_t ldo, float* lse, int max_seqlen, st_stream_t stream) {
-    if (!q || !k || !v || !cu_seqlens || !out || !lse || n_seq <= 0 || T <= 0 || n_q <= 0 || n_kv <= 0 || (n_q % n_kv) ||
-        (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || max_seqlen <= 0)
-        return ST_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(st_cdiv(max_seqlen, Q_TILE), n_q, n_seq);
-    const float sl2 = scale * LOG2E;
-    StProfScope ps(D == 128 ? ST_K_ATTN_FWD : ST_K_VIT_ATTN, s, 0.0);
-    if (D == 128 && causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, cu_seqlens, T, n_q, n_kv, sl2, out, ldo, lse);
-    else if (D == 128) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, cu_seqlens, T, n_q, n_kv, sl2, out, ldo, lse);
-    else if (D == 80 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<80, false>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, cu_seqlens, T, n_q, n_kv, sl2, out, ldo, lse);
-    else if (D == 80) hipLaunchKernelGGL((attn_fwd_kernel<80, true>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, cu_seqlens, T, n_q, n_kv, sl2, out, ldo, lse);
-    else return ST_EINVAL;
-    ST_CHECK_LAUNCH();
-    return 0;
+    if (!cu_seqlens) return ST_EINVAL;
+    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, cu_seqlens, cu_seqlens + 1, cu_seqlens, cu_seqlens + 1, nullptr, n_seq, T, n_q, n_kv, D,
+                           scale, causal, out, ldo, lse, max_seqlen, D == 128 ? ST_K_ATTN_FWD : ST_K_VIT_ATTN, stream);
+}
+
+int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                       const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
+                       const int32_t* o_beg, int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo,
+                       float* lse, int max_q, st_stream_t stream) {
+    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, n_seq, T_out, n_q, n_kv, D, scale, 0, out, ldo,
+                           lse, max_q, ST_K_DECODE_ATTN, stream);
 }
 
 int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,

@@ -66,7 +66,11 @@ struct StProfScope {
     int k; hipStream_t s; bool live;
     StProfScope(int klass, hipStream_t st, double units) : k(klass), s(st), live(false) {
         StProf& p = g_prof[k];
-        if (p.on && p.n < p.cap) { live = true; hipEventRecord(p.ev[2 * p.n], s); p.units += units; }
+        if (p.on && p.n < p.cap) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            hipStreamIsCapturing(s, &cs);                       // launches captured into a hipGraph are not timed
+            if (cs == hipStreamCaptureStatusNone) { live = true; hipEventRecord(p.ev[2 * p.n], s); p.units += units; }
+        }
     }
     ~StProfScope() {
         if (live) { StProf& p = g_prof[k]; hipEventRecord(p.ev[2 * p.n + 1], s); p.n++; }

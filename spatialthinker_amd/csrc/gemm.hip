@@ -155,6 +155,160 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const uint16_t* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Skinny variant for the rollout decode step (M <= 256 rows: one token per live sequence).  There the GEMM is a
+// pure WEIGHT STREAM (HBM-bound: 2*N*K bytes per launch, ~15 GB per decode step of the 7B LM), so the mapping
+// maximises the number of workgroups pulling weights from HBM and keeps the activation traffic on chip:
+//   * workgroup = 4 waves = 64 output columns x ALL rows x one K-slice (grid = N/64 x SPLITK, SPLITK chosen so the
+//     grid is >= ~2 workgroups per CU);
+//   * weights go HBM -> VGPR directly (each wave owns 16 columns; a W line is used by exactly one wave: no LDS);
+//   * the activation K-chunk (M x 64) is staged ONCE per workgroup into LDS by LDS-DMA (double-buffered, same XOR
+//     swizzle as the big kernel) and shared by the 4 waves, so x traffic is M/64 of the W traffic instead of M/16;
+//   * SPLITK > 1: fp32 partial slabs [split][M][N] go to a caller-provided scratch with plain 16-byte stores and a finish
+//     kernel applies bias/residual, rounds to bf16 and re-zeroes the scratch (self-cleaning).
+// ------------------------------------------------------------------------------------------------------
+template <int MT, bool DIRECT, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                         const uint16_t* __restrict__ B, int64_t ldb,
+                                                         const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res,
+                                                         int64_t ldr, uint16_t* __restrict__ C, int64_t ldc,
+                                                         float* __restrict__ scratch, int M, int N, int K, int k_per_split) {
+    constexpr int ROWS = MT * 16;
+    constexpr int XBYTES = ROWS * 128;                    // one 64-wide K-chunk of x
+    __shared__ __attribute__((aligned(16))) char smem[2 * XBYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const int k_begin = blockIdx.y * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    const int nchunks = (k_end - k_begin) / 64;
+    const int fr = lane & 15, fk = lane >> 4;
+    int bn = n0 + fr; bn = bn < N ? bn : N - 1;
+    const uint16_t* bp = B + (int64_t)bn * ldb + k_begin + fk * 8;
+
+    auto stage_x = [&](int chunk, char* dst) {
+        // ROWS*8 16-byte pieces, 64 per wave-instruction; wave w issues instructions w, w+4, ...
+#pragma unroll
+        for (int inst = wave; inst < ROWS / 8; inst += 4) {
+            const int p = inst * 64 + lane;
+            const int r = p >> 3, cpos = p & 7;
+            const int kc = cpos ^ ((r >> 1) & 7);
+            const int gr = r < M ? r : M - 1;
+            glds16(A + (int64_t)gr * lda + k_begin + chunk * 64 + kc * 8, dst + inst * 1024);
+        }
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[2], wn[2];
+    if (nchunks > 0) {
+        stage_x(0, smem);
+        wf[0] = *reinterpret_cast<const bf16x8*>(bp);
+        wf[1] = *reinterpret_cast<const bf16x8*>(bp + 32);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        char* cur = smem + (c & 1) * XBYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            stage_x(c + 1, smem + ((c + 1) & 1) * XBYTES);
+            wn[0] = *reinterpret_cast<const bf16x8*>(bp + (c + 1) * 64);
+            wn[1] = *reinterpret_cast<const bf16x8*>(bp + (c + 1) * 64 + 32);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = mt * 16 + fr;
+                const int kc = s * 4 + fk;
+                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(cur + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xa, acc[mt], 0, 0, 0);      // D[n][m]
+            }
+        }
+        wf[0] = wn[0]; wf[1] = wn[1];
+    }
+    const int n = n0 + fk * 4;
+    if (n >= N) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + fr;
+        if (m >= M) continue;
+        float v[4] = {acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]};
+        if (DIRECT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < N) {
+                    if (HAS_BIAS) v[r] += bf2f(bias[n + r]);
+                    if (HAS_RES) v[r] += bf2f(res[(int64_t)m * ldr + n + r]);
+                }
+            }
+            uint16_t* cp = C + (int64_t)m * ldc + n;
+            if (n + 3 < N && (ldc & 3) == 0) {
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+            }
+        } else {
+            float* sp = scratch + ((int64_t)blockIdx.y * M + m) * N + n;          // partial slab [split][M][N]
+            if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(sp) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) sp[r] = v[r];
+            }
+        }
+    }
+}
+
+template <bool HAS_BIAS, bool HAS_RES>
+__global__ void gemm_skinny_finish(const float* __restrict__ scratch, int splits, const uint16_t* __restrict__ bias,
+                                   const uint16_t* __restrict__ res, int64_t ldr, uint16_t* __restrict__ C, int64_t ldc, int M, int N) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += scratch[(int64_t)s * M * N + idx];      // fixed order: deterministic
+    if (HAS_BIAS) v += bf2f(bias[n]);
+    if (HAS_RES) v += bf2f(res[(int64_t)m * ldr + n]);
+    C[(int64_t)m * ldc + n] = f2bf(v);
+}
+
+template <int MT>
+static int launch_skinny(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
+                         int64_t ldr, uint16_t* C, int64_t ldc, float* scratch, int64_t scratch_elems, int M, int N, int K, hipStream_t s) {
+    const int nblk = st_cdiv(N, 64);
+    int sk = 1;
+    if (scratch && scratch_elems >= (int64_t)2 * M * N) {
+        sk = st_cdiv(512, nblk);
+        if ((int64_t)sk * M * N > scratch_elems) sk = (int)(scratch_elems / ((int64_t)M * N));
+        const int max_sk = K / 128;                          // at least two 64-chunks per slice
+        if (sk > max_sk) sk = max_sk;
+        if (sk > 16) sk = 16;
+        if (sk < 1) sk = 1;
+    }
+    int kps = st_cdiv(st_cdiv(K, sk), 64) * 64;
+    sk = st_cdiv(K, kps);
+    const dim3 grid(nblk, sk), block(256);
+    const bool hb = bias != nullptr, hr = res != nullptr;
+    if (sk == 1) {
+#define SKD(HB, HR) hipLaunchKernelGGL((gemm_skinny_kernel<MT, true, HB, HR>), grid, block, 0, s, A, lda, B, ldb, bias, res, ldr, C, ldc, scratch, M, N, K, kps)
+        if (hb && hr) SKD(true, true); else if (hb) SKD(true, false); else if (hr) SKD(false, true); else SKD(false, false);
+#undef SKD
+    } else {
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, false, false, false>), grid, block, 0, s, A, lda, B, ldb, bias, res, ldr, C, ldc, scratch, M, N, K, kps);
+        const dim3 fg(st_cdiv((int64_t)M * N, 256));
+#define SKF(HB, HR) hipLaunchKernelGGL((gemm_skinny_finish<HB, HR>), fg, dim3(256), 0, s, scratch, sk, bias, res, ldr, C, ldc, M, N)
+        if (hb && hr) SKF(true, true); else if (hb) SKF(true, false); else if (hr) SKF(false, true); else SKF(false, false);
+#undef SKF
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 template <bool HB, bool HR, bool OB, bool OF, bool AC>
 static int launch_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
                        const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K,
@@ -175,8 +329,8 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     if ((((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return ST_EINVAL;
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
     const bool hb = bias != nullptr, hr = residual != nullptr;
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);   // MFMA-bound class only (roofline.achieved)
 #define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
     if (out_bf16) {
         if (hb && hr) GO(true, true, true, false, false);
@@ -189,4 +343,19 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
         GO(false, false, false, true, false);
     }
 #undef GO
+}
+
+/* decode-shaped GEMM (M <= 256): out_bf16 = A B^T (+bias)(+residual).  scratch (scratch_elems floats, contents
+ * irrelevant) holds the split-K partial slabs [split][M][N]; NULL disables split-K. */
+extern "C" int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
+                                 const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc, float* scratch,
+                                 int64_t scratch_elems, int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || !out_bf16 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+        ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 32) return launch_skinny<2>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+    if (M <= 64) return launch_skinny<4>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+    if (M <= 128) return launch_skinny<8>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+    return launch_skinny<16>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
 }

@@ -140,6 +140,18 @@ def gelu_bwd(x, dy):
 
 
 # ------------------------------------------------------------------ GEMM
+_SCRATCH_ELEMS = 16 * 256 * 4608
+_scratch = {}
+
+
+def _skinny_scratch(device):
+    """fp32 split-K slab buffer [split][M][N] of the decode-shaped GEMM (contents irrelevant between calls)."""
+    key = (device.type, device.index)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(_SCRATCH_ELEMS, dtype=F32, device=device)
+    return _scratch[key]
+
+
 def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulate=False):
     """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(+residual).  Returns bf16 `out` (allocated if needed) unless `out_f32` given."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
@@ -148,6 +160,12 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
     assert b.shape[1] == K, (a.shape, b.shape)
     if out_f32 is None and out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
+    if out_f32 is None and M <= 256:                         # decode-shaped: weight-streaming skinny kernel
+        scratch = _skinny_scratch(a.device)
+        lib().st_gemm_nt_skinny(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
+                                residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), _p(scratch),
+                                scratch.numel(), M, N, K, _s())
+        return out
     c = out if out_f32 is None else out_f32
     lib().st_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
                      residual.stride(0) if residual is not None else 0, _p(out) if out_f32 is None else None,
@@ -259,3 +277,36 @@ def prof_read(klass: int):
     n, ms, units = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
     lib().st_prof_read(klass, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(units))
     return n.value, ms.value, units.value
+
+
+# ------------------------------------------------------------------ rollout (decode) kernels
+def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, scale, out, lse, o_beg=None):
+    """out: (T_out, n_q*D) bf16 slab buffer, lse: (n_q, T_out) fp32 — both caller-owned (several launches fill disjoint slabs)."""
+    lib().st_attn_fwd_ranges(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(q_beg), _p(q_end), _p(k_beg), _p(k_end),
+                             _p(o_beg), q_beg.numel(), out.shape[0], n_q, n_kv, D, scale, _p(out), out.stride(0), _p(lse), int(max_q), _s())
+    return out, lse
+
+
+def attn_merge(parts, lse, n_parts, heads, D, out=None):
+    rows = parts.shape[0] // n_parts
+    o = torch.empty(rows, heads * D, dtype=BF16, device=parts.device) if out is None else out
+    lib().st_attn_merge(_p(parts), parts.stride(0), _p(lse), n_parts, _p(o), o.stride(0), rows, heads, D, _s())
+    return o
+
+
+def kv_append_(qkv, col_k, col_v, width, kg, vg, gen_len, active=None, increment=False):
+    B = qkv.shape[0]
+    lib().st_kv_append(_p(qkv), qkv.stride(0), col_k, col_v, width, _p(kg), _p(vg), kg.stride(0), _p(gen_len), _p(active), B,
+                       int(increment), _s())
+
+
+def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, step_dev=None, out=None):
+    B, V = logits.shape
+    out = torch.empty(B, dtype=I32, device=logits.device) if out is None else out
+    lib().st_sample(_p(logits), logits.stride(0), B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step), _p(step_dev),
+                    _p(forced), _p(out), _s())
+    return out
+
+
+def prof_disable(klass: int):
+    lib().st_prof_disable(klass)

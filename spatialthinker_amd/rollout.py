@@ -1,0 +1,172 @@
+"""Rollout generator on MI355X: packed prefill + KV-cache decode, n samples per prompt.
+
+Replaces vLLMRollout.generate_sequences (verl/workers/rollout/vllm_rollout_spmd.py:115-188) and the
+FSDP->vLLM weight hand-off (verl/workers/sharding_manager/fsdp_vllm.py:76-116): the generator reads the
+actor's own flat weight buffer, so it always samples from the post-update policy with zero copies.
+
+Design: the n rollouts of a prompt share the prompt's KV (prefilled once); each decode step runs the
+MFMA attention kernel twice per layer — one tile per (prompt, kv head) over the shared prompt keys for all
+n x (n_q/n_kv) query rows, one per sample over its own generated keys — and merges the two partials.
+Sampling is exact multinomial (Gumbel-max) with a counter RNG keyed by (seed, step, row).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import indexing as ix
+from . import ops
+from .model import BF16, F32, I32, I64, Qwen25VL
+
+
+class Generator:
+    def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768):
+        self.m = model
+        self.prefill_chunk_tokens = prefill_chunk_tokens
+
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
+                 eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
+                 image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
+                 sync_every: int = 32, use_graph: bool = True) -> torch.Tensor:
+        """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
+        pixel_values[i] (N_i, 1176) / image_grid_thw[i] (1, 3).  Returns responses (b*n, max_new_tokens) int64 on the
+        device, prompt-major, padded with pad_token_id after the first EOS (vllm_rollout_spmd.py:144-147).
+        forced_lengths (b*n,): synthetic-benchmark mode — EOS is forced at exactly that response length."""
+        m, c, w = self.m, self.m.cfg, self.m.p.w
+        dev = self.m.p.device
+        ids_np, mask_np, pos_np = (np.asarray(x.cpu() if torch.is_tensor(x) else x) for x in (input_ids, attention_mask, position_ids))
+        nb, P = ids_np.shape
+        if pos_np.ndim == 2:
+            pos_np = np.repeat(pos_np[:, None, :], 3, 1)
+        B, R = nb * n, max_new_tokens
+        D, nq, nkv, L = c.head_dim, c.num_heads, c.num_kv_heads, c.num_layers
+        g, width = nq // nkv, nkv * D
+        eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+        lens = mask_np.sum(1).astype(np.int64)
+        # ---------------- prefill (chunks of prompts), prompt KV per layer: (Tp, n_kv*D)
+        p_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        Tp = int(p_off[-1])
+        kp = torch.empty(L, Tp + 128, width, dtype=BF16, device=dev)
+        vp = torch.empty(L, Tp + 128, width, dtype=BF16, device=dev)
+        last_h = torch.empty(nb, c.hidden_size, dtype=BF16, device=dev)
+        i0 = 0
+        while i0 < nb:
+            i1, tok = i0, 0
+            while i1 < nb and (i1 == i0 or tok + lens[i1] <= self.prefill_chunk_tokens):
+                tok += int(lens[i1]); i1 += 1
+            px = gr = None
+            if pixel_values is not None:
+                px = torch.cat([torch.as_tensor(pixel_values[i]) for i in range(i0, i1)], 0)
+                gr = np.concatenate([np.asarray(image_grid_thw[i]).reshape(-1, 3) for i in range(i0, i1)], 0)
+            b = m.stage(ids_np[i0:i1], mask_np[i0:i1], pos_np[i0:i1], 0, px, gr)
+            T, base = b.pk.T, int(p_off[i0])
+
+            def keep_kv(layer, k, v, T=T, base=base):
+                kp[layer, base:base + T].copy_(k[:T]); vp[layer, base:base + T].copy_(v[:T])
+
+            x = m._embed(b, None)
+            for layer in range(L):
+                x = m._lm_layer_fwd(layer, x, b, None, kv_out=keep_kv)
+            rows = torch.from_numpy((b.pk.cu_seqlens[1:] - 1).astype(np.int32)).to(dev)
+            ops.rows_gather(x, rows, out=last_h[i0:i1])
+            i0 = i1
+        head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
+        # ---------------- decode state
+        rep = torch.arange(nb, device=dev, dtype=I32).repeat_interleave(n)
+        hn, _ = ops.rmsnorm_fwd(ops.rows_gather(last_h, rep), w["final_norm"], c.rms_eps, want_rstd=False)
+        Bp = ix.round_up(B, 32) if B <= 256 else ix.round_up(B, 128)     # decode GEMMs take the skinny path for M <= 256
+        out = torch.full((B, R), pad_token_id, dtype=I64, device=dev)
+        kg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
+        vg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
+        gen_len = torch.zeros(B, dtype=I32, device=dev)
+        active = torch.ones(B, dtype=I32, device=dev)
+        last_pos = torch.from_numpy(np.ascontiguousarray(pos_np[:, :, -1].T)).to(dev, I32).repeat_interleave(n, dim=1)   # (3, B)
+        eos_t = torch.tensor(eos, device=dev, dtype=I64)
+        forced_len = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I64)
+        ar = torch.arange(B, device=dev, dtype=I32)
+        # prompt partial: one "sequence" per (key chunk c, prompt p) -> slab c of the partial buffer (flash-decoding split-KV)
+        CK = 256
+        C = max(1, int(-(-int(lens.max()) // CK)))
+        rows_all = B * g
+        pb, pe = p_off[:-1].astype(np.int64), p_off[1:].astype(np.int64)
+        kb1_np = np.concatenate([np.minimum(pb + c * CK, pe) for c in range(C)])
+        ke1_np = np.concatenate([np.minimum(pb + (c + 1) * CK, pe) for c in range(C)])
+        qb1_np = np.tile(np.arange(nb) * (n * g), C)
+        ob1_np = np.concatenate([c * rows_all + np.arange(nb) * (n * g) for c in range(C)])
+        ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
+        qb1, kb1, ke1, ob1 = ti(qb1_np), ti(kb1_np), ti(ke1_np), ti(ob1_np)
+        qe1 = qb1 + n * g
+        qb2 = (ar * g).contiguous(); qe2 = qb2 + g
+        kb2 = (ar * R).contiguous()
+        ob2 = (C * rows_all + ar * g).contiguous()
+        parts = torch.empty((C + 1) * rows_all, width, dtype=BF16, device=dev)
+        lse_parts = torch.empty(nkv, (C + 1) * rows_all, dtype=F32, device=dev)
+        xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
+        logits = torch.empty(Bp if Bp <= 256 else B, c.vocab_size, dtype=BF16, device=dev)
+        ops.gemm_nt(hn, head, out=logits[:B])
+        step_t = torch.zeros(1, dtype=I64, device=dev)
+        pos = (last_pos + 1).contiguous()                      # position of the token sampled at response index 0
+        tok32 = torch.zeros(B, dtype=I32, device=dev)
+        pad_t = torch.full((B,), pad_token_id, dtype=I64, device=dev)
+
+        def iteration():
+            """sample -> record -> one decode forward for all B rows -> next logits.  Device state only (graph-capturable).
+            Finished rows keep computing on their last token; their output is ignored (cheaper than re-packing every step)."""
+            nonlocal active
+            forced = None
+            if forced_len is not None:
+                forced = torch.where(forced_len == step_t + 1, int(eos[0]), -1).to(I32)
+            ops.sample(logits[:B], temperature, seed, forced=forced, step_dev=step_t, out=tok32)
+            tok = tok32.to(I64)
+            live = active.bool()
+            out.scatter_(1, step_t.expand(B, 1), torch.where(live, tok, pad_t)[:, None])
+            if not ignore_eos:
+                active.copy_((live & ~(tok[:, None] == eos_t[None, :]).any(1)).to(I32))
+            cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
+            ops.embed_gather(w["embed"], tok32, out=xbuf[:B])
+            x = xbuf
+            ke2 = kb2 + gen_len + 1
+            for layer in range(L):
+                p = f"l.{layer}."
+                h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
+                qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+                ops.rope_apply_(qkv[:B], cos, sin, nq + nkv, D)
+                ops.kv_append_(qkv[:B], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
+                q2 = qkv[:B, :nq * D].view(B, nkv, g, D).permute(0, 2, 1, 3).reshape(B * g, width)
+                ops.attn_fwd_ranges(q2, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob1)
+                ops.attn_fwd_ranges(q2, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
+                                    nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2)
+                om = ops.attn_merge(parts, lse_parts, C + 1, nkv, D)
+                a = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)
+                a[:B] = om.view(B, g, nkv, D).permute(0, 2, 1, 3).reshape(B, nq * D)
+                x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x)
+                h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
+                mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
+                x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
+            hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
+            ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits)
+            gen_len.add_(1); pos.add_(1); step_t.add_(1)
+
+        # the decode iteration is launch-bound (~20 launches x layers): capture it once into a hipGraph and replay
+        graph = None
+        if use_graph and R > 2:
+            iteration()                                            # eager warm-up iteration (response index 0)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                iteration()
+            first = 2                                              # capture itself does not execute: replay from index 1
+            graph.replay()
+        else:
+            first = 0
+        for step in range(first, R):
+            if graph is not None:
+                graph.replay()
+            else:
+                iteration()
+            if step % sync_every == sync_every - 1 and int(active.sum().item()) == 0:
+                break
+        return out

@@ -1,0 +1,101 @@
+"""Rollout generator parity: KV-cache decode with shared prompt KV vs teacher-forced fp32 oracle logits,
+response post-processing layout, and the sampler's distribution."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tiny  # noqa: E402
+from oracle import qwen25vl as Q  # noqa: E402
+from oracle import positions as P  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir):
+    from spatialthinker_amd import model as mdl
+    from spatialthinker_amd.rollout import Generator
+    cfg = mdl.VLConfig(**tiny.TINY)
+    params = tiny.make_params()
+    store = mdl.ParamStore(cfg, trainable=False)
+    store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = mdl.Qwen25VL(cfg, store)
+    return cfg, params, eng, Generator(eng)
+
+
+def _prompts():
+    b = tiny.make_batch()
+    Pn = b["P"]
+    ids, mask = b["input_ids"][:, :Pn], b["attention_mask"][:, :Pn]
+    pos = np.stack([P.mrope_position_ids(ids[i], b["image_grid_thw"][i:i + 1], mask[i], image_token_id=tiny.TINY["image_token_id"],
+                                         vision_start_token_id=tiny.TINY["vision_start_token_id"]) for i in range(2)])
+    pos[:, :, :][np.repeat((mask == 0)[:, None, :], 3, 1)] = 0
+    off = np.concatenate([[0], np.cumsum(b["patch_counts"])])
+    pix = [torch.from_numpy(b["pixel_values"][off[i]:off[i + 1]]) for i in range(2)]
+    grids = [b["image_grid_thw"][i:i + 1] for i in range(2)]
+    return ids, mask, pos, pix, grids
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_greedy_decode_matches_teacher_forced_oracle(env, use_graph):
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    R, n = 10, 2
+    out = gen.generate(ids, mask, pos, n=n, max_new_tokens=R, temperature=0.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                       pixel_values=pix, image_grid_thw=grids, ignore_eos=True, use_graph=use_graph).cpu().numpy()
+    assert out.shape == (4, R)
+    np.testing.assert_array_equal(out[0], out[1]); np.testing.assert_array_equal(out[2], out[3])     # greedy: rollouts of a prompt coincide
+    p32 = {k: torch.from_numpy(v) for k, v in params.items()}
+    ocfg = Q.VLConfig(**tiny.TINY)
+    for b in range(2):
+        sel = mask[b] == 1
+        seq = np.concatenate([ids[b][sel], out[b * n]])
+        ppos = np.concatenate([pos[b][:, sel], pos[b][:, -1:] + np.arange(1, R + 1)], 1)
+        logits = Q.forward_logits(p32, ocfg, torch.from_numpy(seq), torch.from_numpy(ppos), [0, len(seq)], pix[b], grids[b])
+        L0 = int(sel.sum())
+        for j in range(R):
+            row = logits[L0 - 1 + j]
+            chosen = float(row[out[b * n][j]])
+            assert chosen >= float(row.max()) - 0.08, (b, j, chosen, float(row.max()))    # argmax up to bf16 noise
+
+
+def test_eos_stops_and_pads_and_forced_lengths(env):
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    lens = np.array([3, 7, 1, 12])
+    out = gen.generate(ids, mask, pos, n=2, max_new_tokens=12, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                       pixel_values=pix, image_grid_thw=grids, forced_lengths=lens, seed=5).cpu().numpy()
+    for i, L in enumerate(lens):
+        assert out[i, L - 1] == tiny.EOS_ID and (out[i, L:] == tiny.PAD_ID).all()
+        assert (out[i, :L - 1] != tiny.PAD_ID).all()
+    # different seeds give different samples, same seed reproduces
+    a = gen.generate(ids, mask, pos, n=2, max_new_tokens=8, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                     pixel_values=pix, image_grid_thw=grids, ignore_eos=True, seed=1).cpu().numpy()
+    b = gen.generate(ids, mask, pos, n=2, max_new_tokens=8, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                     pixel_values=pix, image_grid_thw=grids, ignore_eos=True, seed=1).cpu().numpy()
+    c = gen.generate(ids, mask, pos, n=2, max_new_tokens=8, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                     pixel_values=pix, image_grid_thw=grids, ignore_eos=True, seed=2).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    assert (a != c).any() and (a[0] != a[1]).any()
+
+
+def test_sampler_distribution():
+    from spatialthinker_amd import ops
+    z = torch.tensor([2.0, 1.0, 0.0, -1.0, 0.5, -3.0, 1.5, 0.25]).bfloat16()
+    B = 4096
+    logits = z[None, :].repeat(B, 1).cuda()
+    for temp in (1.0, 0.5):
+        counts = np.zeros(8)
+        for step in range(8):
+            t = ops.sample(logits, temp, seed=11, step=step).cpu().numpy()
+            counts += np.bincount(t, minlength=8)
+        p = torch.softmax(z.float() / temp, 0).numpy()
+        n = counts.sum()
+        chi2 = ((counts - n * p) ** 2 / (n * p)).sum()
+        assert chi2 < 30, (temp, chi2, counts / n, p)                   # 7 dof: P(chi2 > 30) ~ 1e-4
+    assert (ops.sample(logits, 0.0, seed=3, step=0).cpu().numpy() == 0).all()
+    forced = torch.full((B,), -1, dtype=torch.int32); forced[5] = 6
+    t = ops.sample(logits, 1.0, seed=3, step=0, forced=forced.cuda()).cpu().numpy()
+    assert t[5] == 6

@@ -1,0 +1,239 @@
+"""Dense spatial reward of SpatialThinker (reward plug-in `worker.reward.score_function=spatial_sgg`).
+
+Same signature and scores as the reference scorer (verl/utils/reward_score/spatial_sgg.py:644-691 and the
+helpers it reaches); written from the behaviour described in SURVEY.md §8(a6), not from its text:
+
+    overall = 0.1*format + 0.2*count + 0.5*accuracy + 0.2*spatial
+    count, accuracy only if format == 1;  spatial only if accuracy == 1.
+
+Label similarity (`sem_sim`, spaCy `en_core_web_md` vectors in the reference) only steers the Hungarian
+assignment; it is pluggable here (`set_similarity`).  Default: spaCy vectors if the model is installed,
+otherwise exact match of the cleaned label (1.0 / 0.0) — the stub the golden fixtures were generated with.
+"""
+from __future__ import annotations
+
+import json
+import math
+import re
+from functools import lru_cache
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy.optimize import linear_sum_assignment
+
+WEIGHTS = {"format": 0.1, "count": 0.2, "accuracy": 0.5, "spatial_score": 0.2}
+SEM_WEIGHT, BOX_WEIGHT, DUMMY_COST = 2.0, 1.0, 1e5
+_ID_RE = re.compile(r"[a-zA-Z_]+\.\d+")
+_TAGS = ("observe", "think", "scene", "answer")
+
+
+# ------------------------------------------------------------------ label similarity (pluggable)
+def _clean(label: str) -> str:
+    return label.replace("_", " ").replace("-", " ").strip().lower()
+
+
+def _exact_similarity(a: str, b: str) -> float:
+    return 1.0 if a == b else 0.0
+
+
+def _load_default_similarity() -> Callable[[str, str], float]:
+    try:                                                    # the reference's choice, when available
+        import spacy
+        nlp = spacy.load("en_core_web_md", disable=["parser", "ner", "tagger"])
+        doc = lru_cache(maxsize=4096)(nlp)
+        return lambda a, b: float(doc(a).similarity(doc(b)))
+    except Exception:
+        return _exact_similarity
+
+
+_similarity: Optional[Callable[[str, str], float]] = None
+
+
+def set_similarity(fn: Optional[Callable[[str, str], float]]) -> None:
+    global _similarity
+    _similarity = fn
+    _match_cached.cache_clear()
+
+
+def sem_sim(a: str, b: str) -> float:
+    global _similarity
+    if _similarity is None:
+        _similarity = _load_default_similarity()
+    return _similarity(_clean(a.split(".")[0]), _clean(b.split(".")[0]))
+
+
+# ------------------------------------------------------------------ geometry
+def compute_ciou(a: Sequence[float], b: Sequence[float], eps: float = 1e-7) -> float:
+    """Complete-IoU of two [x1,y1,x2,y2] boxes mapped to [0,1] by (ciou+1)/2."""
+    wa, ha, wb, hb = a[2] - a[0], a[3] - a[1], b[2] - b[0], b[3] - b[1]
+    iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
+    ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
+    inter = iw * ih
+    iou = inter / (wa * ha + wb * hb - inter + eps)
+    dist2 = ((a[0] + a[2]) / 2 - (b[0] + b[2]) / 2) ** 2 + ((a[1] + a[3]) / 2 - (b[1] + b[3]) / 2) ** 2
+    diag2 = (max(a[2], b[2]) - min(a[0], b[0])) ** 2 + (max(a[3], b[3]) - min(a[1], b[1])) ** 2 + eps
+    v = (4 / (math.pi ** 2)) * (math.atan(wb / (hb + eps)) - math.atan(wa / (ha + eps))) ** 2
+    denom = (1 - iou) + v
+    alpha = v / denom if denom != 0 else 0.0
+    return ((iou - (dist2 / diag2 + alpha * v)) + 1) / 2
+
+
+# ------------------------------------------------------------------ parsing / validity
+def extract_answer(text: str) -> str:
+    m = re.search(r"<answer>(.*?)</answer>", text, re.DOTALL)
+    return m.group(1).strip() if m else ""
+
+
+def extract_scene(text: str) -> dict:
+    m = re.search(r"<scene>(.*?)</scene>", text, re.DOTALL)
+    if not m:
+        return {}
+    try:
+        obj = json.loads(m.group(1).strip())
+    except Exception:
+        return {}
+    return obj if isinstance(obj, dict) else {}
+
+
+def extract_image_size(problem: str) -> Tuple[int, int]:
+    m = re.search(r"Image size: \((.*?) x (.*?)\)", problem)
+    if not m:
+        raise ValueError("Image size not found in problem!!! Required for spatial_sgg reward scoring.")
+    return int(m.group(1)), int(m.group(2))
+
+
+def is_valid_object(o) -> bool:
+    if not isinstance(o, dict) or set(o.keys()) != {"id", "bbox"}:
+        return False
+    if not isinstance(o["id"], str) or not _ID_RE.fullmatch(o["id"]):
+        return False
+    box = o["bbox"]
+    return isinstance(box, list) and len(box) == 4 and all(isinstance(x, (int, float)) for x in box)
+
+
+def is_valid_relation(r) -> bool:
+    if not isinstance(r, dict) or not {"subject", "predicate", "object"} <= set(r.keys()):
+        return False
+    if not all(isinstance(r[k], str) for k in ("subject", "predicate", "object")):
+        return False
+    return bool(_ID_RE.fullmatch(r["subject"])) and bool(_ID_RE.fullmatch(r["object"]))
+
+
+def format_reward(text: str) -> float:
+    try:
+        for tag in _TAGS:
+            if not re.search(rf"<{tag}>.*?</{tag}>", text, re.DOTALL) or text.count(f"<{tag}>") != 1:
+                return 0.0
+        scene = extract_scene(text)
+        if not scene:
+            return 0.0
+        objs, rels = scene.get("objects", []), scene.get("relationships", [])
+        if not isinstance(objs, list) or not isinstance(rels, list):
+            return 0.0
+        if not all(is_valid_object(o) for o in objs) or not all(is_valid_relation(r) for r in rels):
+            return 0.0
+        ids = [o["id"] for o in objs]
+        return 1.0 if len(ids) == len(set(ids)) else 0.0
+    except Exception:
+        return 0.0
+
+
+def acc_reward(pred: str, gt: str) -> float:
+    return float(pred.strip().lower() == gt.strip().lower())
+
+
+def count_reward(pred_scene, gt_scene) -> float:
+    if not isinstance(pred_scene, dict) or not isinstance(gt_scene, dict):
+        return 0.0
+    po, go = pred_scene.get("objects"), gt_scene.get("objects")
+    if not isinstance(po, list) or not isinstance(go, list):
+        return 0.0
+    pr, gr = pred_scene.get("relationships") or [], gt_scene.get("relationships") or []
+    closeness = lambda n_pred, n_gt: max(0.0, 1 - abs(n_pred - n_gt) / max(n_gt, 1))
+    obj = closeness(len(po), len(go))
+    return obj if not len(gr) else obj * 0.7 + closeness(len(pr), len(gr)) * 0.3
+
+
+# ------------------------------------------------------------------ matching
+@lru_cache(maxsize=4096)
+def _match_cached(gt_key, pr_key) -> tuple:
+    """Hungarian assignment GT j -> prediction i (or None) minimising 2*(1-sim) + (1-ciou); missing predictions are
+    padded with rows of cost 1e5."""
+    G, P = len(gt_key), len(pr_key)
+    cost = np.zeros((P + max(0, G - P), G))
+    for i, (pid, pbox) in enumerate(pr_key):
+        for j, (gid, gbox) in enumerate(gt_key):
+            # argument order follows the reference call chain (_hungarian -> _cost(p, g) -> compute_ciou(g, p))
+            cost[i, j] = SEM_WEIGHT * (1.0 - sem_sim(gid, pid)) + BOX_WEIGHT * (1.0 - compute_ciou(list(gbox), list(pbox)))
+    cost[P:, :] = DUMMY_COST
+    rows, cols = linear_sum_assignment(cost)
+    out = [None] * G
+    for r, c in zip(rows, cols):
+        if r < P:
+            out[c] = int(r)
+    return tuple(out)
+
+
+def bi_match(gt_objs: List[dict], pr_objs: List[dict]) -> tuple:
+    key = lambda objs: tuple((o["id"], tuple(o["bbox"])) for o in objs)
+    return _match_cached(key(gt_objs), key(pr_objs))
+
+
+def compute_obj_score(gt_objs: List[dict], pr_objs: List[dict]) -> float:
+    if not gt_objs:
+        return 1.0
+    total = 0.0
+    for j, i in enumerate(bi_match(gt_objs, pr_objs)):
+        if i is not None:
+            total += compute_ciou(gt_objs[j]["bbox"], pr_objs[i]["bbox"])
+            sem_sim(gt_objs[j]["id"], pr_objs[i]["id"])
+    return total / len(gt_objs)
+
+
+def _triplet_matches(gt_rels: List[dict], pr_rels: List[dict]) -> int:
+    G, P = len(gt_rels), len(pr_rels)
+    cost = np.zeros((P + max(0, G - P), G))
+    for i, p in enumerate(pr_rels):
+        for j, g in enumerate(gt_rels):
+            cost[i, j] = 1.0 - (0.3 * sem_sim(p["subject"], g["subject"]) + 0.3 * sem_sim(p["object"], g["object"])
+                                + 0.4 * sem_sim(p["predicate"], g["predicate"]))
+    cost[P:, :] = DUMMY_COST
+    rows, _ = linear_sum_assignment(cost)
+    return int(sum(1 for r in rows if r < P))
+
+
+def relaxed_spatial_reward(pred_scene, gt_scene, w: int, h: int, threshold: float = 0.0, rel_gating: bool = False) -> float:
+    if not isinstance(pred_scene, dict) or not isinstance(gt_scene, dict):
+        return 0.0
+    go, po = gt_scene.get("objects") or [], pred_scene.get("objects") or []
+    gr, pr = gt_scene.get("relationships") or [], pred_scene.get("relationships") or []
+    if not all(isinstance(x, list) for x in (go, po, gr, pr)):
+        return 0.0
+    if not all(is_valid_object(o) for o in po) or not all(is_valid_relation(r) for r in pr):
+        return 0.0
+    sx, sy = 1.0 / w, 1.0 / h
+    norm = lambda objs: [{**o, "id": _clean(o["id"]), "bbox": [o["bbox"][0] * sx, o["bbox"][1] * sy, o["bbox"][2] * sx, o["bbox"][3] * sy]}
+                         for o in objs]
+    go, po = norm(go), norm(po)
+    if not gr:
+        return (1.0 if not po else 0.0) if not go else compute_obj_score(go, po)
+    rel = lambda rs: [{**r, "subject": _clean(r["subject"]), "object": _clean(r["object"])} for r in rs]
+    n_matched = _triplet_matches(rel(gr), rel(pr))
+    score = compute_obj_score(go, po)
+    return 0.0 if (n_matched == 0 and rel_gating) else score
+
+
+# ------------------------------------------------------------------ entry point
+def spatial_sgg_compute_score(predict_str: str, ground_truth_str: str, problem: str) -> Dict[str, float]:
+    pred_answer, gt_answer = extract_answer(predict_str), extract_answer(ground_truth_str)
+    pred_scene, gt_scene = extract_scene(predict_str), extract_scene(ground_truth_str)
+    width, height = extract_image_size(problem)
+    fr = format_reward(predict_str)
+    cr = ar = spatial = 0.0
+    if fr == 1.0:
+        cr = count_reward(pred_scene, gt_scene)
+        ar = acc_reward(pred_answer, gt_answer)
+        if ar == 1.0:
+            spatial = relaxed_spatial_reward(pred_scene, gt_scene, width, height, 0.0, False)
+    total = fr * WEIGHTS["format"] + cr * WEIGHTS["count"] + ar * WEIGHTS["accuracy"] + spatial * WEIGHTS["spatial_score"]
+    return {"overall": total, "format": fr, "count": cr, "accuracy": ar, "spatial_score": spatial}

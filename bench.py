@@ -95,7 +95,13 @@ def cpu_baseline(cfg, S_text, grid, R_mean):
     """Times the fp32 CPU oracle on ONE STVQA-shaped sequence at reduced depth — (1,1), (2,1), (1,2) LM/ViT layers —
     and extrapolates linearly in depth to the full model: cost/sample = 2 no-grad forwards (old, ref) + 1 forward/backward."""
     from oracle import qwen25vl as Q
-    threads = os.cpu_count() or 1
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                    # honour the container's CPU quota (cgroup v2)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except Exception:
+        pass
     torch.set_num_threads(threads)
     t, h, w = grid
     n_patch = t * h * w

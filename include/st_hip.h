@@ -199,7 +199,8 @@ int st_add_bf16(const st_bf16* a, const st_bf16* b, st_bf16* out, int64_t n, st_
  * of the synthetic benchmark / max-length handling).  top_k > 0 or top_p < 1 return -38 (not built yet). */
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p,
               uint64_t seed, uint64_t step, const int64_t* step_dev /* device counter overriding `step`, or NULL */,
-              const int32_t* forced, int32_t* out_ids, st_stream_t stream);
+              const int32_t* forced, int32_t* out_ids, float* scratch /* B*32 floats or NULL: splits each row over 16 workgroups */,
+              st_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -64,17 +64,21 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {          // splitmix64 f
     x ^= x >> 31;
     return (uint32_t)(x >> 16);
 }
-// one workgroup per row: argmax_i ( z_i / T + Gumbel_i ),  Gumbel_i = -log(-log(u_i)), u_i from a counter hash.
+// argmax_i ( z_i / T + Gumbel_i ),  Gumbel_i = -log(-log(u_i)), u_i from a counter hash.  Each row is split over gridDim.y
+// workgroups (partials -> scratch), reduced by sample_finish_kernel; with scratch == NULL one workgroup does the whole row.
 __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict__ logits, int64_t ldl, int V, float inv_temp,
                                                     int greedy, uint64_t seed, uint64_t step_host, const int64_t* __restrict__ step_dev,
-                                                    const int32_t* __restrict__ forced, int32_t* __restrict__ out_ids) {
+                                                    const int32_t* __restrict__ forced, int32_t* __restrict__ out_ids,
+                                                    float* __restrict__ scratch) {
     const int row = blockIdx.x;
     const uint16_t* x = logits + (int64_t)row * ldl;
     float best = -INFINITY;
-    int besti = 0;
+    int besti = 0x7fffffff;
     const uint64_t step = step_dev ? (uint64_t)step_dev[0] : step_host;
     const uint64_t key = (seed * 0x100000001B3ull) ^ (step << 32) ^ ((uint64_t)row * 0x9E3779B1ull);
-    for (int i = threadIdx.x; i < V; i += 256) {
+    const int per = (V + gridDim.y - 1) / gridDim.y;
+    const int v0 = blockIdx.y * per, v1 = min(V, v0 + per);
+    for (int i = v0 + threadIdx.x; i < v1; i += 256) {
         float z = bf2f(x[i]) * inv_temp;
         if (!greedy) {
             const uint32_t r = mix32(key + (uint64_t)i * 0xD6E8FEB86659FD93ull);
@@ -95,9 +99,28 @@ __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; ++k) if (sb[k] > best || (sb[k] == best && si[k] < besti)) { best = sb[k]; besti = si[k]; }
-        if (forced && forced[row] >= 0) besti = forced[row];
-        out_ids[row] = besti;
+        if (scratch) {
+            scratch[((int64_t)row * gridDim.y + blockIdx.y) * 2] = best;
+            scratch[((int64_t)row * gridDim.y + blockIdx.y) * 2 + 1] = __int_as_float(besti);
+        } else {
+            if (forced && forced[row] >= 0) besti = forced[row];
+            out_ids[row] = besti;
+        }
     }
+}
+__global__ void sample_finish_kernel(const float* __restrict__ scratch, int splits, const int32_t* __restrict__ forced,
+                                     int32_t* __restrict__ out_ids, int B) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B) return;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = 0; k < splits; ++k) {
+        const float b = scratch[((int64_t)row * splits + k) * 2];
+        const int i = __float_as_int(scratch[((int64_t)row * splits + k) * 2 + 1]);
+        if (b > best || (b == best && i < besti)) { best = b; besti = i; }
+    }
+    if (forced && forced[row] >= 0) besti = forced[row];
+    out_ids[row] = besti;
 }
 
 extern "C" {
@@ -123,12 +146,15 @@ int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_par
 }
 
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
-              uint64_t step, const int64_t* step_dev, const int32_t* forced, int32_t* out_ids, st_stream_t stream) {
+              uint64_t step, const int64_t* step_dev, const int32_t* forced, int32_t* out_ids, float* scratch, st_stream_t stream) {
     if (!logits || !out_ids || B <= 0 || V <= 0 || temperature < 0.f) return ST_EINVAL;
     if (top_k > 0 || top_p < 1.f) return -38;        // top-k / top-p filtering: not built yet (shipped configs use -1 / 1.0)
     const int greedy = temperature == 0.f;
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature, greedy,
-                       seed, step, step_dev, forced, out_ids);
+    const int splits = scratch ? 16 : 1;                       // scratch: B * 16 * 2 floats
+    hipLaunchKernelGGL(sample_kernel, dim3(B, splits), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature,
+                       greedy, seed, step, step_dev, forced, out_ids, scratch);
+    if (scratch)
+        hipLaunchKernelGGL(sample_finish_kernel, dim3(st_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, scratch, splits, forced, out_ids, B);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -139,70 +139,60 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const uint16_t* __rest
     }
 }
 
-// RMSNorm backward.  Workgroup = 4 waves x ROWS_PER_WAVE rows.  Phase 1: per-row dot = sum(dy*w*xhat)
-// (wave shuffles) into LDS.  Phase 2: column-chunk major — each lane owns 8 columns of a 512-column
-// chunk, walks its wave's rows writing dx and accumulating dw in registers; one fp32 atomicAdd per
-// column per workgroup at the end.
-#define RN_ROWS_PER_WAVE 8
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ x, int64_t ldx,
-                                                         const uint16_t* __restrict__ w,
-                                                         const float* __restrict__ rstd,
-                                                         const uint16_t* __restrict__ dy, int64_t lddy,
-                                                         const uint16_t* __restrict__ dres, int64_t lddres,
-                                                         uint16_t* __restrict__ dx, int64_t lddx,
-                                                         float* __restrict__ dw_accum, int T, int H) {
-    __shared__ float s_dot[4 * RN_ROWS_PER_WAVE];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + wv) * RN_ROWS_PER_WAVE;
-    for (int r = 0; r < RN_ROWS_PER_WAVE; ++r) {
-        const int row = row0 + r;
-        float acc = 0.f;
-        if (row < T) {
-            const float rs = rstd[row];
-            const uint16_t* xr = x + (int64_t)row * ldx;
-            const uint16_t* dyr = dy + (int64_t)row * lddy;
-            for (int i = lane * 8; i < H; i += 512) {
-                float xf[8], df[8], wf[8];
-                unpack8(*reinterpret_cast<const uint4*>(xr + i), xf);
-                unpack8(*reinterpret_cast<const uint4*>(dyr + i), df);
-                unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+// RMSNorm backward, two kernels so that both are bandwidth-shaped:
+//   dx: one wave per row (T waves in flight): pass 1 dot = sum(dy*w*xhat) by wave shuffles, pass 2 (row re-read from L1/L2)
+//       dx = rstd*(dy*w - xhat*dot/H) (+ dres);
+//   dw: column-slab reduction dw[c] += sum_t dy[t,c]*bf16(x[t,c]*rstd[t]) — 64 columns x 256 rows per workgroup, coalesced
+//       128-byte row segments, one fp32 atomicAdd per column per workgroup.
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                            const uint16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                            const uint16_t* __restrict__ dy, int64_t lddy,
+                                                            const uint16_t* __restrict__ dres, int64_t lddres,
+                                                            uint16_t* __restrict__ dx, int64_t lddx, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float rs = rstd[row];
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    const uint16_t* dyr = dy + (int64_t)row * lddy;
+    float acc = 0.f;
+    for (int i = lane * 8; i < H; i += 512) {
+        float xf[8], df[8], wf[8];
+        unpack8(*reinterpret_cast<const uint4*>(xr + i), xf);
+        unpack8(*reinterpret_cast<const uint4*>(dyr + i), df);
+        unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc += df[j] * wf[j] * (xf[j] * rs);
-            }
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) s_dot[wv * RN_ROWS_PER_WAVE + r] = acc;
+        for (int j = 0; j < 8; ++j) acc += df[j] * wf[j] * (xf[j] * rs);
     }
+    const float mdot = wave_sum(acc) / (float)H;
+    for (int i = lane * 8; i < H; i += 512) {
+        float xf[8], df[8], wf[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(xr + i), xf);
+        unpack8(*reinterpret_cast<const uint4*>(dyr + i), df);
+        unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+        if (dres) unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * lddres + i), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = rs * (df[j] * wf[j] - (xf[j] * rs) * mdot);
+            o[j] = dres ? (o[j] + d) : d;
+        }
+        *reinterpret_cast<uint4*>(dx + (int64_t)row * lddx + i) = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ rstd, const uint16_t* __restrict__ dy,
+                                                            int64_t lddy, float* __restrict__ dw, int T, int H, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(T, r0 + rows_per_block);
+    float acc = 0.f;
+    if (c < H)
+        for (int r = r0 + ty; r < r1; r += 4)
+            acc += bf2f(dy[(int64_t)r * lddy + c]) * bfround(bf2f(x[(int64_t)r * ldx + c]) * rstd[r]);
+    part[ty][threadIdx.x & 63] = acc;
     __syncthreads();
-    const float invH = 1.f / (float)H;
-    for (int c0 = lane * 8; c0 < H; c0 += 512) {
-        float wf[8], dwl[8];
-        unpack8(*reinterpret_cast<const uint4*>(w + c0), wf);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dwl[j] = 0.f;
-        for (int r = 0; r < RN_ROWS_PER_WAVE; ++r) {
-            const int row = row0 + r;
-            if (row >= T) break;
-            const float rs = rstd[row];
-            const float mdot = s_dot[wv * RN_ROWS_PER_WAVE + r] * invH;
-            float xf[8], df[8], o[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)row * ldx + c0), xf);
-            unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)row * lddy + c0), df);
-            if (dres) unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * lddres + c0), o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = xf[j] * rs;
-                const float d = rs * (df[j] * wf[j] - xh * mdot);
-                dwl[j] += df[j] * bfround(xh);
-                o[j] = dres ? (o[j] + d) : d;
-            }
-            *reinterpret_cast<uint4*>(dx + (int64_t)row * lddx + c0) = pack8(o);
-        }
-        if (dw_accum) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(dw_accum + c0 + j, dwl[j]);
-        }
-    }
+    if (ty == 0 && c < H) atomicAdd(dw + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 extern "C" {
@@ -248,8 +238,11 @@ int st_rmsnorm_bwd(const st_bf16* x, int64_t ldx, const st_bf16* w, const float*
         return ST_EINVAL;
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(st_cdiv(T, 4 * RN_ROWS_PER_WAVE)), dim3(256), 0, s, x, ldx, w, rstd, dy,
-                       lddy, dres, lddres, dx, lddx, dw_accum, T, H);
+    // dw first: dx may alias dy (in-place), and dw needs the original dy
+    if (dw_accum)
+        hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel, dim3(st_cdiv(H, 64), st_cdiv(T, 256)), dim3(256), 0, s, x, ldx, rstd, dy, lddy, dw_accum,
+                           T, H, 256);
+    hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, rstd, dy, lddy, dres, lddres, dx, lddx, T, H);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,125 @@
+"""CPU tests of the API mirror: config parsing of the shipped scripts' keys, DataProto semantics, balancing, reward manager."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from verl.protocol import DataProto, pad_dataproto_to_divisor, unpad_dataproto
+from verl.trainer.config import PPOConfig, load_config
+from verl.utils.seqlen_balancing import get_seqlen_balanced_partitions, log_seqlen_unbalance
+
+REF_YAML = """
+data: {train_files: a@train, val_files: a@val, prompt_key: problem, answer_key: answer, image_key: image, max_prompt_length: 2048,
+       max_response_length: 2048, rollout_batch_size: 512, val_batch_size: -1, shuffle: true, seed: 1, max_pixels: 4194304, min_pixels: 262144}
+algorithm: {adv_estimator: grpo, disable_kl: false, use_kl_loss: true, kl_penalty: low_var_kl, kl_coef: 1.0e-2}
+worker:
+  actor:
+    global_batch_size: 128
+    micro_batch_size_per_device_for_update: 4
+    micro_batch_size_per_device_for_experience: 16
+    padding_free: true
+    model: {model_path: Qwen/Qwen2.5-7B-Instruct, enable_gradient_checkpointing: true, trust_remote_code: false}
+    optim: {lr: 1.0e-6, weight_decay: 1.0e-2, strategy: adamw, lr_warmup_ratio: 0.0}
+    fsdp: {enable_full_shard: true, enable_rank0_init: true}
+    offload: {offload_params: true, offload_optimizer: true}
+  rollout: {temperature: 1.0, n: 5, tensor_parallel_size: 2, val_override_config: {temperature: 0.5, n: 1}}
+  ref: {fsdp: {enable_cpu_offload: true}, offload: {offload_params: false}}
+  reward: {reward_type: function, score_function: r1v, skip_special_tokens: true}
+trainer: {total_episodes: 15, logger: [console, wandb], n_gpus_per_node: 4, val_freq: 5, save_freq: 5, save_limit: 1, save_checkpoint_path: null}
+"""
+
+
+def test_config_merge_like_the_launch_scripts(tmp_path):
+    y = tmp_path / "config.yaml"
+    y.write_text(REF_YAML)
+    cfg = load_config([f"config={y}", "data.train_files=hub/STVQA-7K@train", "worker.actor.model.model_path=Qwen/Qwen2.5-VL-7B-Instruct",
+                       "worker.reward.score_function=spatial_sgg", "trainer.experiment_name=spatialthinker10k_7B", "trainer.n_gpus_per_node=4",
+                       "trainer.save_checkpoint_path=ckpts/x", "worker.actor.fsdp.torch_dtype=bf16", "worker.actor.optim.strategy=adamw_bf16",
+                       "worker.rollout.n=8", "trainer.max_steps=75", "trainer.total_episodes=75", "data.answer_key=answer_option_text",
+                       "data.image_key=images", "data.val_batch_size=8", "data.max_prompt_length=6144", "data.max_response_length=2048",
+                       "worker.rollout.max_num_batched_tokens=8192", "data.format_prompt=<image> You FIRST think\n about it.\n Q. ",
+                       "trainer.logger=['console','swanlab']"])
+    cfg.deep_post_init()
+    assert cfg.worker.rollout.n == 8 and cfg.worker.rollout.prompt_length == 6144 and cfg.worker.rollout.response_length == 2048
+    assert cfg.worker.actor.use_kl_loss and cfg.worker.actor.kl_penalty == "low_var_kl" and cfg.worker.actor.kl_coef == 1e-2
+    assert cfg.worker.ref.padding_free is True and cfg.worker.ref.micro_batch_size_per_device_for_experience == 16
+    assert cfg.worker.actor.model.tokenizer_path == "Qwen/Qwen2.5-VL-7B-Instruct"
+    assert cfg.trainer.logger == ("console", "swanlab") and cfg.trainer.max_steps == 75 and cfg.trainer.save_checkpoint_path == "ckpts/x"
+    assert cfg.data.format_prompt == "<image> You FIRST think\n about it.\n Q. "          # multi-line strings survive verbatim
+    assert cfg.worker.rollout.val_override_config == {"temperature": 0.5, "n": 1}
+    assert PPOConfig().trainer.save_checkpoint_path is None
+    d = PPOConfig(); d.deep_post_init()
+    assert d.trainer.save_checkpoint_path == os.path.join("checkpoints", "easy_r1", "demo")
+    with pytest.raises(KeyError):
+        load_config(["data.no_such_key=1"])
+    with pytest.raises(ValueError):
+        load_config(["worker.rollout.n=abc"])
+    json.dumps(cfg.to_dict())
+
+
+def _proto(n=8):
+    return DataProto.from_single_dict({"a": torch.arange(n * 2).view(n, 2), "b": torch.arange(n).float(),
+                                       "s": np.array([f"s{i}" for i in range(n)], dtype=object)}, meta_info={"t": 1.0})
+
+
+def test_dataproto_semantics():
+    d = _proto(8)
+    assert len(d) == 8 and d[2].batch["b"].item() == 2.0 and d[2].non_tensor_batch["s"] == "s2"
+    parts = d.chunk(4)
+    assert [len(p) for p in parts] == [2, 2, 2, 2] and parts[3].non_tensor_batch["s"].tolist() == ["s6", "s7"] and parts[0].meta_info == {"t": 1.0}
+    with pytest.raises(AssertionError):
+        d.chunk(3)
+    back = DataProto.concat(parts)
+    assert torch.equal(back.batch["a"], d.batch["a"]) and back.non_tensor_batch["s"].tolist() == d.non_tensor_batch["s"].tolist()
+    r = d.repeat(3, interleave=True)
+    assert r.batch["b"][:4].tolist() == [0, 0, 0, 1] and r.non_tensor_batch["s"][:4].tolist() == ["s0", "s0", "s0", "s1"]
+    r2 = d.repeat(2, interleave=False)
+    assert r2.batch["b"][8].item() == 0 and r2.non_tensor_batch["s"][9] == "s1"
+    p = d.pop(batch_keys=["b"], non_tensor_batch_keys=["s"])
+    assert "b" not in d.batch and "s" not in d.non_tensor_batch and len(p) == 8
+    d.union(p)
+    assert "b" in d.batch
+    with pytest.raises(ValueError):
+        d.union(DataProto.from_dict({"b": torch.zeros(8)}))
+    d.reorder(torch.tensor([7, 6, 5, 4, 3, 2, 1, 0]))
+    assert d.batch["b"][0].item() == 7 and d.non_tensor_batch["s"][0] == "s7"
+    sel = d.select(batch_keys=["a"], non_tensor_batch_keys=[])
+    assert list(sel.batch.keys()) == ["a"] and sel.non_tensor_batch == {}
+    padded, pad = pad_dataproto_to_divisor(_proto(5), 4)
+    assert len(padded) == 8 and pad == 3 and len(unpad_dataproto(padded, pad)) == 5
+    with pytest.raises(AssertionError):
+        DataProto.from_dict({"a": torch.zeros(3), "b": torch.zeros(4)})
+
+
+def test_balanced_partitions_golden(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "balance.json"))):
+        parts = get_seqlen_balanced_partitions(case["lens"], case["k"], equal_size=True)
+        assert parts == case["parts"]
+        stats = log_seqlen_unbalance(case["lens"], parts, "global_seqlen")
+        assert stats["global_seqlen/balanced_max"] - stats["global_seqlen/balanced_min"] <= stats["global_seqlen/minmax_diff"] + max(case["lens"])
+
+
+class _Tok:
+    def decode(self, ids, skip_special_tokens=True):
+        return "".join(chr(int(i)) for i in ids)
+
+
+def test_reward_manager_places_score_on_last_valid_token():
+    from verl.workers.reward import CustomRewardManager
+    from verl.trainer.config import RewardConfig
+    texts = ["<think>a</think> <answer>cat</answer>", "junk"]
+    R = 48
+    resp = torch.zeros(2, R, dtype=torch.long)
+    mask = torch.zeros(2, R, dtype=torch.long)
+    for i, t in enumerate(texts):
+        resp[i, :len(t)] = torch.tensor([ord(c) for c in t]); mask[i, :len(t)] = 1
+    data = DataProto.from_dict({"responses": resp, "response_mask": mask},
+                               non_tensors={"ground_truth": np.array(["cat", "dog"], dtype=object), "problem": np.array(["p", "p"], dtype=object)})
+    rm = CustomRewardManager(_Tok(), RewardConfig(score_function="r1v"))
+    reward, metrics = rm(data)
+    assert reward[0, len(texts[0]) - 1].item() == 1.0 and reward[0].sum().item() == 1.0 and reward[1].sum().item() == 0.0
+    assert metrics["overall"] == [1.0, 0.0] and metrics["format"] == [1.0, 0.0]
+    with pytest.raises(NotImplementedError):
+        CustomRewardManager(_Tok(), RewardConfig(score_function="nope"))

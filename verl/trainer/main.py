@@ -1,0 +1,71 @@
+"""Entry point: `python3 -m verl.trainer.main config=<yaml> a.b.c=value ...` — same command line as the reference
+(verl/trainer/main.py:88-105; scripts/spatialthinker_*_grpo.sh drop in unchanged).
+
+Launch: one process per GPU.  When started as a single process on a node with several GPUs and
+trainer.n_gpus_per_node > 1, this module re-launches itself under torch.distributed.run (a CHILD process: nothing has
+touched the GPU yet) so the shipped scripts need no edit."""
+import json
+import os
+import subprocess
+import sys
+
+
+def _maybe_spawn(n_gpus: int) -> bool:
+    if "RANK" in os.environ or n_gpus <= 1:
+        return False
+    import torch
+    n = min(n_gpus, torch.cuda.device_count())          # device_count() does not initialise the GPU on this image
+    if n <= 1:
+        return False
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", os.environ.get("MASTER_PORT", "29531"), "-m", "verl.trainer.main"] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def main():
+    from .config import load_config
+    cfg = load_config(sys.argv[1:])
+    _maybe_spawn(cfg.trainer.n_gpus_per_node * cfg.trainer.nnodes)
+    cfg.deep_post_init()
+    rank = int(os.environ.get("RANK", 0))
+    if rank == 0:
+        print(json.dumps(cfg.to_dict(), indent=2))
+    import torch
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    from ..single_controller import SPMDWorkerGroup
+    from ..utils.dataset import RLHFDataset, SyntheticSTVQADataset
+    from ..utils.tokenizer import get_processor, get_tokenizer, is_synthetic
+    from ..workers.fsdp_workers import FSDPWorker
+    from ..workers.reward import CustomRewardManager
+    from .ray_trainer import RayPPOTrainer
+
+    mc = cfg.worker.actor.model
+    tokenizer = get_tokenizer(mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
+    processor = get_processor(mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
+    reward_fn = CustomRewardManager(tokenizer, cfg.worker.reward)
+
+    def dataset(spec):
+        if not spec:
+            return None
+        if spec.startswith("synthetic:") or is_synthetic(mc.model_path):
+            from spatialthinker_amd.pretrained import synthetic_config
+            mcfg, _ = synthetic_config(mc.model_path if is_synthetic(mc.model_path) else "random:7b")
+            tiny = mcfg.hidden_size <= 512
+            return SyntheticSTVQADataset(mcfg, tokenizer, size=max(4 * cfg.data.rollout_batch_size, 64), max_prompt_length=cfg.data.max_prompt_length,
+                                         seed=cfg.data.seed, grid=(1, 8, 8) if tiny else (1, 32, 42), text_tokens=(8, 12) if tiny else (200, 564))
+        return RLHFDataset(spec, tokenizer, processor, prompt_key=cfg.data.prompt_key, answer_key=cfg.data.answer_key, image_key=cfg.data.image_key,
+                           max_prompt_length=cfg.data.max_prompt_length, truncation="right", format_prompt=cfg.data.format_prompt,
+                           min_pixels=cfg.data.min_pixels, max_pixels=cfg.data.max_pixels, text_only=cfg.data.text_only)
+
+    # the trainer validates the batch-size relations on the user's numbers BEFORE the worker scales global_batch_size by
+    # rollout.n (ray_trainer.py:238-263 runs before fsdp_workers.py:130-136 in the reference too)
+    trainer = RayPPOTrainer(cfg, tokenizer, processor, None, None, reward_fn, reward_fn, dataset(cfg.data.train_files), dataset(cfg.data.val_files))
+    role = "actor_rollout" if cfg.algorithm.disable_kl else "actor_rollout_ref"      # colocated roles (ray/base.py:453-493)
+    wg = SPMDWorkerGroup(FSDPWorker(cfg.worker, role))
+    trainer.set_worker_groups(wg, wg)
+    trainer.init_workers()
+    trainer.fit()
+
+
+if __name__ == "__main__":
+    main()

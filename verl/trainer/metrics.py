@@ -1,0 +1,49 @@
+"""Step metrics with the reference's keys (verl/trainer/metrics.py:23-120)."""
+from typing import Any, Dict, List
+
+import numpy as np
+import torch
+
+from ..protocol import DataProto
+
+
+def reduce_metrics(metrics: Dict[str, List[Any]]) -> Dict[str, Any]:
+    return {k: float(np.mean(v)) for k, v in metrics.items()}
+
+
+def _stats(prefix: str, t: torch.Tensor) -> Dict[str, float]:
+    t = t.float()
+    return {f"{prefix}/mean": t.mean().item(), f"{prefix}/max": t.max().item(), f"{prefix}/min": t.min().item()}
+
+
+def compute_data_metrics(batch: DataProto, use_critic: bool = False) -> Dict[str, Any]:
+    b = batch.batch
+    R = b["responses"].size(-1)
+    mask = b["attention_mask"]
+    prompt_mask, resp_mask = mask[:, :-R].bool(), mask[:, -R:].bool()
+    plen, rlen = prompt_mask.sum(-1).float(), resp_mask.sum(-1).float()
+    out: Dict[str, Any] = {}
+    out.update(_stats("critic/score", b["token_level_scores"].sum(-1)))
+    out.update(_stats("critic/rewards", b["token_level_rewards"].sum(-1)))
+    out.update(_stats("critic/advantages", torch.masked_select(b["advantages"], resp_mask)))
+    out.update(_stats("critic/returns", torch.masked_select(b["returns"], resp_mask)))
+    out.update(_stats("response_length", rlen))
+    out["response_length/clip_ratio"] = (rlen == R).float().mean().item()
+    out.update(_stats("prompt_length", plen))
+    out["prompt_length/clip_ratio"] = (plen == prompt_mask.size(-1)).float().mean().item()
+    return out
+
+
+def compute_timing_metrics(batch: DataProto, timing_raw: Dict[str, float]) -> Dict[str, Any]:
+    n_resp = int(batch.batch["response_mask"].sum().item())
+    n_all = sum(batch.meta_info["global_token_num"])
+    per = {**dict.fromkeys(["gen", "reward"], n_resp), **dict.fromkeys(["ref", "old", "values", "adv", "update_critic", "update_actor"], n_all)}
+    out = {f"timing_s/{k}": v for k, v in timing_raw.items()}
+    out.update({f"timing_per_token_ms/{k}": timing_raw[k] * 1000 / per[k] for k in per.keys() & timing_raw.keys()})
+    return out
+
+
+def compute_throughout_metrics(batch: DataProto, timing_raw: Dict[str, float], n_gpus: int) -> Dict[str, Any]:
+    total = sum(batch.meta_info["global_token_num"])
+    t = timing_raw["step"]
+    return {"perf/total_num_tokens": total, "perf/time_per_step": t, "perf/throughput": total / (t * n_gpus)}

@@ -1,0 +1,200 @@
+"""FSDPWorker — the worker API surface of the reference (verl/workers/fsdp_workers.py:65-616) on the MI355X engine.
+
+Same constructor, roles and `@register`-tagged methods (init_model, generate_sequences, compute_log_probs,
+compute_ref_log_probs, update_actor, save_checkpoint, load_checkpoint) and the same DataProto key contract
+(SURVEY.md §8b).  What changed underneath: no FSDP sharding (a 7B actor + optimizer + frozen reference is ~130 GB of the
+288 GB HBM, so every rank keeps full replicas and gradients are all-reduced once per optimizer step over RCCL), no
+vLLM (the generator reads the actor's own weight buffer, so the per-step weight hand-off of fsdp_vllm.py:76-116 is
+free), no CPU offload.  The `fsdp.*`, `offload.*`, `rollout.tensor_parallel_size`, `gpu_memory_utilization` keys are
+accepted and ignored."""
+from __future__ import annotations
+
+import os
+import time
+from typing import Literal
+
+import numpy as np
+import psutil
+import torch
+import torch.distributed as dist
+
+from spatialthinker_amd.actor import ActorHyper, PolicyEngine
+from spatialthinker_amd.pretrained import load_model, save_hf
+from spatialthinker_amd.rollout import Generator
+
+from ..protocol import DataProto
+from ..single_controller.decorator import Dispatch, register
+from ..utils.flops_counter import FlopsCounter
+from ..utils.tokenizer import get_processor, get_tokenizer
+
+
+class FSDPWorker:
+    def __init__(self, config, role: Literal["actor", "critic", "rollout", "ref", "actor_rollout", "actor_rollout_ref"]):
+        self.config, self.role = config, role
+        self.world_size = int(os.environ.get("WORLD_SIZE", 1))
+        self.rank = int(os.environ.get("RANK", 0))
+        if self.world_size > 1 and not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+            dist.init_process_group(backend="nccl")           # "nccl" IS RCCL on ROCm
+        self._is_actor = role in ("actor", "actor_rollout", "actor_rollout_ref")
+        self._is_rollout = role in ("rollout", "actor_rollout", "actor_rollout_ref")
+        self._is_ref = role in ("ref", "actor_rollout_ref")
+        if role == "critic":
+            raise NotImplementedError("the critic is only used by adv_estimator=gae, outside the GRPO path")
+        if self._is_actor:
+            self._init_batch_sizes(self.config.actor)
+
+    def _init_batch_sizes(self, cfg):
+        """fsdp_workers.py:130-147: global batch is counted in rollouts, then split over the ranks."""
+        if self.config.rollout.n > 1:
+            cfg.global_batch_size *= self.config.rollout.n
+        cfg.global_batch_size_per_device = cfg.global_batch_size // self.world_size
+        if cfg.global_batch_size_per_device == 0:
+            raise ValueError("actor global batch size * ulysses size must be larger than num gpus.")
+        if cfg.global_batch_size_per_device % cfg.micro_batch_size_per_device_for_update != 0:
+            raise ValueError("actor global batch size per device must be divisible by the micro batch size.")
+
+    def print_rank0(self, *a):
+        if self.rank == 0:
+            print(*a, flush=True)
+
+    # ------------------------------------------------------------------------------------------------
+    @register(dispatch_mode=Dispatch.ONE_TO_ALL)
+    def init_model(self):
+        mc = self.config.actor.model
+        self.tokenizer = get_tokenizer(mc.tokenizer_path or mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
+        self.processor = get_processor(mc.tokenizer_path or mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
+        if self._is_actor:
+            a = self.config.actor
+            if a.optim.strategy not in ("adamw_bf16", "adamw"):
+                raise NotImplementedError(f"Optimizer {a.optim.strategy} not supported.")
+            if a.optim.strategy == "adamw":
+                self.print_rank0("note: optim.strategy=adamw runs the bf16-state Kahan AdamW kernel (the shipped scripts use adamw_bf16)")
+            cfg, store, special = load_model(mc.model_path, trainable=True)
+            hyper = ActorHyper(micro_batch_size_per_device_for_update=a.micro_batch_size_per_device_for_update,
+                               micro_batch_size_per_device_for_experience=a.micro_batch_size_per_device_for_experience,
+                               global_batch_size_per_device=a.global_batch_size_per_device, max_grad_norm=a.max_grad_norm,
+                               clip_ratio_low=a.clip_ratio_low, clip_ratio_high=a.clip_ratio_high, clip_ratio_dual=a.clip_ratio_dual,
+                               ppo_epochs=a.ppo_epochs, use_kl_loss=a.use_kl_loss, disable_kl=a.disable_kl, kl_penalty=a.kl_penalty,
+                               kl_coef=a.kl_coef, lr=a.optim.lr, betas=tuple(a.optim.betas), weight_decay=a.optim.weight_decay,
+                               lr_warmup_steps=int(a.optim.lr_warmup_ratio * max(a.optim.training_steps, 0)))
+            self.model_config, self.special = cfg, special
+            self.actor = PolicyEngine(cfg, store, hyper)
+            self.flops_counter = FlopsCounter(cfg)
+            if self.world_size > 1:                          # sync_module_states: rank 0's weights everywhere (fsdp_workers.py:261-263)
+                dist.broadcast(store.flat, src=0)
+                store.refresh_transposes()
+        if self._is_rollout:
+            self.generator = Generator(self.actor.model)
+        if self._is_ref:
+            cfg, store, special = load_model(mc.model_path, trainable=False)
+            if self._is_actor:
+                store.flat.copy_(self.actor.store.flat)
+            elif self.world_size > 1:
+                dist.broadcast(store.flat, src=0)
+            self.model_config, self.special = cfg, special
+            self.ref_policy = PolicyEngine(cfg, store, None)
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _as_dict(data: DataProto):
+        d = {k: v for k, v in data.batch.items()}
+        d.update(data.non_tensor_batch)
+        return d
+
+    @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+    def generate_sequences(self, prompts: DataProto) -> DataProto:
+        assert self._is_rollout
+        r = self.config.rollout
+        over = {k: prompts.meta_info[k] for k in ("temperature", "n", "top_p", "top_k", "ignore_eos") if k in prompts.meta_info}
+        n = int(over.get("n", r.n))
+        temperature = float(over.get("temperature", r.temperature))
+        if float(over.get("top_p", r.top_p)) < 1.0 or int(over.get("top_k", r.top_k)) > 0:
+            raise NotImplementedError("top_p < 1 / top_k > 0 sampling is not built yet (shipped configs use 1.0 / -1)")
+        ids, mask, pos = prompts.batch["input_ids"], prompts.batch["attention_mask"], prompts.batch["position_ids"]
+        mm = prompts.non_tensor_batch.get("multi_modal_inputs")
+        px = gr = None
+        if mm is not None:
+            px = [m["pixel_values"] for m in mm]
+            gr = [m["image_grid_thw"] for m in mm]
+        eos = self.special["eos"]
+        self._gen_calls = getattr(self, "_gen_calls", 0) + 1
+        resp = self.generator.generate(ids, mask, pos, n=n, max_new_tokens=r.response_length, temperature=temperature,
+                                       eos_token_id=eos, pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls,
+                                       pixel_values=px, image_grid_thw=gr, ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)),
+                                       forced_lengths=prompts.meta_info.get("synthetic_response_lengths")).cpu()
+        # post-processing of vllm_rollout_spmd.py:144-188
+        if n > 1:
+            ids, mask, pos = (t.repeat_interleave(n, dim=0) for t in (ids, mask, pos))
+        eos_list = [eos] if isinstance(eos, int) else list(eos)
+        is_eos = torch.zeros_like(resp, dtype=torch.bool)
+        for e in eos_list:
+            is_eos |= resp.eq(e)
+        resp_mask = ((torch.cumsum(is_eos.long(), 1) - is_eos.long()) == 0).to(mask.dtype)
+        R = resp.shape[1]
+        delta = torch.arange(1, R + 1)
+        resp_pos = pos[..., -1:] + (delta.view(1, 1, -1) if pos.dim() == 3 else delta.view(1, -1))
+        batch = {"prompts": ids, "responses": resp, "input_ids": torch.cat([ids, resp], -1),
+                 "attention_mask": torch.cat([mask, resp_mask], -1), "response_mask": resp_mask,
+                 "position_ids": torch.cat([pos, resp_pos], -1)}
+        non_tensor = {}
+        if mm is not None:
+            non_tensor["multi_modal_inputs"] = np.repeat(mm, n, axis=0) if n > 1 else mm
+        return DataProto.from_dict(batch, non_tensors=non_tensor)
+
+    @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+    def compute_log_probs(self, data: DataProto) -> DataProto:
+        assert self._is_actor
+        t = self.config.rollout.temperature
+        data.meta_info["temperature"] = t
+        lp = self.actor.compute_log_prob(self._as_dict(data), t).cpu()
+        return DataProto.from_dict(tensors={"old_log_probs": lp}, meta_info={"temperature": t})
+
+    @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+    def compute_ref_log_probs(self, data: DataProto) -> DataProto:
+        assert self._is_ref
+        t = self.config.rollout.temperature
+        lp = self.ref_policy.compute_log_prob(self._as_dict(data), t, self.config.ref.micro_batch_size_per_device_for_experience).cpu()
+        return DataProto.from_dict(tensors={"ref_log_probs": lp})
+
+    @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+    def update_actor(self, data: DataProto) -> DataProto:
+        assert self._is_actor
+        torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        metrics = self.actor.update_policy(self._as_dict(data), data.meta_info["temperature"])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        est, promised = self.flops_counter.estimate_flops(data.meta_info["global_token_num"], dt)
+        metrics["perf/mfu_actor"] = est * self.config.actor.ppo_epochs / (promised * self.world_size)
+        metrics["perf/max_memory_allocated_gb"] = torch.cuda.max_memory_allocated() / (1024 ** 3)
+        metrics["perf/max_memory_reserved_gb"] = torch.cuda.max_memory_reserved() / (1024 ** 3)
+        metrics["perf/cpu_memory_used_gb"] = psutil.virtual_memory().used / (1024 ** 3)
+        return DataProto(non_tensor_batch={k: np.array([v] if np.isscalar(v) else v) for k, v in metrics.items()})
+
+    # ------------------------------------------------------------------------------------------------
+    @register(dispatch_mode=Dispatch.ONE_TO_ALL)
+    def save_checkpoint(self, path: str):
+        """Replicas are identical, so rank 0 writes ONE HF-format model + the optimizer state."""
+        assert self._is_actor
+        if self.rank == 0:
+            save_hf(self.actor.store, os.path.join(path, "huggingface"))
+            st = self.actor.store
+            torch.save({"m": st.m.cpu(), "v": st.v.cpu(), "c": st.c.cpu(), "opt_steps": self.actor.opt_steps,
+                        "sched_steps": self.actor.sched_steps}, os.path.join(path, "optim_world_size_1_rank_0.pt"))
+        if self.world_size > 1:
+            dist.barrier()
+
+    @register(dispatch_mode=Dispatch.ONE_TO_ALL)
+    def load_checkpoint(self, path: str):
+        if path is None:
+            return
+        from safetensors.torch import load_file
+        sd = load_file(os.path.join(path, "huggingface", "model.safetensors"))
+        self.actor.store.load_hf_state_dict(sd)
+        opt = torch.load(os.path.join(path, "optim_world_size_1_rank_0.pt"), map_location="cpu")
+        st = self.actor.store
+        st.m.copy_(opt["m"]); st.v.copy_(opt["v"]); st.c.copy_(opt["c"])
+        self.actor.opt_steps, self.actor.sched_steps = opt["opt_steps"], opt["sched_steps"]
+        if self.world_size > 1:
+            dist.barrier()

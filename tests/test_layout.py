@@ -1,0 +1,49 @@
+"""Repository contract checks that need no GPU: the C-ABI library exports every symbol include/st_hip.h declares, and the
+product path never imports the oracle (only tests/, __graft_entry__.smoke and bench.py's cpu_baseline may)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from spatialthinker_amd.lib import LIB_PATH, parse_header
+    protos = parse_header()
+    assert len(protos) >= 30
+    dll = ctypes.CDLL(LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in include/st_hip.h but not exported"
+    assert dll.st_version() == 1
+    for name, (_res, argtypes, argnames) in protos.items():
+        assert len(argtypes) == len(argnames)
+        if name not in ("st_version", "st_arch", "st_prof_enable", "st_prof_read", "st_prof_disable"):
+            assert argnames[-1] == "stream", f"{name}: every compute entry takes the stream last"
+
+
+def test_product_code_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    bad = []
+    for top in ("spatialthinker_amd", "verl"):
+        for dirpath, _dirs, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py") and pat.search(open(os.path.join(dirpath, f)).read()):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in pat.finditer(bench)]
+    assert uses and all(bench.rfind("def ", 0, u) == bench.find("def cpu_baseline") for u in uses), "bench.py may touch oracle/ only in cpu_baseline"
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+    import spatialthinker_amd.lib as L
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(L, "_lib", None)
+    try:
+        L.lib()
+    except ImportError as e:
+        assert "no CPU fallback" in str(e) or "not found" in str(e)
+    else:
+        raise AssertionError("lib() must raise when libst_hip.so is missing")
+    importlib.reload(L)

@@ -114,6 +114,11 @@ int st_gelu_bwd(const st_bf16* x, const st_bf16* dy, st_bf16* dx, int64_t n, st_
 int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
                int accumulate, int M, int N, int K, st_stream_t stream);
+/* Tuning/inspection entry: the same GEMM with an explicit tile variant (0: 128x128 2-stage, 1: 128x128 3-stage,
+ * 2: 256x128 2-stage, 3: 256x128 3-stage, 4: 256x256 2-stage, 5: 128x256 3-stage).  st_gemm_nt picks per shape. */
+int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
+                       const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc, int accumulate,
+                       int M, int N, int K, st_stream_t stream);
 /* Decode-shaped variant (M <= 256, the rollout's one-token-per-sequence GEMMs: a weight stream bound by HBM,
  * 2*N*K bytes).  scratch (scratch_elems floats, contents irrelevant) receives the split-K partial slabs
  * [split][M][N], summed in a fixed order by a finish kernel; NULL disables split-K. */
@@ -152,13 +157,14 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
  * lse = -inf. */
 int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
-                       const int32_t* o_beg /* output row base per sequence, NULL = q_beg */, int n_seq, int T_out, int n_q,
-                       int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse /* (n_q, T_out) */, int max_q,
+                       const int32_t* o_beg /* output row base per sequence, NULL = q_beg */,
+                       int q_group /* g > 0: query row R = (sample R/g, head h*g + R%g) read in place from (B, n_q*D); 0: plain rows */,
+                       int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse /* (n_q, T_out) */, int max_q,
                        st_stream_t stream);
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
 int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows,
-                  int heads, int D, st_stream_t stream);
+                  int heads, int D, int q_group /* g > 0: write row r, head h to out[r/g][(h*g + r%g)*D] */, st_stream_t stream);
 /* KV-cache append: for each sample b (active[b] != 0 or active NULL) copy the K and V column slices of qkv row b
  * into kg/vg[b, gen_len[b], :width]; if increment, gen_len[b] += 1 afterwards. */
 int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width, st_bf16* kg, st_bf16* vg,

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                                       const uint16_t* __restrict__ v, int64_t ldv,
                                                       const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end,
                                                       const int32_t* __restrict__ k_beg, const int32_t* __restrict__ k_end,
-                                                      const int32_t* __restrict__ o_beg, int T, int n_q, int n_kv,
+                                                      const int32_t* __restrict__ o_beg, int qgroup, int T, int n_q, int n_kv,
                                                       float scale_log2, uint16_t* __restrict__ out, int64_t ldo,
                                                       float* __restrict__ lse) {
     using C = AttnCfg<D>;
@@ -89,7 +89,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     // Q fragments (MFMA B operand: n = q row, k = 8 contiguous d), resident for the whole kernel
     bf16x8 qf[C::KS];
     {
-        const uint16_t* qp = q + (int64_t)(s0 + (q_ok ? q_idx : 0)) * ldq + (int64_t)h * D + half * 8;
+        // qgroup > 0 (decode): query row R of this launch is (sample b = R / g, group-local head R % g) of KV head h, read
+        // straight from the (B, n_q*D) projection output — no permuted copy of q is ever made.
+        const int64_t R = s0 + (q_ok ? q_idx : 0);
+        const uint16_t* qp = qgroup > 0 ? q + (R / qgroup) * ldq + ((int64_t)h * qgroup + R % qgroup) * D + half * 8
+                                        : q + R * ldq + (int64_t)h * D + half * 8;
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
             uint4 r = q_ok ? *reinterpret_cast<const uint4*>(qp + s * 16) : make_uint4(0, 0, 0, 0);
@@ -503,8 +507,8 @@ extern "C" {
 
 static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                            const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
-                           const int32_t* o_beg, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal, st_bf16* out,
-                           int64_t ldo, float* lse, int max_q, int klass, st_stream_t stream) {
+                           const int32_t* o_beg, int qgroup, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
+                           st_bf16* out, int64_t ldo, float* lse, int max_q, int klass, st_stream_t stream) {
     if (!q || !k || !v || !q_beg || !q_end || !k_beg || !k_end || !out || !lse || n_seq <= 0 || T <= 0 || n_q <= 0 || n_kv <= 0 ||
         (n_q % n_kv) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || max_q <= 0)
         return ST_EINVAL;
@@ -512,7 +516,7 @@ static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int6
     const dim3 grid(st_cdiv(max_q, Q_TILE), n_q, n_seq);
     const float sl2 = scale * LOG2E;
     StProfScope ps(klass, s, 0.0);
-#define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, T, n_q, n_kv, sl2, out, ldo, lse)
+#define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
     if (D == 128 && causal) ST_FWD(128, true);
     else if (D == 128) ST_FWD(128, false);
     else if (D == 80 && !causal) ST_FWD(80, false);
@@ -527,15 +531,15 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal, st_bf16* out,
                 int64_t ldo, float* lse, int max_seqlen, st_stream_t stream) {
     if (!cu_seqlens) return ST_EINVAL;
-    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, cu_seqlens, cu_seqlens + 1, cu_seqlens, cu_seqlens + 1, nullptr, n_seq, T, n_q, n_kv, D,
+    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, cu_seqlens, cu_seqlens + 1, cu_seqlens, cu_seqlens + 1, nullptr, 0, n_seq, T, n_q, n_kv, D,
                            scale, causal, out, ldo, lse, max_seqlen, D == 128 ? ST_K_ATTN_FWD : ST_K_VIT_ATTN, stream);
 }
 
 int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
-                       const int32_t* o_beg, int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo,
-                       float* lse, int max_q, st_stream_t stream) {
-    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, n_seq, T_out, n_q, n_kv, D, scale, 0, out, ldo,
+                       const int32_t* o_beg, int q_group, int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out,
+                       int64_t ldo, float* lse, int max_q, st_stream_t stream) {
+    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, q_group, n_seq, T_out, n_q, n_kv, D, scale, 0, out, ldo,
                            lse, max_q, ST_K_DECODE_ATTN, stream);
 }
 

@@ -26,7 +26,7 @@ __global__ void inc_len_kernel(int32_t* __restrict__ gen_len, const int32_t* __r
 // out[r, h, :] = sum_p w_p * part[p][r, h, :],  w_p = exp(lse[h][p*rows + r] - m) / sum_p exp(...)  (flash-decoding merge of
 // P partial attentions over disjoint key sets).  parts: (P*rows, heads*D) bf16, lse: (heads, P*rows) fp32.
 __global__ void attn_merge_kernel(const uint16_t* __restrict__ parts, int64_t ldp, const float* __restrict__ lse, int P,
-                                  uint16_t* __restrict__ out, int64_t ldo, int rows, int heads, int D) {
+                                  uint16_t* __restrict__ out, int64_t ldo, int rows, int heads, int D, int qgroup) {
     const int chunks = D >> 3;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)rows * heads * chunks) return;
@@ -53,7 +53,9 @@ __global__ void attn_merge_kernel(const uint16_t* __restrict__ parts, int64_t ld
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] *= inv;
     }
-    *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + h * D + c) = pack8(acc);
+    // qgroup > 0: grouped row r = (sample r / g, group-local head r % g) -> final (B, n_q*D) layout, query head h*g + r%g
+    uint16_t* op = qgroup > 0 ? out + (int64_t)(r / qgroup) * ldo + ((int64_t)h * qgroup + r % qgroup) * D + c : out + (int64_t)r * ldo + h * D + c;
+    *reinterpret_cast<uint4*>(op) = pack8(acc);
 }
 
 // ---- sampling --------------------------------------------------------------------------------
@@ -137,10 +139,10 @@ int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width
 }
 
 int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows, int heads,
-                  int D, st_stream_t stream) {
+                  int D, int q_group, st_stream_t stream) {
     if (!parts || !lse || !out || n_parts <= 0 || rows <= 0 || heads <= 0 || (D & 7) || (ldp & 7) || (ldo & 7)) return ST_EINVAL;
     hipLaunchKernelGGL(attn_merge_kernel, dim3(st_cdiv((int64_t)rows * heads * (D / 8), 256)), dim3(256), 0, (hipStream_t)stream, parts,
-                       ldp, lse, n_parts, out, ldo, rows, heads, D);
+                       ldp, lse, n_parts, out, ldo, rows, heads, D, q_group);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -320,6 +320,10 @@ static int launch_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     return e == hipSuccess ? 0 : (int)e;
 }
 
+int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
+                          const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K,
+                          hipStream_t s);
+
 extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                           const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
                           int accumulate, int M, int N, int K, st_stream_t stream) {
@@ -331,6 +335,10 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     hipStream_t s = (hipStream_t)stream;
     const bool hb = bias != nullptr, hr = residual != nullptr;
     StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);   // MFMA-bound class only (roofline.achieved)
+    // tile choice (tools/gemm_tune.py on MI355X): the 256x256 tile (8 waves, 128 KiB LDS, 128 flop/B of L2 traffic) wins
+    // by 10-15 % once there are >= ~1.75 workgroups per CU; below that the 128x128 tile (2 workgroups/CU) fills the chip better.
+    if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 450)
+        return st_gemm_tile_dispatch(4, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);
 #define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
     if (out_bf16) {
         if (hb && hr) GO(true, true, true, false, false);

@@ -1,0 +1,229 @@
+// gemm_tiles.hip — tile-shape / pipeline-depth family of the bf16 MFMA GEMM (C = A B^T), used (a) by the tuning
+// harness tools/gemm_tune.py through st_gemm_nt_variant and (b) by st_gemm_nt for the shapes where a larger tile wins.
+//
+// Same building blocks as gemm.hip (LDS-DMA staging, XOR-swizzled lane-linear LDS image, MFMA 16x16x32 with swapped
+// operands) generalised over:
+//   BM x BN  output tile, WM x WN waves (each wave (BM/WM) x (BN/WN)), STAGES LDS ring slots of (BM+BN) x 64 bf16.
+// STAGES == 2: one `vmcnt(0)` + barrier per K-tile (loads of tile t+1 fly during the MFMAs of tile t).
+// STAGES == 3: counted `vmcnt(N)` + raw s_barrier: two K-tiles of LDS-DMA stay in flight across the barrier
+//              (cdna_hip_programming.md §5 "Pipelining across barriers"); the wait counts only THIS wave's own loads,
+//              the barrier publishes every wave's landed pieces.
+// Why larger tiles: the 128x128x64 tile moves 32 KiB per 2.1 MFLOP = 64 flop/B, i.e. ~39 TB/s of L2->LDS traffic at the
+// 2.5 PF MFMA peak — above the ~34 TB/s aggregate L2 bandwidth; 256x128 needs 29 TB/s, 256x256 19.5 TB/s.
+#include "common.h"
+
+__device__ __forceinline__ void glds16t(const void* gsrc, char* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
+                                                                const uint16_t* __restrict__ B, int64_t ldb,
+                                                                const uint16_t* __restrict__ bias,
+                                                                const uint16_t* __restrict__ res, int64_t ldr,
+                                                                uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc,
+                                                                int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;            // wave tile
+    constexpr int TM = WTM / 16, TN = WTN / 16;            // MFMA tiles per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INST = BM / 8, B_INST = BN / 8;        // 1 KiB wave-instructions per operand tile
+    constexpr int PER_WAVE = (A_INST + B_INST) / NW;       // LDS-DMA instructions each wave issues per K-tile
+    static_assert(A_INST % NW == 0 && B_INST % NW == 0, "tile rows must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nb = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GM = (BM >= 256) ? 4 : 8;
+    const int per_group = GM * tiles_n;
+    const int group = bid / per_group, in_g = bid % per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    auto stage = [&](int kt, char* dst) {
+#pragma unroll
+        for (int j = 0; j < A_INST / NW; ++j) {
+            const int inst = wave * (A_INST / NW) + j;
+            const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
+            int gr = m0 + r; gr = gr < M ? gr : M - 1;
+            glds16t(A + (int64_t)gr * lda + kt * 64 + kc * 8, dst + inst * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < B_INST / NW; ++j) {
+            const int inst = wave * (B_INST / NW) + j;
+            const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
+            int gr = n0 + r; gr = gr < N ? gr : N - 1;
+            glds16t(B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + inst * 1024);
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / 64;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);
+
+    const int frow = lane & 15, fk = lane >> 4;
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
+        if (STAGES == 2 || kt + STAGES - 2 >= nk) wait_vmcnt<0>();
+        else wait_vmcnt<(STAGES - 2) * PER_WAVE>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                       // keep LDS reads / DMA issue below the barrier
+        if (kt + STAGES - 1 < nk) {
+            int ns = slot + STAGES - 1; ns = ns >= STAGES ? ns - STAGES : ns;
+            stage(kt + STAGES - 1, smem + ns * STAGE);
+        }
+        const char* la = smem + slot * STAGE;
+        const char* lb = la + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[TM], bfr[TN];
+            const int kc = s * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ra = wm * WTM + i * 16 + frow;
+                af[i] = *reinterpret_cast<const bf16x8*>(la + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int rb = wn * WTN + i * 16 + frow;
+                bfr[i] = *reinterpret_cast<const bf16x8*>(lb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * WTM + mi * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            const bool full = (n + 3 < N);
+            if (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (full || n + r < N) v[r] += bf2f(bias[n + r]);
+            }
+            if (HAS_RES) {
+                const uint16_t* rp = res + (int64_t)m * ldr + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (full || n + r < N) v[r] += bf2f(rp[r]);
+            }
+            if (OUT_BF16) {
+                uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                if (full && ((ldc & 3) == 0)) {
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+                }
+            } else {
+                float* cp = Cf + (int64_t)m * ldc + n;
+                if (full && ((ldc & 3) == 0)) {
+                    float4 o = ACCUM ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = (ACCUM ? cp[r] : 0.f) + v[r];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC>
+static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
+                       int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    constexpr int smem = STAGES * (BM + BN) * 128;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC>;
+    static bool configured = false;
+    if (!configured) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
+    const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K,
+                       tiles_m, tiles_n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// variant ids: 0 = 128x128 2x2 waves 2 stages, 1 = 128x128 3 stages, 2 = 256x128 4x2 2 stages, 3 = 256x128 4x2 3 stages,
+//              4 = 256x256 4x2 2 stages, 5 = 128x256 2x4 3 stages
+int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
+                          const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K,
+                          hipStream_t s) {
+#define TILE_GO(BM, BN, WM, WN, ST)                                                                                              \
+    do {                                                                                                                         \
+        if (Cb) {                                                                                                                \
+            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
+            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
+            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
+            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
+        }                                                                                                                        \
+        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
+        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
+    } while (0)
+    switch (variant) {
+        case 0: TILE_GO(128, 128, 2, 2, 2);
+        case 1: TILE_GO(128, 128, 2, 2, 3);
+        case 2: TILE_GO(256, 128, 4, 2, 2);
+        case 3: TILE_GO(256, 128, 4, 2, 3);
+        case 4: TILE_GO(256, 256, 4, 2, 2);
+        case 5: TILE_GO(128, 256, 2, 4, 3);
+        default: return ST_EINVAL;
+    }
+#undef TILE_GO
+}
+
+extern "C" int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
+                                  const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc, int accumulate,
+                                  int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || M <= 0 || N <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || ((out_bf16 == nullptr) == (out_f32 == nullptr)))
+        return ST_EINVAL;
+    if (out_f32 && (bias || residual)) return ST_EINVAL;
+    return st_gemm_tile_dispatch(variant, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K,
+                                 (hipStream_t)stream);
+}

@@ -173,6 +173,18 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
     return c
 
 
+def gemm_nt_variant(variant, a, b, out=None, out_f32=None, accumulate=False, bias=None, residual=None):
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None and out_f32 is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    c = out if out_f32 is None else out_f32
+    lib().st_gemm_nt_variant(int(variant), _p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
+                             residual.stride(0) if residual is not None else 0, _p(out) if out_f32 is None else None, _p(out_f32),
+                             c.stride(0), int(accumulate), M, N, K, _s())
+    return c
+
+
 def transpose(x, out=None):
     R, C = x.shape
     o = torch.empty(C, R, dtype=BF16, device=x.device) if out is None else out
@@ -280,17 +292,17 @@ def prof_read(klass: int):
 
 
 # ------------------------------------------------------------------ rollout (decode) kernels
-def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, scale, out, lse, o_beg=None):
+def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, scale, out, lse, o_beg=None, q_group=0):
     """out: (T_out, n_q*D) bf16 slab buffer, lse: (n_q, T_out) fp32 — both caller-owned (several launches fill disjoint slabs)."""
     lib().st_attn_fwd_ranges(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(q_beg), _p(q_end), _p(k_beg), _p(k_end),
-                             _p(o_beg), q_beg.numel(), out.shape[0], n_q, n_kv, D, scale, _p(out), out.stride(0), _p(lse), int(max_q), _s())
+                             _p(o_beg), int(q_group), q_beg.numel(), out.shape[0], n_q, n_kv, D, scale, _p(out), out.stride(0), _p(lse), int(max_q), _s())
     return out, lse
 
 
-def attn_merge(parts, lse, n_parts, heads, D, out=None):
+def attn_merge(parts, lse, n_parts, heads, D, out=None, q_group=0):
     rows = parts.shape[0] // n_parts
     o = torch.empty(rows, heads * D, dtype=BF16, device=parts.device) if out is None else out
-    lib().st_attn_merge(_p(parts), parts.stride(0), _p(lse), n_parts, _p(o), o.stride(0), rows, heads, D, _s())
+    lib().st_attn_merge(_p(parts), parts.stride(0), _p(lse), n_parts, _p(o), o.stride(0), rows, heads, D, int(q_group), _s())
     return o
 
 

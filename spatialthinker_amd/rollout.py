@@ -105,6 +105,7 @@ class Generator:
         parts = torch.empty((C + 1) * rows_all, width, dtype=BF16, device=dev)
         lse_parts = torch.empty(nkv, (C + 1) * rows_all, dtype=F32, device=dev)
         xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
+        abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)              # attention output, pad rows stay zero
         logits = torch.empty(Bp if Bp <= 256 else B, c.vocab_size, dtype=BF16, device=dev)
         ops.gemm_nt(hn, head, out=logits[:B])
         step_t = torch.zeros(1, dtype=I64, device=dev)
@@ -135,14 +136,12 @@ class Generator:
                 qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
                 ops.rope_apply_(qkv[:B], cos, sin, nq + nkv, D)
                 ops.kv_append_(qkv[:B], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
-                q2 = qkv[:B, :nq * D].view(B, nkv, g, D).permute(0, 2, 1, 3).reshape(B * g, width)
-                ops.attn_fwd_ranges(q2, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob1)
-                ops.attn_fwd_ranges(q2, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
-                                    nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2)
-                om = ops.attn_merge(parts, lse_parts, C + 1, nkv, D)
-                a = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)
-                a[:B] = om.view(B, g, nkv, D).permute(0, 2, 1, 3).reshape(B, nq * D)
-                x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x)
+                ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts,
+                                    o_beg=ob1, q_group=g)
+                ops.attn_fwd_ranges(qkv, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
+                                    nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
+                ops.attn_merge(parts, lse_parts, C + 1, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
+                x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
                 h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
                 mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
                 x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)

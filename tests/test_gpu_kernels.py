@@ -264,7 +264,7 @@ def test_sumsq(ops):
 
 
 # ------------------------------------------------------------------ GEMM & layout helpers
-@pytest.mark.parametrize("M_,N,K", [(128, 128, 64), (256, 384, 512), (200, 1000, 256), (1, 136, 128), (517, 264, 3584), (64, 37888 // 8, 320)])
+@pytest.mark.parametrize("M_,N,K", [(128, 128, 64), (256, 384, 512), (200, 1000, 256), (1, 136, 128), (517, 264, 3584), (64, 37888 // 8, 320), (2300, 12900, 128)])
 def test_gemm_nt(ops, M_, N, K):
     rs = np.random.RandomState(M_ + N + K)
     a = bf(rs.standard_normal((M_, K)))

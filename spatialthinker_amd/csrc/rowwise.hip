@@ -139,6 +139,39 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const uint16_t* __rest
     }
 }
 
+// Small-T variant (decode: one token per live sequence): one 256-thread workgroup per row so a 64-row call still puts 64
+// workgroups in flight and the row is touched once per thread (row kept in registers between the two passes).
+__global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                             const uint16_t* __restrict__ w, float eps,
+                                                             uint16_t* __restrict__ y, int64_t ldy,
+                                                             float* __restrict__ rstd_out, int H) {
+    __shared__ float part[4];
+    const int row = blockIdx.x;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    uint16_t* yr = y + (int64_t)row * ldy;
+    float f[2][8];
+    float ss = 0.f;
+    int cnt = 0;
+    for (int i = threadIdx.x * 8; i < H && cnt < 2; i += 2048, ++cnt) {
+        unpack8(*reinterpret_cast<const uint4*>(xr + i), f[cnt]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[cnt][j] * f[cnt][j];
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)H + eps);
+    if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+    cnt = 0;
+    for (int i = threadIdx.x * 8; i < H && cnt < 2; i += 2048, ++cnt) {
+        float wf[8];
+        unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[cnt][j] = wf[j] * bfround(f[cnt][j] * rstd);
+        *reinterpret_cast<uint4*>(yr + i) = pack8(f[cnt]);
+    }
+}
+
 // RMSNorm backward, two kernels so that both are bandwidth-shaped:
 //   dx: one wave per row (T waves in flight): pass 1 dot = sum(dy*w*xhat) by wave shuffles, pass 2 (row re-read from L1/L2)
 //       dx = rstd*(dy*w - xhat*dot/H) (+ dres);
@@ -225,7 +258,10 @@ int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, s
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     StProfScope ps(ST_K_RMSNORM, s, 4.0 * (double)T * (double)H);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
+    if (T <= 1024 && H <= 4096)
+        hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, H);
+    else
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
     ST_CHECK_LAUNCH();
     return 0;
 }

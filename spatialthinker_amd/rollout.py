@@ -99,11 +99,15 @@ class Generator:
         ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
         qb1, kb1, ke1, ob1 = ti(qb1_np), ti(kb1_np), ti(ke1_np), ti(ob1_np)
         qe1 = qb1 + n * g
-        qb2 = (ar * g).contiguous(); qe2 = qb2 + g
-        kb2 = (ar * R).contiguous()
-        ob2 = (C * rows_all + ar * g).contiguous()
-        parts = torch.empty((C + 1) * rows_all, width, dtype=BF16, device=dev)
-        lse_parts = torch.empty(nkv, (C + 1) * rows_all, dtype=F32, device=dev)
+        # generated partial: one "sequence" per (key chunk c, sample b); chunks beyond the current length are empty ranges
+        Cg = max(1, -(-R // CK))
+        qb2 = (ar * g).repeat(Cg).contiguous(); qe2 = qb2 + g
+        kbase = (ar * R).repeat(Cg)
+        kb2 = (kbase + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(B) * CK).contiguous()
+        ob2 = ((C + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(B)) * rows_all + (ar * g).repeat(Cg)).contiguous()
+        NP = C + Cg
+        parts = torch.empty(NP * rows_all, width, dtype=BF16, device=dev)
+        lse_parts = torch.empty(nkv, NP * rows_all, dtype=F32, device=dev)
         xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
         abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)              # attention output, pad rows stay zero
         logits = torch.empty(Bp if Bp <= 256 else B, c.vocab_size, dtype=BF16, device=dev)
@@ -129,7 +133,7 @@ class Generator:
             cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
             ops.embed_gather(w["embed"], tok32, out=xbuf[:B])
             x = xbuf
-            ke2 = kb2 + gen_len + 1
+            ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (gen_len + 1).repeat(Cg)), kb2).contiguous()
             for layer in range(L):
                 p = f"l.{layer}."
                 h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
@@ -140,7 +144,7 @@ class Generator:
                                     o_beg=ob1, q_group=g)
                 ops.attn_fwd_ranges(qkv, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
                                     nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
-                ops.attn_merge(parts, lse_parts, C + 1, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
+                ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
                 x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
                 h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
                 mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))

@@ -11,6 +11,7 @@
 // Why larger tiles: the 128x128x64 tile moves 32 KiB per 2.1 MFLOP = 64 flop/B, i.e. ~39 TB/s of L2->LDS traffic at the
 // 2.5 PF MFMA peak — above the ~34 TB/s aggregate L2 bandwidth; 256x128 needs 29 TB/s, 256x256 19.5 TB/s.
 #include "common.h"
+#include <type_traits>
 
 __device__ __forceinline__ void glds16t(const void* gsrc, char* lds_dst_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -28,6 +29,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// Compile-time unrolled sched_group_barrier pattern (the builtin wants literal arguments): per slot one DS read, one MFMA,
+// optionally one VMEM (LDS-DMA) issue, then the slot's remaining MFMAs.
+template <int I, int SLOTS, int BASE, int EXTRA, int NVMEM>
+__device__ __forceinline__ void pin_schedule() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (I < NVMEM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    constexpr int REST = BASE - 1 + (I < EXTRA ? 1 : 0);
+    if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+    if constexpr (I + 1 < SLOTS) pin_schedule<I + 1, SLOTS, BASE, EXTRA, NVMEM>();
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM>
@@ -93,40 +106,62 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 
     const int frow = lane & 15, fk = lane >> 4;
     int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    auto tile_body = [&](int kt, auto prefetch_tag) {
+        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
         // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
-        if (STAGES == 2 || kt + STAGES - 2 >= nk) wait_vmcnt<0>();
+        if (STAGES == 2 || !PREFETCH) wait_vmcnt<0>();          // tail tiles: nothing younger is in flight to count
         else wait_vmcnt<(STAGES - 2) * PER_WAVE>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                       // keep LDS reads / DMA issue below the barrier
-        if (kt + STAGES - 1 < nk) {
-            int ns = slot + STAGES - 1; ns = ns >= STAGES ? ns - STAGES : ns;
-            stage(kt + STAGES - 1, smem + ns * STAGE);
-        }
         const char* la = smem + slot * STAGE;
         const char* lb = la + A_BYTES;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM], bfr[TN];
+        // fragment double-buffering: the LDS reads of k-step s+1 are issued BEFORE the MFMAs of k-step s, so the ~130-cycle
+        // LDS latency hides under 2*TM*TN MFMAs instead of being exposed in front of every MFMA group
+        bf16x8 af[2][TM], bfr[2][TN];
+        auto load_frags = [&](int s, bf16x8 (&a_)[TM], bf16x8 (&b_)[TN]) {
             const int kc = s * 4 + fk;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int ra = wm * WTM + i * 16 + frow;
-                af[i] = *reinterpret_cast<const bf16x8*>(la + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
+                a_[i] = *reinterpret_cast<const bf16x8*>(la + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int rb = wn * WTN + i * 16 + frow;
-                bfr[i] = *reinterpret_cast<const bf16x8*>(lb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+                b_[i] = *reinterpret_cast<const bf16x8*>(lb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
             }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        };
+        load_frags(0, af[0], bfr[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        // the LDS-DMA issues of the next K-tile (~100 cycles of issue each) are spread between the MFMAs of k-step 0 as well,
+        // instead of sitting in front of them with the matrix pipe idle
+        if constexpr (PREFETCH) {
+            int ns = slot + STAGES - 1; ns = ns >= STAGES ? ns - STAGES : ns;
+            stage(kt + STAGES - 1, smem + ns * STAGE);
         }
+        load_frags(1, af[1], bfr[1]);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][ni], af[0][mi], acc[ni][mi], 0, 0, 0);
+        // pin the interleave: one LDS fragment read of k-step 1 per two MFMAs of k-step 0 (hipcc otherwise re-serialises
+        // the reads in front of their consumers to save registers)
+        {
+            constexpr int SLOTS = TM + TN, BASE = (TM * TN) / SLOTS, EXTRA = TM * TN - BASE * SLOTS;
+            pin_schedule<0, SLOTS, BASE, EXTRA, PREFETCH ? PER_WAVE : 0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][ni], af[1][mi], acc[ni][mi], 0, 0, 0);
         slot = slot + 1 == STAGES ? 0 : slot + 1;
-    }
+    };
+    int kt = 0;
+    for (; kt + STAGES - 1 < nk; ++kt) tile_body(kt, std::true_type{});
+    for (; kt < nk; ++kt) tile_body(kt, std::false_type{});
 
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {

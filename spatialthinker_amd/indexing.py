@@ -174,7 +174,11 @@ def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: 
     bb, jj = np.nonzero(valid)
     logit_rows = packed_row[bb, cols[jj] - 1]
     labels = ids[bb, cols[jj]].astype(np.int64)
-    img_rows = np.nonzero(p_ids[:T] == image_token_id)[0].astype(np.int32)
+    # image placeholders live in the prompt part only; a sampled response token that happens to equal the placeholder id is
+    # ordinary text (HF's masked_scatter would raise on such a row; random-weight synthetic models do sample it)
+    in_prompt = np.zeros((B, S), dtype=bool)
+    in_prompt[:, :S - R] = True
+    img_rows = np.nonzero((p_ids[:T] == image_token_id) & in_prompt.reshape(-1)[flat])[0].astype(np.int32)
     embed_ids = p_ids.copy()
     embed_ids[img_rows] = -1
     embed_ids[T:] = -1

@@ -141,12 +141,15 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                 st_bf16* out, int64_t ldo, float* lse, int max_seqlen, st_stream_t stream);
 /* backward: dq/dk/dv with the same layouts/strides as q/k/v (dk, dv summed over the q heads of a
- * group); delta (n_q, T) fp32 scratch. */
+ * group); delta (n_q, T) fp32 scratch.  D == 128 additionally needs `workspace` of at least
+ * st_attn_bwd_workspace_bytes(T, n_q, D) bytes (per-query-head bf16 partials of dK/dV, reduced over each KV group in a
+ * fixed order); D == 80 ignores it (may be NULL). */
+int64_t st_attn_bwd_workspace_bytes(int T, int n_q, int D);
 int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                 const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                 st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv,
-                float* delta, int max_seqlen, st_stream_t stream);
+                float* delta, void* workspace, int64_t workspace_bytes, int max_seqlen, st_stream_t stream);
 /* Attention over explicit row ranges (rollout decode; replaces vLLM paged attention,
  * verl/workers/rollout/vllm_rollout_spmd.py:141-143): sequence s has query rows [q_beg[s], q_end[s]) of q and key
  * rows [k_beg[s], k_end[s]) of k/v (device int32 arrays, read at run time so a captured hipGraph replays with

@@ -14,11 +14,13 @@
 //     h / (n_q / n_kv).
 // Roofline: MFMA-bound, 4*D*Lq*Lk flop per (sequence, head) pair (half of that when causal).
 #include "common.h"
+#include <stdlib.h>
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define KV_TILE 64
 #define Q_TILE 128
+#define QT_ROWS 32
 #define VT_PITCH 136            // bytes per V^T row (64 keys * 2 B + 8 pad)
 
 template <int D> struct AttnCfg {
@@ -204,6 +206,215 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
 
 // =============================================================================================
+// D = 128 forward, asynchronous staging (the LM path: training/prefill and the decode partials).
+// Same MFMA mapping as attn_fwd_kernel (S^T = K Q^T, P^T fed from the accumulator registers), but the K/V tiles are
+// copied HBM -> LDS by LDS-DMA (no register pass), double-buffered one tile ahead behind ONE barrier per tile:
+//   K image  [64 keys][256 B]; 16-byte chunk c of row r sits at chunk position c ^ (r & 15): the 16 rows a ds_read_b128
+//            lane group touches land on 16 distinct bank slots;
+//   V image  32 sub-tiles of [8 keys][32 d] (512 B, 64-B rows), sub-tile (key>>3)*4 + (d>>5): the PV operand V^T is read
+//            with ds_read_b64_tr_b16 — each 32-lane half of the instruction covers 4 keys x 32 d = one 256-B bank row —
+//            so V is never transposed by stores (the old kernel issued 8 ds_write_b16 per 16 bytes).
+// The swizzles live in the SOURCE addresses of the DMA (the LDS side of global_load_lds is lane-linear).
+// =============================================================================================
+// Eight transpose reads of one 16-key k-slot (4 d-blocks x 2 key groups) as ONE asm statement: hipcc puts `s_waitcnt
+// vmcnt(0)` in front of the builtin form (it cannot tell the read from the LDS-DMA prefetch in flight), which would drain
+// the next tile's DMA in the middle of every tile.  The results are valid only after tr_wait8 on the same registers.
+__device__ __forceinline__ void tr_issue8(uint2 (&f)[8], uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                 "ds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %3, %8 offset:2560\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:1024\n\t"
+                 "ds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
+                 "ds_read_b64_tr_b16 %6, %8 offset:1536\n\t"
+                 "ds_read_b64_tr_b16 %7, %8 offset:3584"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+                 : "v"(addr)
+                 : "memory");
+}
+__device__ __forceinline__ void tr_wait8(uint2 (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ bf16x8 tr_frag(const uint2& lo, const uint2& hi) {
+    uint4 w; w.x = lo.x; w.y = lo.y; w.z = hi.x; w.w = hi.y;
+    return *reinterpret_cast<bf16x8*>(&w);
+}
+
+#define F2_STAGE 32768
+#define F2_V_OFF 16384
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+                                                            const uint16_t* __restrict__ k, int64_t ldk,
+                                                            const uint16_t* __restrict__ v, int64_t ldv,
+                                                            const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end,
+                                                            const int32_t* __restrict__ k_beg, const int32_t* __restrict__ k_end,
+                                                            const int32_t* __restrict__ o_beg, int qgroup, int T, int n_q, int n_kv,
+                                                            float scale_log2, uint16_t* __restrict__ out, int64_t ldo,
+                                                            float* __restrict__ lse) {
+    constexpr int D = 128;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * F2_STAGE];
+    const int seq = blockIdx.z, h = blockIdx.y;
+    const int s0 = q_beg[seq], Lq = q_end[seq] - s0;
+    const int sk = k_beg[seq], L = k_end[seq] - sk;
+    // causal work grows with the q tile index: launch the heavy tiles first
+    const int q_base = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * Q_TILE;
+    if (q_base >= Lq) return;
+    const int kvh = h / (n_q / n_kv);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qc = lane & 31, half = lane >> 5;
+    const int q_idx = q_base + wave * 32 + qc;
+    const bool q_ok = q_idx < Lq;
+
+    bf16x8 qf[8];
+    {
+        const int64_t R = s0 + (q_ok ? q_idx : 0);
+        const uint16_t* qp = qgroup > 0 ? q + (R / qgroup) * ldq + ((int64_t)h * qgroup + R % qgroup) * D + half * 8
+                                        : q + R * ldq + (int64_t)h * D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 r = q_ok ? *reinterpret_cast<const uint4*>(qp + s * 16) : make_uint4(0, 0, 0, 0);
+            qf[s] = *reinterpret_cast<bf16x8*>(&r);
+        }
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
+    const int n_tiles = (kv_end + KV_TILE - 1) / KV_TILE;
+    const uint16_t* kbase = k + (int64_t)sk * ldk + kvh * D;
+    const uint16_t* vbase = v + (int64_t)sk * ldv + kvh * D;
+
+    auto stage = [&](int t, char* dst) {
+        const int kt0 = t * KV_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // K: instruction = 4 rows x 16 chunks
+            const int inst = wave * 4 + j;
+            const int row = inst * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            int key = kt0 + row; key = key < L ? key : L - 1;
+            st_glds16(kbase + (int64_t)key * ldk + c * 8, dst + inst * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // V: instruction = 2 sub-tiles of [8 keys][32 d]
+            const int inst = wave * 4 + j;
+            const int u = 2 * inst + (lane >> 5), slot = lane & 31;
+            int key = kt0 + (u >> 2) * 8 + (slot >> 2); key = key < L ? key : L - 1;
+            st_glds16(vbase + (int64_t)key * ldv + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
+        }
+    };
+    if (n_tiles > 0) stage(0, smem);
+
+    // lane-constant LDS offsets
+    const int k_row_off = qc * 256, k_swz = qc & 15;                       // rows kb*32+qc: (row & 15) == (qc & 15)
+    const int v_lane_off = (4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int kt0 = t * KV_TILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < n_tiles) stage(t + 1, smem + ((t + 1) & 1) * F2_STAGE);
+        if (CAUSAL && kt0 > q_base + wave * 32 + 31) continue;          // tile entirely above this wave's diagonal
+        const char* ks = smem + (t & 1) * F2_STAGE;
+        const uint32_t vaddr = smem_lds + (t & 1) * F2_STAGE + F2_V_OFF + v_lane_off;
+        uint2 va[8], vb[8];
+        tr_issue8(va, vaddr);                               // k-slot 0 of V^T: lands while S^T and the softmax run
+
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            const char* kp = ks + kb * 32 * 256 + k_row_off;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (((2 * s + half) ^ k_swz) << 4));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // mask only where the tile meets the diagonal or the end of the keys (wave-uniform test)
+        if ((kt0 + KV_TILE > L) || (CAUSAL && kt0 + KV_TILE - 1 > q_base + wave * 32)) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = (key < L) && (!CAUSAL || key <= q_idx);
+                    sacc[kb][r] = ok ? sacc[kb][r] : -INFINITY;
+                }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+        mx = st_half_max(mx) * scale_log2;                  // scale_log2 > 0: max commutes with the scaling
+        const float m_new = fmaxf(m_i, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);          // m_i = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], scale_log2, -m_use));
+                sacc[kb][r] = p;
+                rs += p;
+            }
+        rs = st_half_sum(rs);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+        if (!__all(alpha == 1.f)) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        }
+        auto pv_step = [&](int ks2, uint2 (&vf)[8]) {
+            const int kb = ks2 >> 1, rb = (ks2 & 1) * 8;
+            uint4 pw;
+            pw.x = st_pk_bf16(sacc[kb][rb + 0], sacc[kb][rb + 1]);
+            pw.y = st_pk_bf16(sacc[kb][rb + 2], sacc[kb][rb + 3]);
+            pw.z = st_pk_bf16(sacc[kb][rb + 4], sacc[kb][rb + 5]);
+            pw.w = st_pk_bf16(sacc[kb][rb + 6], sacc[kb][rb + 7]);
+            const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pw);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vf[2 * b], vf[2 * b + 1]), pf, o[b], 0, 0, 0);
+        };
+        // V^T fragments ping-pong between two register sets: the reads of k-slot s+1 fly under the MFMAs of k-slot s
+        tr_wait8(va);  tr_issue8(vb, vaddr + 4096);   pv_step(0, va);
+        tr_wait8(vb);  tr_issue8(va, vaddr + 8192);   pv_step(1, vb);
+        tr_wait8(va);  tr_issue8(vb, vaddr + 12288);  pv_step(2, va);
+        tr_wait8(vb);                                 pv_step(3, vb);
+    }
+    if (!q_ok) return;
+    const float inv_l = l_i > 0.f ? 1.f / l_i : 0.f;
+    const int64_t orow = (o_beg ? o_beg[seq] : s0) + q_idx;
+    uint16_t* op = out + orow * ldo + (int64_t)h * D;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = b * 32 + 8 * g + 4 * half;
+            uint2 w;
+            w.x = st_pk_bf16(o[b][4 * g + 0] * inv_l, o[b][4 * g + 1] * inv_l);
+            w.y = st_pk_bf16(o[b][4 * g + 2] * inv_l, o[b][4 * g + 3] * inv_l);
+            *reinterpret_cast<uint2*>(op + d) = w;
+        }
+    if (half == 0) lse[(int64_t)h * T + orow] = l_i > 0.f ? (m_i + log2f(l_i)) * LN2 : -INFINITY;
+}
+
+
+// =============================================================================================
 // Backward.  Two deterministic kernels (no atomics):
 //   attn_bwd_dq_kernel  — same decomposition as the forward (128 q rows x one head per workgroup); per KV
 //                         tile recomputes S^T, forms dP^T = V dO^T, dS^T = P^T o (dP^T - delta) * scale and
@@ -370,7 +581,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
         }
 }
 
-#define QT_ROWS 32
 #define QT_PITCH 72            // bytes per row of the transposed [D][32] images (32*2 + 8 pad)
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ q, int64_t ldq,
@@ -503,6 +713,400 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
         }
 }
 
+// =============================================================================================
+// D = 128 backward with asynchronous staging (same decomposition as the generic kernels below; LM path).
+// Streamed tiles ([rows][128] bf16, 256-B rows) are needed BOTH as natural MFMA operands (ds_read_b128 of 8 contiguous d)
+// AND transposed (ds_read_b64_tr_b16, contraction over the row index), so they use ONE dual-use image: 16-byte chunk c
+// of row r sits at chunk position c ^ swz16(r), swz16(r) = (r&3)<<2 | (r>>2)&3.  The 16 rows of a ds_read_b128 lane group
+// have 16 distinct (r & 15) -> 16 distinct slots; the 4 rows x 4 chunks a 32-lane half of a transpose read touches differ
+// in the upper two chunk bits by (r&3) -> 16 distinct slots as well.  Filled by LDS-DMA with the permutation applied to
+// the source column, double/triple buffered, one barrier per tile.
+// =============================================================================================
+__device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int ROWS>
+__device__ __forceinline__ void stage_dual(const uint16_t* __restrict__ base, int64_t ld, int row0, int L, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < ROWS / 16; ++j) {                   // ROWS/4 one-KiB instructions over 4 waves
+        const int inst = wave * (ROWS / 16) + j;
+        const int row = inst * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ swz16(row);
+        int g = row0 + row; g = g < L ? g : L - 1;
+        st_glds16(base + (int64_t)g * ld + c * 8, dst + inst * 1024);
+    }
+}
+
+// lane-constant byte offsets of the transpose reads inside a dual-use image: entry [2*b + j] = d-block b (32 d), key/row
+// group j (rows +0..3 / +8..11 of a 16-row k-slot; the +8 rows and the k-slot base are immediates at the call site)
+__device__ __forceinline__ void tr_dual_offsets(uint32_t (&a)[8], int lane) {
+    const int s = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = ((s >> 2) << 2) | ((h + 2 * j) & 3);
+            const int c = 4 * b + 2 * g + ((s & 3) >> 1);
+            a[2 * b + j] = (uint32_t)((4 * h + (s >> 2)) * 256 + ((c ^ f) << 4) + (s & 1) * 8);
+        }
+}
+template <int OFF>
+__device__ __forceinline__ void tr_issue8_dual(uint2 (&f)[8], const uint32_t (&a)[8], uint32_t base) {
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
+                 "ds_read_b64_tr_b16 %1, %9 offset:%17\n\t"
+                 "ds_read_b64_tr_b16 %2, %10 offset:%16\n\t"
+                 "ds_read_b64_tr_b16 %3, %11 offset:%17\n\t"
+                 "ds_read_b64_tr_b16 %4, %12 offset:%16\n\t"
+                 "ds_read_b64_tr_b16 %5, %13 offset:%17\n\t"
+                 "ds_read_b64_tr_b16 %6, %14 offset:%16\n\t"
+                 "ds_read_b64_tr_b16 %7, %15 offset:%17"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+                 : "v"(a[0] + base), "v"(a[1] + base), "v"(a[2] + base), "v"(a[3] + base), "v"(a[4] + base), "v"(a[5] + base),
+                   "v"(a[6] + base), "v"(a[7] + base), "n"(OFF), "n"(OFF + 2048)
+                 : "memory");
+}
+
+#define B2_KV_STAGE 32768          // dq kernel: K image 16 KiB + V image 16 KiB
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+                                                               const uint16_t* __restrict__ k, int64_t ldk,
+                                                               const uint16_t* __restrict__ v, int64_t ldv,
+                                                               const uint16_t* __restrict__ dout, int64_t lddo,
+                                                               const uint16_t* __restrict__ out, int64_t ldo,
+                                                               const float* __restrict__ lse, float* __restrict__ delta,
+                                                               const int32_t* __restrict__ cu, int T, int n_q, int n_kv,
+                                                               float scale, uint16_t* __restrict__ dq, int64_t lddq) {
+    constexpr int D = 128;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * B2_KV_STAGE];
+    const int seq = blockIdx.z, h = blockIdx.y;
+    const int s0 = cu[seq], L = cu[seq + 1] - s0;
+    const int q_base = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * Q_TILE;
+    if (q_base >= L) return;
+    const int kvh = h / (n_q / n_kv);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qc = lane & 31, half = lane >> 5;
+    const int q_idx = q_base + wave * 32 + qc;
+    const bool q_ok = q_idx < L;
+    const float scale_log2 = scale * LOG2E;
+
+    // Q, dO fragments; delta = rowsum(dO o O) is formed here (each lane holds half of its row's d) and published for the
+    // dK kernel that follows on the stream
+    bf16x8 qf[8], dof[8];
+    float dlt = 0.f;
+    {
+        const int64_t row = s0 + (q_ok ? q_idx : 0);
+        const uint16_t* qp = q + row * ldq + (int64_t)h * D + half * 8;
+        const uint16_t* dp = dout + row * lddo + (int64_t)h * D + half * 8;
+        const uint16_t* op = out + row * ldo + (int64_t)h * D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 a = q_ok ? *reinterpret_cast<const uint4*>(qp + s * 16) : make_uint4(0, 0, 0, 0);
+            uint4 b = q_ok ? *reinterpret_cast<const uint4*>(dp + s * 16) : make_uint4(0, 0, 0, 0);
+            uint4 c = q_ok ? *reinterpret_cast<const uint4*>(op + s * 16) : make_uint4(0, 0, 0, 0);
+            qf[s] = *reinterpret_cast<bf16x8*>(&a);
+            dof[s] = *reinterpret_cast<bf16x8*>(&b);
+            float x[8], y[8];
+            unpack8(b, x); unpack8(c, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt = fmaf(x[j], y[j], dlt);
+        }
+    }
+    dlt = st_half_sum(dlt);
+    if (q_ok && half == 0) delta[(int64_t)h * T + s0 + q_idx] = dlt;
+    const float lse2 = q_ok ? lse[(int64_t)h * T + s0 + q_idx] * LOG2E : 0.f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
+    const int n_tiles = (kv_end + KV_TILE - 1) / KV_TILE;
+    const uint16_t* kbase = k + (int64_t)s0 * ldk + kvh * D;
+    const uint16_t* vbase = v + (int64_t)s0 * ldv + kvh * D;
+    auto stage = [&](int t, char* dst) {
+        stage_dual<KV_TILE>(kbase, ldk, t * KV_TILE, L, dst, wave, lane);
+        stage_dual<KV_TILE>(vbase, ldv, t * KV_TILE, L, dst + 16384, wave, lane);
+    };
+    if (n_tiles > 0) stage(0, smem);
+
+    const int nat_row = qc * 256, nat_swz = swz16(qc);       // natural reads: rows kb*32 + qc
+    uint32_t tro[8];
+    tr_dual_offsets(tro, lane);
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int kt0 = t * KV_TILE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < n_tiles) stage(t + 1, smem + ((t + 1) & 1) * B2_KV_STAGE);
+        if (CAUSAL && kt0 > q_base + wave * 32 + 31) continue;
+        const char* ks = smem + (t & 1) * B2_KV_STAGE;
+        const char* vs = ks + 16384;
+        const uint32_t kaddr = smem_lds + (t & 1) * B2_KV_STAGE;
+        const bool need_mask = (kt0 + KV_TILE > L) || (CAUSAL && kt0 + KV_TILE - 1 > q_base + wave * 32);
+
+        uint2 ta[8], tb[8];
+        tr_issue8_dual<0>(ta, tro, kaddr);                               // K^T of keys 0..15
+        auto block = [&](int kb, uint2 (&t0)[8], uint2 (&t1)[8], auto issue_mid, auto issue_end) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            const char* kp = ks + kb * 32 * 256 + nat_row;
+            const char* vp = vs + kb * 32 * 256 + nat_row;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int off = ((2 * s + half) ^ nat_swz) << 4;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + off);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vp + off);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);     // S^T  = K Q^T
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], pacc, 0, 0, 0);    // dP^T = V dO^T
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -lse2));
+                if (need_mask) {
+                    const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    p = ((key < L) && (!CAUSAL || key <= q_idx)) ? p : 0.f;
+                }
+                sacc[r] = p * (pacc[r] - dlt) * scale;                                         // dS^T
+            }
+            auto dq_step = [&](int rb, uint2 (&tf)[8]) {
+                uint4 pw;
+                pw.x = st_pk_bf16(sacc[rb + 0], sacc[rb + 1]);
+                pw.y = st_pk_bf16(sacc[rb + 2], sacc[rb + 3]);
+                pw.z = st_pk_bf16(sacc[rb + 4], sacc[rb + 5]);
+                pw.w = st_pk_bf16(sacc[rb + 6], sacc[rb + 7]);
+                const bf16x8 df = *reinterpret_cast<bf16x8*>(&pw);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tf[2 * b], tf[2 * b + 1]), df, acc[b], 0, 0, 0);   // dQ^T += K^T dS^T
+            };
+            tr_wait8(t0); issue_mid(); dq_step(0, t0);
+            tr_wait8(t1); issue_end(); dq_step(8, t1);
+        };
+        block(0, ta, tb, [&] { tr_issue8_dual<4096>(tb, tro, kaddr); }, [&] { tr_issue8_dual<8192>(ta, tro, kaddr); });
+        block(1, ta, tb, [&] { tr_issue8_dual<12288>(tb, tro, kaddr); }, [&] {});
+    }
+    if (!q_ok) return;
+    uint16_t* op = dq + (int64_t)(s0 + q_idx) * lddq + (int64_t)h * D;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = b * 32 + 8 * g + 4 * half;
+            uint2 w;
+            w.x = st_pk_bf16(acc[b][4 * g + 0], acc[b][4 * g + 1]);
+            w.y = st_pk_bf16(acc[b][4 * g + 2], acc[b][4 * g + 3]);
+            *reinterpret_cast<uint2*>(op + d) = w;
+        }
+}
+
+// dK / dV: workgroup = 128 keys x ONE query head (wave = 32 keys, K/V fragments register resident); the head's 32-row Q/dO
+// tiles stream through a 3-slot LDS ring (dual-use images + the rows' lse/delta), two tiles in flight.  Holding dK^T and dV^T
+// accumulators together needs > 256 registers per lane (one wave per SIMD, nothing to overlap the softmax VALU work with),
+// so the work is split into two launches that each fit two waves per SIMD:
+//   MODE 0: S, dP, dS -> dK^T += Q^T dS      MODE 1: S, P -> dV^T += dO^T P      (S is recomputed: 5 matmuls instead of 4)
+// Each (query head, key block) writes a bf16 partial; attn_bwd128_reduce_kernel sums the query heads of a KV group in fp32
+// in a fixed order (deterministic, no atomics).
+template <int N> __device__ __forceinline__ void st_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// QR = q rows per ring slot (32 or 64), NST = ring slots.  Slot = Q image (QR x 256 B) + dO image + QR lse + QR delta floats.
+template <bool CAUSAL, int MODE, int QR, int NST>
+__global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+                                                               const uint16_t* __restrict__ k, int64_t ldk,
+                                                               const uint16_t* __restrict__ v, int64_t ldv,
+                                                               const uint16_t* __restrict__ dout, int64_t lddo,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const int32_t* __restrict__ cu, int T, int n_q, int n_kv,
+                                                               float scale, uint16_t* __restrict__ part) {
+    constexpr int D = 128;
+    constexpr int IMG = QR * 256, SLOT = 2 * IMG + 1024;
+    constexpr int PER = 2 * (QR / 16), EXTRA = QR / 32;      // LDS-DMA instructions per wave per slot (+ wave 0: lse/delta)
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SLOT];
+    const int seq = blockIdx.z, hq = blockIdx.y;
+    const int s0 = cu[seq], L = cu[seq + 1] - s0;
+    const int k_base = blockIdx.x * 128;
+    if (k_base >= L) return;
+    const int kvh = hq / (n_q / n_kv);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kc = lane & 31, half = lane >> 5;
+    const int key_idx = k_base + wave * 32 + kc;
+    const bool k_ok = key_idx < L;
+    const float scale_log2 = scale * LOG2E;
+
+    bf16x8 kf[8], vf[MODE == 0 ? 8 : 1];      // MFMA B operands: n = key, k = 8 contiguous d
+    {
+        const int64_t row = s0 + (k_ok ? key_idx : 0);
+        const uint16_t* kp = k + row * ldk + (int64_t)kvh * D + half * 8;
+        const uint16_t* vp = v + row * ldv + (int64_t)kvh * D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 a = k_ok ? *reinterpret_cast<const uint4*>(kp + s * 16) : make_uint4(0, 0, 0, 0);
+            kf[s] = *reinterpret_cast<bf16x8*>(&a);
+            if constexpr (MODE == 0) {
+                uint4 b = k_ok ? *reinterpret_cast<const uint4*>(vp + s * 16) : make_uint4(0, 0, 0, 0);
+                vf[s] = *reinterpret_cast<bf16x8*>(&b);
+            }
+        }
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    const int q_start = CAUSAL ? (k_base / QR) * QR : 0;
+    const int n_stage = (L - q_start + QR - 1) / QR;
+    const uint16_t* qbase = q + (int64_t)s0 * ldq + hq * D;
+    const uint16_t* dobase = dout + (int64_t)s0 * lddo + hq * D;
+    auto stage = [&](int i, char* dst) {
+        const int qt0 = q_start + i * QR;
+        stage_dual<QR>(qbase, ldq, qt0, L, dst, wave, lane);
+        stage_dual<QR>(dobase, lddo, qt0, L, dst + IMG, wave, lane);
+        if (wave == 0) {                                   // 4-byte DMA: QR lse rows then QR delta rows
+#pragma unroll
+            for (int e = 0; e < EXTRA; ++e) {
+                const int idx = e * 64 + lane;             // < 2*QR
+                int qi = qt0 + (idx % QR); qi = qi < L ? qi : L - 1;
+                const float* src = (idx < QR ? lse : delta) + (int64_t)hq * T + s0 + qi;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + 2 * IMG + e * 256), 4, 0, 0);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) if (i < n_stage) stage(i, smem + i * SLOT);
+
+    const int nat_row = kc * 256, nat_swz = swz16(kc);       // natural reads: rows = q_local = lane & 31
+    uint32_t tro[8];
+    tr_dual_offsets(tro, lane);
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
+    constexpr int TR_IMG = MODE == 0 ? 0 : IMG;              // transposed operand: Q^T (dK) or dO^T (dV)
+
+    int slot = 0;
+    for (int i = 0; i < n_stage; ++i) {
+        // tile i must have landed; with 3 slots tile i+1 (this wave's own copies) may stay in flight
+        if (NST == 2 || i + 1 >= n_stage) st_wait_vmcnt<0>();
+        else if (wave == 0) st_wait_vmcnt<PER + EXTRA>();
+        else st_wait_vmcnt<PER>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + NST - 1 < n_stage) { int ns = slot + NST - 1; ns = ns >= NST ? ns - NST : ns; stage(i + NST - 1, smem + ns * SLOT); }
+        const char* slot_p = smem + slot * SLOT;
+        const uint32_t slot_a = smem_lds + slot * SLOT;
+        slot = slot + 1 == NST ? 0 : slot + 1;
+#pragma unroll
+        for (int sub = 0; sub < QR / 32; ++sub) {
+            const int qt0 = q_start + i * QR + sub * 32;
+            if (qt0 >= L) continue;
+            if (CAUSAL && qt0 + 31 < k_base + wave * 32) continue;           // these 32 q rows are before this wave's keys
+            const char* qs = slot_p + sub * 8192;
+            const char* dos = qs + IMG;
+            const uint32_t qaddr = slot_a + sub * 8192;
+            const float* s_lse = reinterpret_cast<const float*>(slot_p + 2 * IMG) + sub * 32;
+            const float* s_dlt = s_lse + QR;
+
+            uint2 ta[8], tb[8];
+            tr_issue8_dual<TR_IMG>(ta, tro, qaddr);            // transposed operand, q rows 0..15
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; if constexpr (MODE == 0) pacc[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int off = nat_row + (((2 * s + half) ^ nat_swz) << 4);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(qs + off);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], sacc, 0, 0, 0);          // S  = Q K^T   (rows q, cols key)
+                if constexpr (MODE == 0) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(dos + off);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, vf[s], pacc, 0, 0, 0);      // dP = dO V^T
+                }
+            }
+            const bool need_mask = (qt0 + 32 > L) || (k_base + wave * 32 + 32 > L) || (CAUSAL && qt0 < k_base + wave * 32 + 31);
+            uint32_t pk[8];                                    // packed bf16 P (dV) or dS (dK), rows 2i, 2i+1
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 8 * g + 4 * half);
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE == 0) d4 = *reinterpret_cast<const f32x4*>(s_dlt + 8 * g + 4 * half);
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -l4[j] * LOG2E));
+                    if (need_mask) {
+                        const int qi = qt0 + 8 * g + 4 * half + j;
+                        p = (k_ok && (qi < L) && (!CAUSAL || key_idx <= qi)) ? p : 0.f;
+                    }
+                    x[j] = MODE == 0 ? p * (pacc[r] - d4[j]) * scale : p;
+                }
+                pk[2 * g] = st_pk_bf16(x[0], x[1]);
+                pk[2 * g + 1] = st_pk_bf16(x[2], x[3]);
+            }
+            auto kv_step = [&](int ks2, uint2 (&tf)[8]) {
+                uint4 pw;
+                pw.x = pk[4 * ks2]; pw.y = pk[4 * ks2 + 1]; pw.z = pk[4 * ks2 + 2]; pw.w = pk[4 * ks2 + 3];
+                const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pw);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tf[2 * b], tf[2 * b + 1]), pf, acc[b], 0, 0, 0);
+            };
+            tr_wait8(ta);
+            tr_issue8_dual<TR_IMG + 4096>(tb, tro, qaddr);     // q rows 16..31
+            kv_step(0, ta);
+            tr_wait8(tb);
+            kv_step(1, tb);
+        }
+    }
+    if (!k_ok) return;
+    uint16_t* pp = part + ((int64_t)hq * T + s0 + key_idx) * D;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = b * 32 + 8 * g + 4 * half;
+            uint2 w;
+            w.x = st_pk_bf16(acc[b][4 * g + 0], acc[b][4 * g + 1]);
+            w.y = st_pk_bf16(acc[b][4 * g + 2], acc[b][4 * g + 3]);
+            *reinterpret_cast<uint2*>(pp + d) = w;
+        }
+}
+
+// dk[t][kvh*128 + d] = sum over the group's query heads of the bf16 partials (fp32 accumulate, fixed order); same for dv.
+__global__ void attn_bwd128_reduce_kernel(const uint16_t* __restrict__ pk, const uint16_t* __restrict__ pv,
+                                          const int32_t* __restrict__ t_end, int T, int n_kv, int group, uint16_t* __restrict__ dk, int64_t lddk, uint16_t* __restrict__ dv,
+                                          int64_t lddv) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte chunk of one (tensor, kv head, token)
+    const int64_t per = (int64_t)n_kv * T * 16;
+    if (idx >= 2 * per) return;
+    const bool is_v = idx >= per;
+    const int64_t i = is_v ? idx - per : idx;
+    const int c = (int)(i & 15);
+    const int64_t t = (i >> 4) % T;
+    if (t >= *t_end) return;                               // rows after the last sequence (padding) hold no partials: left untouched
+    const int kvh = (int)((i >> 4) / T);
+    const uint16_t* src = (is_v ? pv : pk) + (((int64_t)kvh * group) * T + t) * 128 + c * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < group; ++g) {
+        float x[8];
+        unpack8(*reinterpret_cast<const uint4*>(src + (int64_t)g * T * 128), x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += x[j];
+    }
+    uint4 o;
+    o.x = st_pk_bf16(a[0], a[1]); o.y = st_pk_bf16(a[2], a[3]); o.z = st_pk_bf16(a[4], a[5]); o.w = st_pk_bf16(a[6], a[7]);
+    uint16_t* dst = (is_v ? dv + t * lddv : dk + t * lddk) + kvh * 128 + c * 8;
+    *reinterpret_cast<uint4*>(dst) = o;
+}
+
+
 extern "C" {
 
 static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
@@ -517,7 +1121,10 @@ static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int6
     const float sl2 = scale * LOG2E;
     StProfScope ps(klass, s, 0.0);
 #define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
-    if (D == 128 && causal) ST_FWD(128, true);
+    static const bool old128 = getenv("ST_ATTN_OLD") != nullptr;       // development A/B switch
+#define ST_FWD2(CC) hipLaunchKernelGGL((attn_fwd128_kernel<CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
+    if (D == 128 && !old128) { if (causal) ST_FWD2(true); else ST_FWD2(false); }
+    else if (D == 128 && causal) ST_FWD(128, true);
     else if (D == 128) ST_FWD(128, false);
     else if (D == 80 && !causal) ST_FWD(80, false);
     else if (D == 80) ST_FWD(80, true);
@@ -543,25 +1150,50 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
                            lse, max_q, ST_K_DECODE_ATTN, stream);
 }
 
+int64_t st_attn_bwd_workspace_bytes(int T, int n_q, int D) {
+    return D == 128 ? (int64_t)2 * n_q * T * 128 * (int64_t)sizeof(uint16_t) : 0;
+}
+
 int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                 const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                 st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv, float* delta,
-                int max_seqlen, st_stream_t stream) {
+                void* workspace, int64_t workspace_bytes, int max_seqlen, st_stream_t stream) {
     if (!q || !k || !v || !out || !dout || !lse || !cu_seqlens || !dq || !dk || !dv || !delta || n_seq <= 0 || T <= 0 ||
         n_q <= 0 || n_kv <= 0 || (n_q % n_kv) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) ||
         (lddk & 3) || (lddv & 3) || max_seqlen <= 0 || (D != 128 && D != 80))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     StProfScope ps(D == 128 ? ST_K_ATTN_BWD : ST_K_VIT_ATTN, s, 0.0);
-    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(st_cdiv((int64_t)T * n_q, 256)), dim3(256), 0, s, out, ldo, dout, lddo, T, n_q, D, delta);
     const dim3 gq(st_cdiv(max_seqlen, Q_TILE), n_q, n_seq), gk(st_cdiv(max_seqlen, 128), n_kv, n_seq);
 #define ST_BWD(DD, CC)                                                                                                         \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, CC>), gq, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,       \
                        cu_seqlens, T, n_q, n_kv, scale, dq, lddq);                                                             \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, CC>), gk, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,      \
                        cu_seqlens, T, n_q, n_kv, scale, dk, lddk, dv, lddv)
-    if (D == 128 && causal) { ST_BWD(128, true); }
+    static const bool old128 = getenv("ST_ATTN_OLD") != nullptr;       // development A/B switch
+    if (D != 128 || old128)
+        hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(st_cdiv((int64_t)T * n_q, 256)), dim3(256), 0, s, out, ldo, dout, lddo, T, n_q, D, delta);
+    const int64_t ws_need = st_attn_bwd_workspace_bytes(T, n_q, D);
+    if (D == 128 && !old128 && (!workspace || workspace_bytes < ws_need)) return ST_EINVAL;
+    uint16_t* part_k = (uint16_t*)workspace;
+    uint16_t* part_v = part_k + (int64_t)n_q * T * 128;
+    const dim3 gkv(st_cdiv(max_seqlen, 128), n_q, n_seq);
+#define ST_BWD2(CC, KVQ, KVS)                                                                                                       \
+    hipLaunchKernelGGL((attn_bwd128_dq_kernel<CC>), gq, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, out, ldo, lse,     \
+                       delta, cu_seqlens, T, n_q, n_kv, scale, dq, lddq);                                                      \
+    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 0, KVQ, KVS>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,    \
+                       cu_seqlens, T, n_q, n_kv, scale, part_k);                                                               \
+    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 1, KVQ, KVS>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,    \
+                       cu_seqlens, T, n_q, n_kv, scale, part_v);                                                               \
+    hipLaunchKernelGGL(attn_bwd128_reduce_kernel, dim3(st_cdiv((int64_t)2 * n_kv * T * 16, 256)), dim3(256), 0, s, part_k,     \
+                       part_v, cu_seqlens + n_seq, T, n_kv, n_q / n_kv, dk, lddk, dv, lddv)
+    static const int kv_cfg = getenv("ST_ATTN_KV_CFG") ? atoi(getenv("ST_ATTN_KV_CFG")) : 1;    // development switch
+    if (D == 128 && !old128) {
+        if (kv_cfg == 0) { if (causal) { ST_BWD2(true, 32, 3); } else { ST_BWD2(false, 32, 3); } }
+        else { if (causal) { ST_BWD2(true, 64, 2); } else { ST_BWD2(false, 64, 2); } }
+    }
+    else if (D == 128 && causal) { ST_BWD(128, true); }
     else if (D == 128) { ST_BWD(128, false); }
     else if (causal) { ST_BWD(80, true); }
     else { ST_BWD(80, false); }

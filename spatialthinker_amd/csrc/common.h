@@ -53,6 +53,37 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// ---- gfx950 data-movement helpers ------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+
+// LDS-DMA: every lane copies 16 B global -> LDS; the LDS destination is wave-uniform base + lane*16 (lane-linear image).
+__device__ __forceinline__ void st_glds16(const void* gsrc, char* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+// Hardware transpose read: within a 16-lane group whose lane s points at row (s>>2), column 4*(s&3) of a [4][16] bf16 block,
+// lane i receives column i (the 4 rows) — i.e. 4 contiguous k-values of a k-strided MFMA operand.
+__device__ __forceinline__ s16x4_t st_lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+// two fp32 -> packed bf16 pair with the hardware RNE convert (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t st_pk_bf16(float a, float b) {
+    hw_f32x2_t f = {a, b};
+    hw_bf16x2_t h = __builtin_convertvector(f, hw_bf16x2_t);
+    return *reinterpret_cast<uint32_t*>(&h);
+}
+// max / sum across the two 32-lane halves without touching the LDS crossbar (v_permlane32_swap)
+__device__ __forceinline__ float st_half_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float st_half_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ---- launch / profiling plumbing (host side) -------------------------------------------------
 struct StProf {
     bool on = false;

@@ -27,7 +27,7 @@ def parse_header(path: str = HEADER):
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
     out = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(st_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(st_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argtypes, argnames = [], []
         args = args.strip()
@@ -41,7 +41,7 @@ def parse_header(path: str = HEADER):
                     parts = a.replace("const ", "").split()
                     argtypes.append(_SCALARS[parts[0]])
                     argnames.append(parts[-1])
-        out[name] = (ctypes.c_int if ret == "int" else ctypes.c_char_p, argtypes, argnames)
+        out[name] = ({"int": ctypes.c_int, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_char_p), argtypes, argnames)
     return out
 
 

@@ -210,12 +210,20 @@ def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=N
     return o, lse
 
 
+_attn_ws = {}
+
+
 def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, dq, dk, dv):
     T = q.shape[0]
     delta = torch.empty(n_q, T, dtype=F32, device=q.device)
+    need = int(lib().st_attn_bwd_workspace_bytes(T, n_q, D))
+    ws = _attn_ws.get(q.device)
+    if need and (ws is None or ws.numel() < need):                       # grow-only scratch for the per-head dK/dV partials
+        ws = _attn_ws[q.device] = torch.empty(need, dtype=torch.uint8, device=q.device)
     lib().st_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), _p(do), do.stride(0),
                       _p(lse), _p(cu_seqlens), cu_seqlens.numel() - 1, T, n_q, n_kv, D, scale, int(causal),
-                      _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(delta), int(max_seqlen), _s())
+                      _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(delta),
+                      _p(ws) if need else None, need, int(max_seqlen), _s())
     return dq, dk, dv
 
 

@@ -125,6 +125,10 @@ int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16
 int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                       const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc, float* scratch,
                       int64_t scratch_elems, int M, int N, int K, st_stream_t stream);
+/* tuning entry for the decode-shaped GEMM: explicit tile variant (10..18, see gemm_tiles.hip) and split-K count */
+int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
+                              const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,
+                              float* scratch, int64_t scratch_elems, int M, int N, int K, st_stream_t stream);
 /* out (C, R) = in (R, C)^T, bf16 (operand re-layout for the backward GEMMs). */
 int st_transpose(const st_bf16* in, int64_t ldin, st_bf16* out, int64_t ldout, int R, int C, st_stream_t stream);
 /* column sums: out_f32 (C,) (+)= sum_r in[r, c]  (bias gradients). */

@@ -353,6 +353,76 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
 #undef GO
 }
 
+int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
+                        const uint16_t* res, int64_t ldr, uint16_t* Cb, float* slabs, int M, int N, int K, int64_t ldc, hipStream_t s);
+
+static int launch_decode_tiles(int variant, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                               const uint16_t* bias, const uint16_t* res, int64_t ldr, uint16_t* C, int64_t ldc, float* scratch,
+                               int64_t scratch_elems, int M, int N, int K, hipStream_t s) {
+    if (splits > K / 64) splits = K / 64;
+    if (splits > 1 && (!scratch || (int64_t)splits * M * N > scratch_elems)) return ST_EINVAL;
+    if (splits < 1) splits = 1;
+    const int kt_per = st_cdiv(K / 64, splits);
+    splits = st_cdiv(K / 64, kt_per);                       // slices actually launched
+    int rc = st_gemm_tile_decode(variant, splits, A, lda, B, ldb, bias, res, ldr, C, scratch, M, N, K, ldc, s);
+    if (rc || splits == 1) return rc;
+    const bool hb = bias != nullptr, hr = res != nullptr;
+    const dim3 fg(st_cdiv((int64_t)M * N, 256));
+#define SKF(HB, HR) hipLaunchKernelGGL((gemm_skinny_finish<HB, HR>), fg, dim3(256), 0, s, scratch, splits, bias, res, ldr, C, ldc, M, N)
+    if (hb && hr) SKF(true, true); else if (hb) SKF(true, false); else if (hr) SKF(false, true); else SKF(false, false);
+#undef SKF
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// Default (variant, splits) of a decode-shaped GEMM, from tools/decode_gemm_tune.py sweeps on MI355X (7B shapes, M = 64 / 256):
+// wide outputs (gate/up, lm_head) stream W with one tile per workgroup and no split; narrow outputs (qkv, o, down) have too
+// few column tiles to fill 256 CUs and split K into ~256-512 workgroups.  A host-side autotuner may override the choice
+// through st_gemm_nt_decode_variant.
+static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant, int* splits) {
+    const int bm = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+    const bool wide = N >= 16384;
+    int v, bn, row_tiles = 1;
+    if (bm == 64) { v = (wide || K >= 8192) ? 11 : 10; bn = v == 11 ? 128 : 64; }
+    else if (bm == 128) { v = wide ? 14 : 13; bn = wide ? 128 : 64; }
+    else if (wide) {
+        // 256x256 tiles are ~10 % faster per flop than 256x128 but quantise worse on 256 CUs: compare the last-round fill
+        const int t18 = st_cdiv(N, 256), t16 = st_cdiv(N, 128);
+        const double e18 = 1.1 * t18 / (double)(st_cdiv(t18, 256) * 256), e16 = t16 / (double)(st_cdiv(t16, 256) * 256);
+        v = e18 >= e16 ? 18 : 16; bn = v == 18 ? 256 : 128;
+    } else if (K >= 8192) { v = 16; bn = 128; }
+    else { v = 13; bn = 64; row_tiles = 2; }
+    int sp = 1;
+    if (!wide) {
+        const int tiles = row_tiles * st_cdiv(N, bn);
+        sp = (256 + tiles / 2) / tiles;
+        if (bm == 64 && sp < 4 && tiles <= 128) sp = 4;
+        if (bm == 64 && K >= 8192) sp = 8;
+        if (sp > 8) sp = 8;
+        while (sp > 1 && (K / 64) / sp < 4) --sp;                       // keep >= 4 K-tiles per slice
+        while (sp > 1 && (int64_t)sp * M * N > scratch_elems) --sp;
+        if (sp < 1) sp = 1;
+    }
+    *variant = v; *splits = sp;
+}
+
+/* tuning entry: explicit tile variant (st_gemm_tile_decode ids) and split count for a decode-shaped GEMM */
+extern "C" int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
+                                         const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,
+                                         float* scratch, int64_t scratch_elems, int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || !out_bf16 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+        ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 0) {                                     // the register-streaming kernel (kept for comparison; picks its own split)
+        if (M <= 32) return launch_skinny<2>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+        if (M <= 64) return launch_skinny<4>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+        if (M <= 128) return launch_skinny<8>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+        return launch_skinny<16>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+    }
+    return launch_decode_tiles(variant, splits, A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+}
+
 /* decode-shaped GEMM (M <= 256): out_bf16 = A B^T (+bias)(+residual).  scratch (scratch_elems floats, contents
  * irrelevant) holds the split-K partial slabs [split][M][N]; NULL disables split-K. */
 extern "C" int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
@@ -361,9 +431,8 @@ extern "C" int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B
     if (!A || !B || !out_bf16 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
         ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
         return ST_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    if (M <= 32) return launch_skinny<2>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
-    if (M <= 64) return launch_skinny<4>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
-    if (M <= 128) return launch_skinny<8>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
-    return launch_skinny<16>(A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
+    int variant, splits;
+    decode_plan(M, N, K, scratch ? scratch_elems : 0, &variant, &splits);
+    return launch_decode_tiles(variant, splits, A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K,
+                               (hipStream_t)stream);
 }

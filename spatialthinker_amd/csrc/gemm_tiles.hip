@@ -26,6 +26,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                                                                 const uint16_t* __restrict__ bias,
                                                                 const uint16_t* __restrict__ res, int64_t ldr,
                                                                 uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc,
-                                                                int M, int N, int K, int tiles_m, int tiles_n) {
+                                                                int M, int N, int K, int tiles_m, int tiles_n, int kt_per_split,
+                                                                int64_t slab_stride) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;            // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;            // MFMA tiles per wave
@@ -100,7 +102,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / 64;
+    // split-K (decode shapes): grid.y slices of kt_per_split K-tiles, fp32 partial slab per slice (summed by a finish kernel)
+    const int kt_begin = blockIdx.y * kt_per_split;
+    const int nk = min(K / 64 - kt_begin, kt_per_split);
+    A += kt_begin * 64;
+    B += kt_begin * 64;
+    if (!OUT_BF16) Cf += blockIdx.y * slab_stride;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);
 
@@ -210,7 +217,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
-                       int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s) {
+                       int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s, int splits = 1,
+                       int64_t slab_stride = 0) {
     constexpr int smem = STAGES * (BM + BN) * 128;
     auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC>;
     static bool configured = false;
@@ -219,8 +227,9 @@ static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
         configured = true;
     }
     const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN);
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K,
-                       tiles_m, tiles_n);
+    const int kt_per_split = st_cdiv(K / 64, splits);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, st_cdiv(K / 64, kt_per_split)), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, bias, res,
+                       ldr, Cb, Cf, ldc, M, N, K, tiles_m, tiles_n, kt_per_split, slab_stride);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -251,6 +260,39 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
         default: return ST_EINVAL;
     }
 #undef TILE_GO
+}
+
+// Decode-shaped launches (M <= 256 rows, weight streaming): small-M tiles with a 3-slot ring and optional split-K into fp32
+// slabs [split][M][N] (ldc = N) that gemm_skinny_finish sums in a fixed order.
+//   10 = 64x64 1x4   11 = 64x128 1x4   12 = 64x256 1x4   13 = 128x64 2x2   14 = 128x128 2x2   15 = 256x64 4x1
+//   16 = 256x128 4x2 (3 slots)   17 = 256x128 4x2 (2 slots)   18 = 256x256 4x2 (2 slots)   19 = 128x128 2x2 (2 slots)
+//   20 = 128x256 2x4 (2 slots)   21 = 64x128 1x4 (2 slots)
+int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
+                        const uint16_t* res, int64_t ldr, uint16_t* Cb, float* slabs, int M, int N, int K, int64_t ldc, hipStream_t s) {
+#define DEC_GO(BM, BN, WM, WN, ST)                                                                                               \
+    do {                                                                                                                         \
+        if (splits > 1) return launch_tile<BM, BN, WM, WN, ST, false, false, false, false>(A, lda, B, ldb, nullptr, nullptr, 0, nullptr, slabs, N, M, N, K, s, splits, (int64_t)M * N); \
+        if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);   \
+        if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);         \
+        if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);          \
+        return launch_tile<BM, BN, WM, WN, ST, false, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);                  \
+    } while (0)
+    switch (variant) {
+        case 10: DEC_GO(64, 64, 1, 4, 3);
+        case 11: DEC_GO(64, 128, 1, 4, 3);
+        case 12: DEC_GO(64, 256, 1, 4, 3);
+        case 13: DEC_GO(128, 64, 2, 2, 3);
+        case 14: DEC_GO(128, 128, 2, 2, 3);
+        case 15: DEC_GO(256, 64, 4, 1, 3);
+        case 16: DEC_GO(256, 128, 4, 2, 3);
+        case 17: DEC_GO(256, 128, 4, 2, 2);
+        case 18: DEC_GO(256, 256, 4, 2, 2);
+        case 19: DEC_GO(128, 128, 2, 2, 2);
+        case 20: DEC_GO(128, 256, 2, 4, 2);
+        case 21: DEC_GO(64, 128, 1, 4, 2);
+        default: return ST_EINVAL;
+    }
+#undef DEC_GO
 }
 
 extern "C" int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,

@@ -152,6 +152,68 @@ def _skinny_scratch(device):
     return _scratch[key]
 
 
+# (M, N, K) -> (tile variant, split-K count) chosen by autotune_decode_gemm; empty = library defaults everywhere
+_decode_plans = {}
+_DECODE_CANDIDATES = {64: (10, 11, 12, 21), 128: (13, 14, 19, 20), 256: (13, 14, 16, 18)}
+
+
+def autotune_decode_gemm(M: int, weights, reps: int = 2):
+    """Time the decode-shaped GEMM out[M,N] = x[M,K] @ weight[N,K]^T for every (tile variant, split-K) candidate and pin the
+    fastest for this (M, N, K).  Launches are replayed from a hipGraph so the timing has no host launch gaps (the decode loop
+    replays a graph as well).  Must not be called while a stream capture is active.  Opt-in: the choice depends on measured
+    times, so two processes may pick different split counts (different fp32 summation order in the last bits)."""
+    weights = [weights] if torch.is_tensor(weights) else list(weights)
+    N, K = weights[0].shape
+    key = (M, N, K)
+    if key in _decode_plans or M > 256:
+        return _decode_plans.get(key)
+    dev = weights[0].device
+    if len(weights) * N * K * 2 < (1 << 30):                 # too small a footprint to defeat the cache: keep the defaults
+        return None
+    x = (torch.randn(M, K, device=dev) * 0.1).to(BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    scratch = _skinny_scratch(dev)
+    bm = 64 if M <= 64 else (128 if M <= 128 else 256)
+
+    def timed(fn):
+        fn(weights[0])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(reps):
+                    for wt in weights:
+                        fn(wt)
+        g.replay()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        g.replay(); g.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / (2 * reps * len(weights))
+
+    def run_default(weight):
+        lib().st_gemm_nt_skinny(_p(x), x.stride(0), _p(weight), weight.stride(0), None, None, 0, _p(out), out.stride(0), _p(scratch),
+                                scratch.numel(), M, N, K, _s())
+
+    best_t, best = timed(run_default), None
+    for v in _DECODE_CANDIDATES[bm]:
+        for sp in (1, 2, 4, 8):
+            if sp > 1 and (sp * M * N > scratch.numel() or N >= 16384 or K // 64 < 4 * sp):
+                continue
+
+            def run(weight, v=v, sp=sp):
+                lib().st_gemm_nt_decode_variant(v, sp, _p(x), x.stride(0), _p(weight), weight.stride(0), None, None, 0, _p(out),
+                                                out.stride(0), _p(scratch), scratch.numel(), M, N, K, _s())
+            t = timed(run)
+            if t < 0.97 * best_t:                           # keep the default unless clearly beaten
+                best_t, best = t, (v, sp)
+    if best is not None:
+        _decode_plans[key] = best
+    return best
+
+
 def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulate=False):
     """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(+residual).  Returns bf16 `out` (allocated if needed) unless `out_f32` given."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
@@ -160,11 +222,16 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
     assert b.shape[1] == K, (a.shape, b.shape)
     if out_f32 is None and out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
-    if out_f32 is None and M <= 256:                         # decode-shaped: weight-streaming skinny kernel
+    if out_f32 is None and M <= 256:                         # decode-shaped: weight-streaming tiles (+ split-K slabs)
         scratch = _skinny_scratch(a.device)
-        lib().st_gemm_nt_skinny(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
-                                residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), _p(scratch),
-                                scratch.numel(), M, N, K, _s())
+        plan = _decode_plans.get((M, N, K))
+        ldr = residual.stride(0) if residual is not None else 0
+        if plan is None:                                    # library default (heuristic table in gemm.hip)
+            lib().st_gemm_nt_skinny(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual), ldr, _p(out), out.stride(0),
+                                    _p(scratch), scratch.numel(), M, N, K, _s())
+        else:
+            lib().st_gemm_nt_decode_variant(plan[0], plan[1], _p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual), ldr,
+                                            _p(out), out.stride(0), _p(scratch), scratch.numel(), M, N, K, _s())
         return out
     c = out if out_f32 is None else out_f32
     lib().st_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),

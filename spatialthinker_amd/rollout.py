@@ -22,9 +22,18 @@ from .model import BF16, F32, I32, I64, Qwen25VL
 
 
 class Generator:
-    def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768):
+    def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False):
         self.m = model
         self.prefill_chunk_tokens = prefill_chunk_tokens
+        self.autotune = autotune          # time the decode GEMM tile/split-K candidates once per (batch, weight shape)
+
+    def _tune_decode(self, B: int):
+        w = self.m.p.w
+        head = w["lm_head"] if "lm_head" in w else w["embed"]
+        L = self.m.cfg.num_layers
+        for name in ("qkv_w", "o_w", "gu_w", "down_w"):
+            ops.autotune_decode_gemm(B, [w[f"l.{i}.{name}"] for i in range(L)])
+        ops.autotune_decode_gemm(B, head)                      # single weight: only tuned when it alone exceeds the cache
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
@@ -116,6 +125,9 @@ class Generator:
         pos = (last_pos + 1).contiguous()                      # position of the token sampled at response index 0
         tok32 = torch.zeros(B, dtype=I32, device=dev)
         pad_t = torch.full((B,), pad_token_id, dtype=I64, device=dev)
+
+        if self.autotune and Bp <= 256:
+            self._tune_decode(Bp)
 
         def iteration():
             """sample -> record -> one decode forward for all B rows -> next logits.  Device state only (graph-capturable).

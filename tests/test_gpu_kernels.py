@@ -328,7 +328,8 @@ def _attn_case(rs, lens, n_q, n_kv, D):
 
 @pytest.mark.parametrize("lens,n_q,n_kv,D,causal", [
     ([5], 2, 1, 128, True), ([130, 64, 1, 257], 4, 2, 128, True), ([200, 77], 7, 1, 128, True),
-    ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False)])
+    ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False),
+    ([700, 129, 383], 7, 1, 128, True), ([450, 65], 2, 2, 128, False)])      # many K/V tiles: the staged pipelines wrap their rings
 def test_attn_fwd(ops, lens, n_q, n_kv, D, causal):
     rs = np.random.RandomState(sum(lens) + D)
     qkv, cu = _attn_case(rs, lens, n_q, n_kv, D)
@@ -356,7 +357,8 @@ def test_attn_fwd(ops, lens, n_q, n_kv, D, causal):
 
 @pytest.mark.parametrize("lens,n_q,n_kv,D,causal", [
     ([5], 2, 1, 128, True), ([130, 64, 1, 257], 4, 2, 128, True), ([200, 77], 7, 1, 128, True),
-    ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False)])
+    ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False),
+    ([700, 129, 383], 7, 1, 128, True), ([450, 65], 2, 2, 128, False)])      # many K/V tiles: the staged pipelines wrap their rings
 def test_attn_bwd(ops, lens, n_q, n_kv, D, causal):
     rs = np.random.RandomState(sum(lens) + D + 1)
     qkv, cu = _attn_case(rs, lens, n_q, n_kv, D)

@@ -1,7 +1,7 @@
 """Generation-only probe (7B shapes): time per decode step with and without hipGraph replay."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_prompts
 from spatialthinker_amd.model import ParamStore, VLConfig, Qwen25VL
 from spatialthinker_amd.rollout import Generator
@@ -11,7 +11,7 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 graph = (sys.argv[3] == "graph") if len(sys.argv) > 3 else True
 cfg = VLConfig.qwen2_5_vl_7b()
 st = ParamStore(cfg, trainable=False); st.init_random(1)
-gen = Generator(Qwen25VL(cfg, st))
+gen = Generator(Qwen25VL(cfg, st), autotune=(os.environ.get("ST_TUNE", "0") == "1"))
 rs = np.random.RandomState(0)
 ids, mask, pos, pix, grids = synth_prompts(cfg, npr, rs, 1152, (1, 32, 42))
 for it in range(2):

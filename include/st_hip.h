@@ -125,6 +125,11 @@ int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16
 int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                       const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc, float* scratch,
                       int64_t scratch_elems, int M, int N, int K, st_stream_t stream);
+/* Decode MLP up-projection with the SwiGLU fused into the GEMM epilogue (M <= 256):
+ * out[M, I] = silu(A gate_w^T) * (A up_w^T) with gate_up_w = [gate_w ; up_w] (2I x K, the fused layout of ParamStore);
+ * same bf16 rounding points as st_gemm_nt + st_swiglu_fwd (HF Qwen2MLP.forward), bit-identical to that pair. */
+int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
+                          int M, int I, int K, st_stream_t stream);
 /* tuning entry for the decode-shaped GEMM: explicit tile variant (10..18, see gemm_tiles.hip) and split-K count */
 int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
                               const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,
@@ -172,6 +177,20 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
 int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows,
                   int heads, int D, int q_group /* g > 0: write row r, head h to out[r/g][(h*g + r%g)*D] */, st_stream_t stream);
+/* ---- fused decode epilogues (rollout decode step; replace finish + RMSNorm / finish + RoPE + KV-append launch chains) ----
+ * st_gemm_nt_decode_slabs: decode-shaped GEMM (M <= 256) that stops at the fp32 split-K slabs [splits][M][N] in `scratch`
+ * (*splits_out >= 1 slabs; host int written synchronously).
+ * st_decode_finish_norm:  x_out = bf16(sum slabs + residual);  h_out = RMSNorm(x_out) * norm_w  (norm_w NULL: finish only).
+ * st_decode_finish_qkv:   row = bf16(sum slabs + bias) of the fused q|k|v projection; M-RoPE on the q and k heads
+ *                         (cos/sin (B, D/2) fp32 as st_mrope_table makes them); q -> q_out[b], k, v -> kg/vg[b, gen_len[b], :].
+ * Bit-identical to st_gemm_nt_skinny -> st_rmsnorm_fwd and st_gemm_nt_skinny -> st_rope_apply -> st_kv_append. */
+int st_gemm_nt_decode_slabs(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, float* scratch, int64_t scratch_elems,
+                            int M, int N, int K, int* splits_out, st_stream_t stream);
+int st_decode_finish_norm(const float* slabs, int splits, const st_bf16* residual, int64_t ldr, st_bf16* x_out, int64_t ldx,
+                          const st_bf16* norm_w, float eps, st_bf16* h_out, int64_t ldh, int M, int N, st_stream_t stream);
+int st_decode_finish_qkv(const float* slabs, int splits, const st_bf16* bias, const float* cos_tab, const float* sin_tab,
+                         st_bf16* q_out, int64_t ldq, st_bf16* kg, st_bf16* vg, int64_t gen_stride, const int32_t* gen_len,
+                         int B, int M, int n_q, int n_kv, int D, st_stream_t stream);
 /* KV-cache append: for each sample b (active[b] != 0 or active NULL) copy the K and V column slices of qkv row b
  * into kg/vg[b, gen_len[b], :width]; if increment, gen_len[b] += 1 afterwards. */
 int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width, st_bf16* kg, st_bf16* vg,

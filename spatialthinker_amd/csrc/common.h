@@ -19,6 +19,7 @@ __device__ __forceinline__ uint16_t f2bf(float f) {            // round-to-neare
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 struct alignas(16) bf8 { uint16_t v[8]; };                      // one 16-byte global/LDS access
 

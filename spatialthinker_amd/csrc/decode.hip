@@ -125,7 +125,190 @@ __global__ void sample_finish_kernel(const float* __restrict__ scratch, int spli
     out_ids[row] = besti;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused decode epilogues.  The decode GEMMs leave fp32 split-K slabs [split][M][N]; instead of a finish kernel followed by
+// separate RMSNorm / RoPE / KV-append launches (each ~5 us of mostly launch latency per layer), one workgroup per row sums
+// the slabs in the fixed split order and applies everything that follows, with the same bf16 rounding points as the
+// unfused kernels (st_gemm_nt_skinny finish -> st_rmsnorm_fwd; finish -> st_rope_apply -> st_kv_append).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab_sum8(const float* __restrict__ slabs, int splits, int64_t slab_stride, int64_t off, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    // loads of four slabs are issued together (one latency instead of four); the additions keep the split order
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(slabs + (s + u) * slab_stride + off);
+            b[u] = *reinterpret_cast<const float4*>(slabs + (s + u) * slab_stride + off + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+        }
+    }
+    for (; s < splits; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(slabs + s * slab_stride + off);
+        const float4 b = *reinterpret_cast<const float4*>(slabs + s * slab_stride + off + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+}
+
+// x_out = bf16(sum slabs + residual);  h_out = rmsnorm(x_out) * norm_w (skipped when norm_w == NULL).  N <= 4096.
+// One workgroup per row; every global load of the row (all S slabs of both column chunks, residual, norm weight) is issued
+// before the first use, so the kernel costs one memory round trip instead of a chain of dependent ones (slab lines come
+// from other XCDs' write-backs: ~2 us each).
+template <int S>
+__global__ __launch_bounds__(256) void decode_finish_norm_kernel(const float* __restrict__ slabs, const uint16_t* __restrict__ res,
+                                                                int64_t ldr, uint16_t* __restrict__ x_out, int64_t ldx,
+                                                                const uint16_t* __restrict__ norm_w, float eps,
+                                                                uint16_t* __restrict__ h_out, int64_t ldh, int M, int N) {
+    __shared__ float part[4];
+    const int row = blockIdx.x;
+    const int64_t slab_stride = (int64_t)M * N;
+    const int i0 = threadIdx.x * 8, i1 = i0 + 2048;
+    const bool ok[2] = {i0 < N, i1 < N};
+    const int col[2] = {i0, i1};
+    float4 sa[2][S], sb[2][S];
+    uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}, ww[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (!ok[c]) continue;
+        const float* sp = slabs + (int64_t)row * N + col[c];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sa[c][s] = *reinterpret_cast<const float4*>(sp + s * slab_stride);
+            sb[c][s] = *reinterpret_cast<const float4*>(sp + s * slab_stride + 4);
+        }
+        if (res) rr[c] = *reinterpret_cast<const uint4*>(res + (int64_t)row * ldr + col[c]);
+        if (norm_w) ww[c] = *reinterpret_cast<const uint4*>(norm_w + col[c]);
+    }
+    float f[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (!ok[c]) continue;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                       // fixed split order: same sums as gemm_skinny_finish
+            v[0] += sa[c][s].x; v[1] += sa[c][s].y; v[2] += sa[c][s].z; v[3] += sa[c][s].w;
+            v[4] += sb[c][s].x; v[5] += sb[c][s].y; v[6] += sb[c][s].z; v[7] += sb[c][s].w;
+        }
+        if (res) {
+            float r[8];
+            unpack8(rr[c], r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+        }
+        const uint4 packed = pack8(v);
+        *reinterpret_cast<uint4*>(x_out + (int64_t)row * ldx + col[c]) = packed;
+        unpack8(packed, f[c]);                              // the norm sees the bf16-rounded stream value
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[c][j] * f[c][j];
+    }
+    if (!norm_w) return;
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)N + eps);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (!ok[c]) continue;
+        float wf[8];
+        unpack8(ww[c], wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[c][j] = wf[j] * bfround(f[c][j] * rstd);
+        *reinterpret_cast<uint4*>(h_out + (int64_t)row * ldh + col[c]) = pack8(f[c]);
+    }
+}
+
+// qkv row = bf16(sum slabs + bias); RoPE on the q and k heads; q -> q_out[b], k/v -> kg/vg[b, gen_len[b]].
+__global__ __launch_bounds__(256) void decode_finish_qkv_kernel(const float* __restrict__ slabs, int splits,
+                                                               const uint16_t* __restrict__ bias, const float* __restrict__ cosb,
+                                                               const float* __restrict__ sinb, uint16_t* __restrict__ q_out,
+                                                               int64_t ldq, uint16_t* __restrict__ kg, uint16_t* __restrict__ vg,
+                                                               int64_t gen_stride, const int32_t* __restrict__ gen_len, int B,
+                                                               int M, int n_q, int n_kv, int D) {
+    const int b = blockIdx.x;
+    const int N = (n_q + 2 * n_kv) * D;
+    const int64_t slab_stride = (int64_t)M * N;
+    const int half = D >> 1, chunks = half >> 3;
+    const int width = n_kv * D;
+    const int64_t cache_row = (int64_t)b * gen_stride + (int64_t)gen_len[b] * width;
+    // rotary heads: item = (head, chunk of 8 inside the first half); partner chunk at +half
+    for (int it = threadIdx.x; it < (n_q + n_kv) * chunks; it += 256) {
+        const int hd = it / chunks, ch = it % chunks;
+        const int col = hd * D + ch * 8;
+        float a[8], bb[8], ba[8], bbv[8];
+        slab_sum8(slabs, splits, slab_stride, (int64_t)b * N + col, a);
+        slab_sum8(slabs, splits, slab_stride, (int64_t)b * N + col + half, bb);
+        if (bias) {
+            unpack8(*reinterpret_cast<const uint4*>(bias + col), ba);
+            unpack8(*reinterpret_cast<const uint4*>(bias + col + half), bbv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] += ba[j]; bb[j] += bbv[j]; }
+        }
+        float c[8], sn[8], o1[8], o2[8];
+        const float* cp = cosb + (int64_t)b * half + ch * 8;
+        const float* sp = sinb + (int64_t)b * half + ch * 8;
+        *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(cp);
+        *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(cp + 4);
+        *reinterpret_cast<float4*>(sn) = *reinterpret_cast<const float4*>(sp);
+        *reinterpret_cast<float4*>(sn + 4) = *reinterpret_cast<const float4*>(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x1 = bfround(a[j]), x2 = bfround(bb[j]);             // the projection output is bf16 before the rotation
+            o1[j] = x1 * c[j] - x2 * sn[j];
+            o2[j] = x2 * c[j] + x1 * sn[j];
+        }
+        uint16_t* dst = hd < n_q ? q_out + (int64_t)b * ldq + col : kg + cache_row + (col - n_q * D);
+        *reinterpret_cast<uint4*>(dst) = pack8(o1);
+        *reinterpret_cast<uint4*>(dst + half) = pack8(o2);
+    }
+    // value heads: plain finish into the cache
+    for (int it = threadIdx.x; it < width / 8; it += 256) {
+        const int col = (n_q + n_kv) * D + it * 8;
+        float v[8], bv[8];
+        slab_sum8(slabs, splits, slab_stride, (int64_t)b * N + col, v);
+        if (bias) {
+            unpack8(*reinterpret_cast<const uint4*>(bias + col), bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bv[j];
+        }
+        *reinterpret_cast<uint4*>(vg + cache_row + it * 8) = pack8(v);
+    }
+}
+
 extern "C" {
+
+int st_decode_finish_norm(const float* slabs, int splits, const st_bf16* residual, int64_t ldr, st_bf16* x_out, int64_t ldx,
+                          const st_bf16* norm_w, float eps, st_bf16* h_out, int64_t ldh, int M, int N, st_stream_t stream) {
+    if (!slabs || splits <= 0 || !x_out || M <= 0 || N <= 0 || N > 4096 || (N & 7) || (ldx & 7) || (residual && (ldr & 7)) ||
+        (norm_w && (!h_out || (ldh & 7))))
+        return ST_EINVAL;
+#define ST_FN(S) hipLaunchKernelGGL(decode_finish_norm_kernel<S>, dim3(M), dim3(256), 0, (hipStream_t)stream, slabs, residual, ldr, x_out, ldx, norm_w, eps, h_out, ldh, M, N)
+    switch (splits) {
+        case 1: ST_FN(1); break; case 2: ST_FN(2); break; case 3: ST_FN(3); break; case 4: ST_FN(4); break;
+        case 5: ST_FN(5); break; case 6: ST_FN(6); break; case 7: ST_FN(7); break; case 8: ST_FN(8); break;
+        default: return ST_EINVAL;                          // decode_plan never splits deeper than 8
+    }
+#undef ST_FN
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_decode_finish_qkv(const float* slabs, int splits, const st_bf16* bias, const float* cos_tab, const float* sin_tab,
+                         st_bf16* q_out, int64_t ldq, st_bf16* kg, st_bf16* vg, int64_t gen_stride, const int32_t* gen_len, int B,
+                         int M, int n_q, int n_kv, int D, st_stream_t stream) {
+    if (!slabs || splits <= 0 || !cos_tab || !sin_tab || !q_out || !kg || !vg || !gen_len || B <= 0 || B > M || n_q <= 0 || n_kv <= 0 ||
+        (D & 15) || (ldq & 7))
+        return ST_EINVAL;
+    hipLaunchKernelGGL(decode_finish_qkv_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, slabs, splits, bias, cos_tab, sin_tab, q_out,
+                       ldq, kg, vg, gen_stride, gen_len, B, M, n_q, n_kv, D);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
 
 int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width, st_bf16* kg, st_bf16* vg, int64_t gen_stride,
                  int32_t* gen_len, const int32_t* active, int B, int increment, st_stream_t stream) {

@@ -51,7 +51,6 @@ __global__ void rope_apply_kernel(uint16_t* __restrict__ x, int64_t ld, const fl
 }
 
 // ------------------------------------------------------------------------------ SwiGLU / GELU
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 __global__ void swiglu_fwd_kernel(const uint16_t* __restrict__ gu, int64_t ldgu, uint16_t* __restrict__ out, int64_t ldo,
                                   int T, int I) {

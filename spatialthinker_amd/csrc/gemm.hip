@@ -423,6 +423,23 @@ extern "C" int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16*
     return launch_decode_tiles(variant, splits, A, lda, B, ldb, bias, residual, ldr, out_bf16, ldc, scratch, scratch_elems, M, N, K, s);
 }
 
+/* decode-shaped GEMM that stops at the fp32 split-K slabs [splits][M][N] (no finish): the caller's fused epilogue
+ * (st_decode_finish_norm / st_decode_finish_qkv) sums them.  *splits_out = number of slabs written (>= 1). */
+extern "C" int st_gemm_nt_decode_slabs(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, float* scratch,
+                                       int64_t scratch_elems, int M, int N, int K, int* splits_out, st_stream_t stream) {
+    if (!A || !B || !scratch || !splits_out || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K ||
+        ldb < K || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15) || scratch_elems < (int64_t)M * N)
+        return ST_EINVAL;
+    int variant, splits;
+    decode_plan(M, N, K, scratch_elems, &variant, &splits);
+    const int kt_per = st_cdiv(K / 64, splits);
+    splits = st_cdiv(K / 64, kt_per);
+    *splits_out = splits;
+    // splits == 1 also goes through the slab output (one fp32 slab) so the fused epilogue has a single input format
+    return st_gemm_tile_decode(variant, splits > 1 ? splits : -1, A, lda, B, ldb, nullptr, nullptr, 0, nullptr, scratch, M, N, K, N,
+                               (hipStream_t)stream);
+}
+
 /* decode-shaped GEMM (M <= 256): out_bf16 = A B^T (+bias)(+residual).  scratch (scratch_elems floats, contents
  * irrelevant) holds the split-K partial slabs [split][M][N]; NULL disables split-K. */
 extern "C" int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,

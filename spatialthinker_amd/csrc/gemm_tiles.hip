@@ -44,7 +44,10 @@ __device__ __forceinline__ void pin_schedule() {
     if constexpr (I + 1 < SLOTS) pin_schedule<I + 1, SLOTS, BASE, EXTRA, NVMEM>();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM>
+// SWIGLU (decode MLP): B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows
+// inside every wave's column slice, so a lane holds gate and up of the same output column in adjacent MFMA tiles and the
+// epilogue writes act(gate) * up for BN/2 output columns — the (M, 2N) intermediate and the SwiGLU launch disappear.
+template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     constexpr int A_INST = BM / 8, B_INST = BN / 8;        // 1 KiB wave-instructions per operand tile
     constexpr int PER_WAVE = (A_INST + B_INST) / NW;       // LDS-DMA instructions each wave issues per K-tile
     static_assert(A_INST % NW == 0 && B_INST % NW == 0, "tile rows must split evenly over the waves");
+    static_assert(!SWIGLU || (WTN % 32 == 0 && OUT_BF16 && !HAS_BIAS && !HAS_RES), "SwiGLU epilogue pairs 16-column MFMA tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int tm = first_m + in_g % gsz, tn = in_g / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = SWIGLU ? tn * (BN / 2) : tn * BN;      // SWIGLU: n0 = first OUTPUT column, N = output width
 
     auto stage = [&](int kt, char* dst) {
 #pragma unroll
@@ -91,7 +95,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         for (int j = 0; j < B_INST / NW; ++j) {
             const int inst = wave * (B_INST / NW) + j;
             const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
-            int gr = n0 + r; gr = gr < N ? gr : N - 1;
+            int gr;
+            if (SWIGLU) {
+                const int within = r % WTN;
+                const int j = (r / WTN) * (WTN / 2) + (within >> 5) * 16 + (within & 15);
+                gr = n0 + j; gr = gr < N ? gr : N - 1;
+                if (within & 16) gr += N;                    // the up-projection rows follow the N gate rows
+            } else {
+                gr = n0 + r; gr = gr < N ? gr : N - 1;
+            }
             glds16t(B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + inst * 1024);
         }
     };
@@ -174,6 +186,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + wm * WTM + mi * 16 + (lane & 15);
         if (m >= M) continue;
+        if constexpr (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ni += 2) {
+                const int n = n0 + wn * (WTN / 2) + (ni / 2) * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                uint16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {               // same roundings as the unfused path: bf16 gate/up, bf16 act(gate)
+                    const float g = bfround(acc[ni][mi][r]), u = bfround(acc[ni + 1][mi][r]);
+                    o[r] = f2bf(bfround(g * sigmoidf_(g)) * u);
+                }
+                uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                if (n + 3 < N && ((ldc & 3) == 0)) {
+                    uint2 w;
+                    w.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                    w.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                    *reinterpret_cast<uint2*>(cp) = w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = o[r];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
@@ -271,7 +307,7 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
                         const uint16_t* res, int64_t ldr, uint16_t* Cb, float* slabs, int M, int N, int K, int64_t ldc, hipStream_t s) {
 #define DEC_GO(BM, BN, WM, WN, ST)                                                                                               \
     do {                                                                                                                         \
-        if (splits > 1) return launch_tile<BM, BN, WM, WN, ST, false, false, false, false>(A, lda, B, ldb, nullptr, nullptr, 0, nullptr, slabs, N, M, N, K, s, splits, (int64_t)M * N); \
+        if (splits > 1 || splits < 0) return launch_tile<BM, BN, WM, WN, ST, false, false, false, false>(A, lda, B, ldb, nullptr, nullptr, 0, nullptr, slabs, N, M, N, K, s, splits < 0 ? 1 : splits, (int64_t)M * N); \
         if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);   \
         if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);         \
         if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);          \
@@ -293,6 +329,34 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
         default: return ST_EINVAL;
     }
 #undef DEC_GO
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_tile_swiglu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N,
+                              int K, hipStream_t s) {
+    constexpr int smem = STAGES * (BM + BN) * 128;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true>;
+    static bool configured = false;
+    if (!configured) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
+    const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN / 2);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr,
+                       (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
+                                     int M, int I, int K, st_stream_t stream) {
+    if (!A || !gate_up_w || !out || M <= 0 || M > 256 || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+        ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 64) return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    if (M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
 }
 
 extern "C" int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,

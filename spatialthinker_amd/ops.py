@@ -240,6 +240,37 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
     return c
 
 
+# ------------------------------------------------------------------ fused decode epilogues
+def gemm_nt_decode_slabs(a, b):
+    """Decode-shaped GEMM (M <= 256) that leaves fp32 split-K slabs in the shared scratch; returns (scratch, splits)."""
+    import ctypes
+    M, K = a.shape
+    N = b.shape[0]
+    scratch = _skinny_scratch(a.device)
+    sp = ctypes.c_int(0)
+    lib().st_gemm_nt_decode_slabs(_p(a), a.stride(0), _p(b), b.stride(0), _p(scratch), scratch.numel(), M, N, K, ctypes.addressof(sp), _s())
+    return scratch, sp.value
+
+
+def decode_finish_norm(slabs, splits, M, N, *, residual, x_out, norm_w=None, eps=1e-6, h_out=None):
+    lib().st_decode_finish_norm(_p(slabs), splits, _p(residual), residual.stride(0) if residual is not None else 0, _p(x_out),
+                                x_out.stride(0), _p(norm_w), eps, _p(h_out), h_out.stride(0) if h_out is not None else 0, M, N, _s())
+
+
+def decode_finish_qkv(slabs, splits, M, bias, cos, sin, q_out, kg, vg, gen_len, B, n_q, n_kv, D):
+    lib().st_decode_finish_qkv(_p(slabs), splits, _p(bias), _p(cos), _p(sin), _p(q_out), q_out.stride(0), _p(kg), _p(vg), kg.stride(0),
+                               _p(gen_len), B, M, n_q, n_kv, D, _s())
+
+
+def gemm_swiglu_decode(a, gate_up_w, out=None):
+    """out[M, I] = silu(a @ gate_w^T) * (a @ up_w^T), gate_up_w = [gate_w ; up_w] (2I, K); M <= 256."""
+    M, K = a.shape
+    I = gate_up_w.shape[0] // 2
+    out = torch.empty(M, I, dtype=BF16, device=a.device) if out is None else out
+    lib().st_gemm_swiglu_decode(_p(a), a.stride(0), _p(gate_up_w), gate_up_w.stride(0), _p(out), out.stride(0), M, I, K, _s())
+    return out
+
+
 def gemm_nt_variant(variant, a, b, out=None, out_f32=None, accumulate=False, bias=None, residual=None):
     M, K = a.shape
     N = b.shape[0]

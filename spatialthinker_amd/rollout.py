@@ -22,8 +22,9 @@ from .model import BF16, F32, I32, I64, Qwen25VL
 
 
 class Generator:
-    def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False):
+    def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False, fused_decode: bool = True):
         self.m = model
+        self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
         self.autotune = autotune          # time the decode GEMM tile/split-K candidates once per (batch, weight shape)
 
@@ -128,6 +129,8 @@ class Generator:
 
         if self.autotune and Bp <= 256:
             self._tune_decode(Bp)
+        fused = self.fused_decode and Bp <= 256 and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
+        qbuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)             # roped queries of the fused path (pad rows stay zero)
 
         def iteration():
             """sample -> record -> one decode forward for all B rows -> next logits.  Device state only (graph-capturable).
@@ -146,22 +149,46 @@ class Generator:
             ops.embed_gather(w["embed"], tok32, out=xbuf[:B])
             x = xbuf
             ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (gen_len + 1).repeat(Cg)), kb2).contiguous()
-            for layer in range(L):
-                p = f"l.{layer}."
-                h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
-                qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
-                ops.rope_apply_(qkv[:B], cos, sin, nq + nkv, D)
-                ops.kv_append_(qkv[:B], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
-                ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts,
-                                    o_beg=ob1, q_group=g)
-                ops.attn_fwd_ranges(qkv, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
-                                    nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
-                ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
-                x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
-                h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
-                mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
-                x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
-            hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
+            if fused:
+                # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE + cache
+                # append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue
+                H = c.hidden_size
+                h1, _ = ops.rmsnorm_fwd(x, w["l.0.in_norm"], c.rms_eps, want_rstd=False)
+                for layer in range(L):
+                    p = f"l.{layer}."
+                    slabs, sp = ops.gemm_nt_decode_slabs(h1, w[p + "qkv_w"])
+                    ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], gen_len, B, nq, nkv, D)
+                    ops.attn_fwd_ranges(qbuf, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts,
+                                        o_beg=ob1, q_group=g)
+                    ops.attn_fwd_ranges(qbuf, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
+                                        nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
+                    ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)
+                    slabs, sp = ops.gemm_nt_decode_slabs(abuf, w[p + "o_w"])
+                    x1 = torch.empty(Bp, H, dtype=BF16, device=dev); h2 = torch.empty(Bp, H, dtype=BF16, device=dev)
+                    ops.decode_finish_norm(slabs, sp, Bp, H, residual=x, x_out=x1, norm_w=w[p + "post_norm"], eps=c.rms_eps, h_out=h2)
+                    mm = ops.gemm_swiglu_decode(h2, w[p + "gu_w"])
+                    slabs, sp = ops.gemm_nt_decode_slabs(mm, w[p + "down_w"])
+                    x = torch.empty(Bp, H, dtype=BF16, device=dev); h1 = torch.empty(Bp, H, dtype=BF16, device=dev)
+                    nxt = w[f"l.{layer + 1}.in_norm"] if layer + 1 < L else w["final_norm"]
+                    ops.decode_finish_norm(slabs, sp, Bp, H, residual=x1, x_out=x, norm_w=nxt, eps=c.rms_eps, h_out=h1)
+                hn2 = h1
+            else:
+                for layer in range(L):
+                    p = f"l.{layer}."
+                    h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
+                    qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+                    ops.rope_apply_(qkv[:B], cos, sin, nq + nkv, D)
+                    ops.kv_append_(qkv[:B], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
+                    ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts,
+                                        o_beg=ob1, q_group=g)
+                    ops.attn_fwd_ranges(qkv, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
+                                        nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
+                    ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
+                    x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
+                    h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
+                    mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
+                    x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
+                hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
             ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits)
             gen_len.add_(1); pos.add_(1); step_t.add_(1)
 

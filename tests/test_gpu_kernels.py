@@ -379,3 +379,47 @@ def test_attn_bwd(ops, lens, n_q, n_kv, D, causal):
     for name, sl in (("dq", slice(0, n_q * D)), ("dk", slice(n_q * D, (n_q + n_kv) * D)), ("dv", slice((n_q + n_kv) * D, None))):
         err = np.abs(got[:, sl] - want[:, sl]).max() / (np.abs(want[:, sl]).max() + 1e-9)
         assert err < 2e-2, (name, err)
+
+
+# ------------------------------------------------------------------ fused decode epilogues vs the unfused launch chain
+@pytest.mark.parametrize("M,B", [(32, 24), (64, 64), (160, 150)])
+def test_decode_fused_ops_bit_identical(ops, M, B):
+    rs = np.random.RandomState(M)
+    n_q, n_kv, D, H, I = 4, 2, 128, 512, 8200          # 2I >= 16384: the gate/up GEMM takes the no-split plan like the real MLP
+    N = (n_q + 2 * n_kv) * D
+    dev_ = lambda a, dt=torch.bfloat16: torch.from_numpy(a).to("cuda").to(dt)
+    h = dev_(rs.randn(M, H).astype(np.float32))
+    wqkv, bqkv = dev_(rs.randn(N, H).astype(np.float32) * 0.05), dev_(rs.randn(N).astype(np.float32))
+    cos = torch.from_numpy(np.cos(rs.rand(B, D // 2) * 6).astype(np.float32)).cuda()
+    sin = torch.from_numpy(np.sin(rs.rand(B, D // 2) * 6).astype(np.float32)).cuda()
+    R, width = 5, n_kv * D
+    gen_len = torch.from_numpy(rs.randint(0, R, B).astype(np.int32)).cuda()
+    # --- unfused: GEMM(+bias) -> RoPE -> KV append
+    qkv = ops.gemm_nt(h, wqkv, bias=bqkv)
+    ops.rope_apply_(qkv[:B], cos, sin, n_q + n_kv, D)
+    kg0, vg0 = torch.zeros(B, R, width, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, R, width, dtype=torch.bfloat16, device="cuda")
+    ops.kv_append_(qkv[:B], n_q * D, n_q * D + width, width, kg0, vg0, gen_len)
+    # --- fused
+    slabs, sp = ops.gemm_nt_decode_slabs(h, wqkv)
+    qb = torch.zeros(M, n_q * D, dtype=torch.bfloat16, device="cuda")
+    kg1, vg1 = torch.zeros_like(kg0), torch.zeros_like(vg0)
+    ops.decode_finish_qkv(slabs, sp, M, bqkv, cos, sin, qb, kg1, vg1, gen_len, B, n_q, n_kv, D)
+    assert torch.equal(qb[:B], qkv[:B, :n_q * D]) and torch.equal(kg0, kg1) and torch.equal(vg0, vg1)
+
+    # --- finish + residual + RMSNorm
+    a = dev_(rs.randn(M, n_q * D).astype(np.float32))
+    wo = dev_(rs.randn(H, n_q * D).astype(np.float32) * 0.05)
+    res = dev_(rs.randn(M, H).astype(np.float32))
+    nw = dev_(1.0 + 0.1 * rs.randn(H).astype(np.float32))
+    x_ref = ops.gemm_nt(a, wo, residual=res)
+    h_ref, _ = ops.rmsnorm_fwd(x_ref, nw, 1e-6, want_rstd=False)
+    slabs, sp = ops.gemm_nt_decode_slabs(a, wo)
+    x1, h1 = torch.empty_like(x_ref), torch.empty_like(h_ref)
+    ops.decode_finish_norm(slabs, sp, M, H, residual=res, x_out=x1, norm_w=nw, eps=1e-6, h_out=h1)
+    assert torch.equal(x1, x_ref) and torch.equal(h1, h_ref)
+
+    # --- SwiGLU in the gate/up epilogue
+    wgu = dev_(rs.randn(2 * I, H).astype(np.float32) * 0.05)
+    ref = ops.swiglu_fwd(ops.gemm_nt(h, wgu))
+    got = ops.gemm_swiglu_decode(h, wgu)
+    assert torch.equal(ref, got)

@@ -61,6 +61,19 @@ def test_greedy_decode_matches_teacher_forced_oracle(env, use_graph):
             assert chosen >= float(row.max()) - 0.08, (b, j, chosen, float(row.max()))    # argmax up to bf16 noise
 
 
+def test_fused_decode_epilogues_are_bit_identical_to_unfused_chain(env):
+    """The fused decode step (slab GEMM + finish/RoPE/KV-append, finish/RMSNorm, SwiGLU epilogue) keeps every bf16 rounding
+    point of the unfused launch chain: sampled responses agree token for token."""
+    from spatialthinker_amd.rollout import Generator
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    kw = dict(n=3, max_new_tokens=12, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID, seed=5,
+              pixel_values=pix, image_grid_thw=grids, ignore_eos=True)
+    a = gen.generate(ids, mask, pos, **kw).cpu().numpy()
+    b = Generator(eng, fused_decode=False).generate(ids, mask, pos, **kw).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+
+
 def test_eos_stops_and_pads_and_forced_lengths(env):
     cfg, params, eng, gen = env
     ids, mask, pos, pix, grids = _prompts()

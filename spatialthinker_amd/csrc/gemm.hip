@@ -335,9 +335,10 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     hipStream_t s = (hipStream_t)stream;
     const bool hb = bias != nullptr, hr = residual != nullptr;
     StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);   // MFMA-bound class only (roofline.achieved)
-    // tile choice (tools/gemm_tune.py on MI355X): the 256x256 tile (8 waves, 128 KiB LDS, 128 flop/B of L2 traffic) wins
-    // by 10-15 % once there are >= ~1.75 workgroups per CU; below that the 128x128 tile (2 workgroups/CU) fills the chip better.
-    if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 450)
+    // tile choice (tools/gemm_shapes.py on MI355X, all 12 fwd/dX/dW shapes of a 7B layer): the 256x256 tile (8 waves, 128 KiB LDS,
+    // 128 flop/B of L2 traffic) wins or ties from ~0.5 workgroups per CU upwards (dW of the 3584x3584 projection, 196 tiles:
+    // 1098 vs 926 TF); only smaller problems fill the chip better with 128x128 tiles at 2 workgroups/CU.
+    if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 128)
         return st_gemm_tile_dispatch(4, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);
 #define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
     if (out_bf16) {

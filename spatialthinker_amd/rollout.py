@@ -24,6 +24,7 @@ from .model import BF16, F32, I32, I64, Qwen25VL
 class Generator:
     def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False, fused_decode: bool = True):
         self.m = model
+        self.max_decode_batch = 256       # sequences decoded together (rows of the decode GEMMs)
         self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
         self.autotune = autotune          # time the decode GEMM tile/split-K candidates once per (batch, weight shape)
@@ -49,6 +50,22 @@ class Generator:
         dev = self.m.p.device
         ids_np, mask_np, pos_np = (np.asarray(x.cpu() if torch.is_tensor(x) else x) for x in (input_ids, attention_mask, position_ids))
         nb, P = ids_np.shape
+        # The decode GEMMs stream the weights once per step for up to 256 rows (above that they turn MFMA-bound and a second
+        # wave costs the same as a wider one): larger rollout batches run as waves of <= 256 sequences, each with its own
+        # prompt KV, caches and decode graph.
+        per_wave = max(1, self.max_decode_batch // n)
+        if nb > per_wave:
+            outs = []
+            for wv, i0 in enumerate(range(0, nb, per_wave)):
+                i1 = min(nb, i0 + per_wave)
+                outs.append(self.generate(ids_np[i0:i1], mask_np[i0:i1], pos_np[i0:i1], n=n, max_new_tokens=max_new_tokens,
+                                          temperature=temperature, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                          seed=seed + 7919 * wv,
+                                          pixel_values=None if pixel_values is None else pixel_values[i0:i1],
+                                          image_grid_thw=None if image_grid_thw is None else image_grid_thw[i0:i1],
+                                          forced_lengths=None if forced_lengths is None else np.asarray(forced_lengths)[i0 * n:i1 * n],
+                                          ignore_eos=ignore_eos, sync_every=sync_every, use_graph=use_graph))
+            return torch.cat(outs, 0)
         if pos_np.ndim == 2:
             pos_np = np.repeat(pos_np[:, None, :], 3, 1)
         B, R = nb * n, max_new_tokens

@@ -1,6 +1,6 @@
 """Run ONE GEMM variant a few times (for rocprofv3 --pmc passes)."""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialthinker_amd import ops
 v, M, N, K = (int(x) for x in sys.argv[1:5])
 a = torch.randn(M, K, device="cuda").bfloat16(); b = torch.randn(N, K, device="cuda").bfloat16()

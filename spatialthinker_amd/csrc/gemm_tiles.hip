@@ -47,7 +47,11 @@ __device__ __forceinline__ void pin_schedule() {
 // SWIGLU (decode MLP): B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows
 // inside every wave's column slice, so a lane holds gate and up of the same output column in adjacent MFMA tiles and the
 // epilogue writes act(gate) * up for BN/2 output columns — the (M, 2N) intermediate and the SwiGLU launch disappear.
-template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false>
+// MIDBAR (2 stages only): the per-tile barrier sits BETWEEN the two k-steps of a tile instead of in front of it.  At that point
+// every wave holds both k-steps' fragments of tile t in registers (slot t is free for the DMA of tile t+2) and tile t+1 has
+// landed, so the fragment reads of tile t+1 run under the MFMAs of (t, k-step 1): no LDS read is ever exposed behind a barrier.
+template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false,
+          bool MIDBAR = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    constexpr int GM = (BM >= 256) ? 4 : 8;
+    constexpr int GM = (BM >= 256) ? 8 : 8;
     const int per_group = GM * tiles_n;
     const int group = bid / per_group, in_g = bid % per_group;
     const int first_m = group * GM;
@@ -178,9 +182,65 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][ni], af[1][mi], acc[ni][mi], 0, 0, 0);
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     };
-    int kt = 0;
-    for (; kt + STAGES - 1 < nk; ++kt) tile_body(kt, std::true_type{});
-    for (; kt < nk; ++kt) tile_body(kt, std::false_type{});
+    if constexpr (!MIDBAR) {
+        int kt = 0;
+        for (; kt + STAGES - 1 < nk; ++kt) tile_body(kt, std::true_type{});
+        for (; kt < nk; ++kt) tile_body(kt, std::false_type{});
+    } else {
+        static_assert(!MIDBAR || STAGES == 2, "mid-tile barrier schedule uses exactly two LDS slots");
+        bf16x8 af[2][TM], bfr[2][TN];
+        auto load_frags = [&](const char* la, int s, bf16x8 (&a_)[TM], bf16x8 (&b_)[TN]) {
+            const char* lb = la + A_BYTES;
+            const int kc = s * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ra = wm * WTM + i * 16 + frow;
+                a_[i] = *reinterpret_cast<const bf16x8*>(la + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int rb = wn * WTN + i * 16 + frow;
+                b_[i] = *reinterpret_cast<const bf16x8*>(lb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+            }
+        };
+        auto mfmas = [&](bf16x8 (&a_)[TM], bf16x8 (&b_)[TN]) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_[ni], a_[mi], acc[ni][mi], 0, 0, 0);
+        };
+        constexpr int SLOTS = TM + TN, BASE = (TM * TN) / SLOTS, EXTRA = TM * TN - BASE * SLOTS;
+        // prologue: tiles 0 and 1 in flight (tile 0 was issued above), fragments of (0, k-step 0) in registers
+        if (nk > 1) { stage(1, smem + STAGE); wait_vmcnt<PER_WAVE>(); } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (nk > 0) load_frags(smem, 0, af[0], bfr[0]);
+        auto tile = [&](int kt, auto next_tag, auto dma_tag) {
+            constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_DMA = decltype(dma_tag)::value;
+            const char* cur = smem + (kt & 1) * STAGE;
+            const char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            // phase A: MFMAs of k-step 0 with the reads of k-step 1 in their shadow
+            load_frags(cur, 1, af[1], bfr[1]);
+            mfmas(af[0], bfr[0]);
+            pin_schedule<0, SLOTS, BASE, EXTRA, 0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HAS_NEXT) {
+                wait_vmcnt<0>();                             // tile kt+1 (issued one tile ago) has landed
+                __builtin_amdgcn_s_barrier();                // ... for every wave, and every wave is done reading slot kt
+                asm volatile("" ::: "memory");
+                if constexpr (HAS_DMA) stage(kt + 2, smem + (kt & 1) * STAGE);
+                load_frags(nxt, 0, af[0], bfr[0]);           // phase B: reads of (kt+1, k-step 0) under the MFMAs of (kt, k-step 1)
+            }
+            mfmas(af[1], bfr[1]);
+            if constexpr (HAS_NEXT) pin_schedule<0, SLOTS, BASE, EXTRA, HAS_DMA ? PER_WAVE : 0>();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { tile(kt, std::true_type{}, std::false_type{}); ++kt; }
+        if (kt < nk) tile(kt, std::false_type{}, std::false_type{});
+    }
 
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -251,12 +311,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC>
+template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
                        int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s, int splits = 1,
                        int64_t slab_stride = 0) {
     constexpr int smem = STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -271,28 +331,30 @@ static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
 }
 
 // variant ids: 0 = 128x128 2x2 waves 2 stages, 1 = 128x128 3 stages, 2 = 256x128 4x2 2 stages, 3 = 256x128 4x2 3 stages,
-//              4 = 256x256 4x2 2 stages, 5 = 128x256 2x4 3 stages
+//              4 = 256x256 4x2 2 stages, 5 = 128x256 2x4 3 stages, 6 / 7 = 256x256 / 128x128 with the mid-tile barrier schedule
 int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
                           const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K,
                           hipStream_t s) {
-#define TILE_GO(BM, BN, WM, WN, ST)                                                                                              \
+#define TILE_GO(BM, BN, WM, WN, ST, MB)                                                                                          \
     do {                                                                                                                         \
         if (Cb) {                                                                                                                \
-            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
-            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
-            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
-            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
+            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
+            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
+            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
+            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
         }                                                                                                                        \
-        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
-        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
+        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
+        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
     } while (0)
     switch (variant) {
-        case 0: TILE_GO(128, 128, 2, 2, 2);
-        case 1: TILE_GO(128, 128, 2, 2, 3);
-        case 2: TILE_GO(256, 128, 4, 2, 2);
-        case 3: TILE_GO(256, 128, 4, 2, 3);
-        case 4: TILE_GO(256, 256, 4, 2, 2);
-        case 5: TILE_GO(128, 256, 2, 4, 3);
+        case 0: TILE_GO(128, 128, 2, 2, 2, false);
+        case 1: TILE_GO(128, 128, 2, 2, 3, false);
+        case 2: TILE_GO(256, 128, 4, 2, 2, false);
+        case 3: TILE_GO(256, 128, 4, 2, 3, false);
+        case 4: TILE_GO(256, 256, 4, 2, 2, false);
+        case 5: TILE_GO(128, 256, 2, 4, 3, false);
+        case 6: TILE_GO(256, 256, 4, 2, 2, true);
+        case 7: TILE_GO(128, 128, 2, 2, 2, true);
         default: return ST_EINVAL;
     }
 #undef TILE_GO

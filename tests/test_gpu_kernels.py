@@ -283,6 +283,24 @@ def test_gemm_nt(ops, M_, N, K):
     assert np.abs(acc.cpu().numpy() - want.numpy()).max() < scale * 1e-5 + 1e-4
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("K", [64, 128, 192, 320])
+def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
+    """Every tile/pipeline variant (2- and 3-slot rings, the mid-tile-barrier schedule) at 1, 2, 3 and 5 K-tiles — the
+    prologue / steady state / peeled tail paths — with ragged M, N; bf16 and fp32-accumulate epilogues."""
+    rs = np.random.RandomState(variant * 100 + K)
+    M_, N = 300, 520
+    a = bf(rs.standard_normal((M_, K))).cuda()
+    b = bf(rs.standard_normal((N, K)) * (1 + np.arange(N)[:, None] / N)).cuda()
+    want = a.float() @ b.float().t()
+    scale = float(want.abs().max())
+    out = ops.gemm_nt_variant(variant, a, b)
+    assert float((out.float() - want).abs().max()) < scale * 2 ** -7
+    acc = torch.full((M_, N), 0.25, dtype=torch.float32, device="cuda")
+    ops.gemm_nt_variant(variant, a, b, out_f32=acc, accumulate=True)
+    assert float((acc - want - 0.25).abs().max()) < scale * 1e-5 + 1e-4
+
+
 def test_gemm_identity_layout(ops):
     """A = I (padded) against an asymmetric B: C must equal B^T block exactly."""
     K = 128

@@ -1,7 +1,7 @@
 """A/B of the GEMM tile variants on the 7B shapes (interleaved rounds, random normal operands), with a correctness check."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialthinker_amd import ops
 
 def bench(fn, iters=10):

@@ -239,9 +239,13 @@ def main():
             for k, v in zip(phase, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
                 phase[k] += v
             seqlens = mask_f.sum(1).tolist()
-            patches = [grid[0] * grid[1] * grid[2]] * B
-            f = cfg.flops_forward(seqlens, patches, logit_rows=int(rmask.sum()))
-            flops["old"] += f; flops["ref"] += f; flops["update"] += 3 * f
+            # the vision tower runs once per distinct image of a micro-batch (the G rollouts of a prompt share theirs): count
+            # only the ViT work actually done — ceil(mb / G) images per micro-batch
+            n_patch = grid[0] * grid[1] * grid[2]
+            vit_passes = lambda mb: (B // mb) * max(1, -(-mb // G)) if B % mb == 0 else B
+            f_exp = cfg.flops_forward(seqlens, [n_patch] * vit_passes(hyper.micro_batch_size_per_device_for_experience), logit_rows=int(rmask.sum()))
+            f_upd = cfg.flops_forward(seqlens, [n_patch] * vit_passes(micro), logit_rows=int(rmask.sum()))
+            flops["old"] += f_exp; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
             tokens_total[0] += int(mask_f.sum())
         return metrics
 

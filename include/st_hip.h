@@ -218,6 +218,11 @@ int st_rows_gather(const st_bf16* src, int64_t lds, const int32_t* rows, st_bf16
                    int H, st_stream_t stream);                     /* dst[i] = src[rows[i]] */
 int st_rows_scatter(const st_bf16* src, int64_t lds, const int32_t* rows, st_bf16* dst, int64_t ldd, int n_rows,
                     int H, int add, st_stream_t stream);           /* dst[rows[i]] (+)= src[i], rows unique */
+/* dst[u] = bf16(sum over r < k of src[idx[u*k + r]]) accumulated in fp32 in the fixed order r = 0..k-1 (entries < 0 are
+ * skipped): backward of a row gather with repeated sources.  Used for the image features that the G rollouts of one prompt share
+ * (the reference runs the vision tower once per SEQUENCE, dp_actor.py:78-83; here once per distinct image of a micro-batch). */
+int st_rows_gather_sum(const st_bf16* src, int64_t lds, const int32_t* idx, int k, st_bf16* dst, int64_t ldd, int n_out, int H,
+                       st_stream_t stream);
 int st_embed_grad(const st_bf16* dx, int64_t ldx, const int32_t* ids, float* dtable, int64_t ldt, int T, int H,
                   st_stream_t stream);                             /* dtable[ids[t]] += dx[t] (fp32 atomics) */
 int st_cast_pad_f32_bf16(const float* in, int64_t ldin, st_bf16* out, int64_t ldout, int R, int C_in, int C_out,

@@ -69,15 +69,28 @@ class PolicyEngine:
     # ------------------------------------------------------------------ micro-batch plumbing
     def _stage(self, data: Dict[str, Any], sl: slice):
         mm = data.get("multi_modal_inputs")
-        px = gr = None
+        px = gr = image_map = None
         if mm is not None:
-            items = mm[sl]
-            pxs = [torch.as_tensor(it["pixel_values"]) for it in items if it is not None and "pixel_values" in it]
-            if pxs:                                              # dp_actor.py:78-83 — concatenate over the samples
-                px = torch.cat(pxs, 0)
-                gr = np.concatenate([np.asarray(it["image_grid_thw"]).reshape(-1, 3) for it in items if it is not None and "image_grid_thw" in it], 0)
+            items = [it for it in mm[sl] if it is not None and "pixel_values" in it]
+            if items:                                            # dp_actor.py:78-83 concatenates over the samples
+                # The G rollouts of a prompt carry the SAME image object (DataProto.repeat / np.repeat keep references): the vision
+                # tower runs once per distinct image of the micro-batch and its features (and their gradient sum) are shared.
+                uniq, image_map = {}, []
+                for it in items:
+                    key = id(it["pixel_values"])
+                    if key not in uniq:
+                        uniq[key] = (len(uniq), it)
+                    image_map.append(uniq[key][0])
+                order = [it for _, it in sorted(uniq.values(), key=lambda kv: kv[0])]
+                px = torch.cat([torch.as_tensor(it["pixel_values"]) for it in order], 0)
+                gr = np.concatenate([np.asarray(it["image_grid_thw"]).reshape(-1, 3) for it in order], 0)
+                if any(len(np.asarray(it["image_grid_thw"]).reshape(-1, 3)) != 1 for it in order) or len(order) == len(items):
+                    if len(order) != len(items):                 # several images per sample: keep the plain per-sample path
+                        px = torch.cat([torch.as_tensor(it["pixel_values"]) for it in items], 0)
+                        gr = np.concatenate([np.asarray(it["image_grid_thw"]).reshape(-1, 3) for it in items], 0)
+                    image_map = None
         R = data["responses"].shape[1]
-        return self.model.stage(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R, px, gr)
+        return self.model.stage(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R, px, gr, image_map=image_map)
 
     @torch.no_grad()
     def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None) -> torch.Tensor:

@@ -212,6 +212,25 @@ __global__ void rows_scatter_kernel(const uint16_t* __restrict__ src, int64_t ld
     }
     *reinterpret_cast<uint4*>(d) = v;
 }
+// dst[u] = bf16( sum_r src[idx[u*k + r]] ) in fp32, fixed order r = 0..k-1, entries < 0 skipped (gradient of a row gather
+// with repeated sources: image features shared by the rollouts of one prompt)
+__global__ void rows_gather_sum_kernel(const uint16_t* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx, int k,
+                                       uint16_t* __restrict__ dst, int64_t ldd, int n_out, int H) {
+    const int chunks = H >> 3;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)n_out * chunks) return;
+    const int u = (int)(id / chunks), c = (int)(id % chunks) * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < k; ++r) {
+        const int32_t row = idx[(int64_t)u * k + r];
+        if (row < 0) continue;
+        float b[8];
+        unpack8(*reinterpret_cast<const uint4*>(src + (int64_t)row * lds + c), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+    }
+    *reinterpret_cast<uint4*>(dst + (int64_t)u * ldd + c) = pack8(a);
+}
 __global__ void embed_grad_kernel(const uint16_t* __restrict__ dx, int64_t ldx, const int32_t* __restrict__ ids,
                                   float* __restrict__ dtable, int64_t ldt, int T, int H) {
     const int chunks = H >> 3;
@@ -500,6 +519,16 @@ int st_rows_scatter(const st_bf16* src, int64_t lds, const int32_t* rows, st_bf1
     const int64_t n = (int64_t)n_rows * (H / 8);
     hipLaunchKernelGGL(rows_scatter_kernel, dim3(st_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, lds, rows, dst, ldd,
                        n_rows, H, add);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+int st_rows_gather_sum(const st_bf16* src, int64_t lds, const int32_t* idx, int k, st_bf16* dst, int64_t ldd, int n_out, int H,
+                       st_stream_t stream) {
+    if (!src || !idx || !dst || k <= 0 || n_out < 0 || H <= 0 || (H & 7) || (lds & 7) || (ldd & 7)) return ST_EINVAL;
+    if (n_out == 0) return 0;
+    const int64_t n = (int64_t)n_out * (H / 8);
+    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(st_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, lds, idx, k, dst, ldd,
+                       n_out, H);
     ST_CHECK_LAUNCH();
     return 0;
 }

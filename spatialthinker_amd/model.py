@@ -320,7 +320,10 @@ class Qwen25VL:
         self.v_scale = cfg.v_head_dim ** -0.5
 
     # ---------------------------------------------------------------- batch staging
-    def stage(self, input_ids, attention_mask, position_ids, response_length: int, pixel_values=None, image_grid_thw=None) -> DeviceBatch:
+    def stage(self, input_ids, attention_mask, position_ids, response_length: int, pixel_values=None, image_grid_thw=None,
+              image_map=None) -> DeviceBatch:
+        """image_map (optional): pixel_values / image_grid_thw hold each DISTINCT image once and image_map[j] names the image of the
+        j-th image-bearing sample (one image per sample); the features are gathered per sample and their gradients summed."""
         c, dev = self.cfg, self.p.device
         pk = ix.pack_batch(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, image_token_id=c.image_token_id)
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
@@ -333,7 +336,25 @@ class Qwen25VL:
         vis = None
         if pixel_values is not None and len(pk.image_rows):
             plan = ix.plan_vision(_np(image_grid_thw), merge=c.v_merge, window=c.v_window, patch=c.v_patch, head_dim=c.v_head_dim)
-            assert plan.n_patches // (c.v_merge ** 2) == len(pk.image_rows), "image tokens != image features"
+            n_feat = plan.n_patches // (c.v_merge ** 2)
+            img_src = dup_idx = None
+            if image_map is not None:
+                g_ = _np(image_grid_thw).reshape(-1, 3)
+                n_tok = (g_[:, 0] * g_[:, 1] * g_[:, 2]) // (c.v_merge ** 2)
+                off = np.concatenate([[0], np.cumsum(n_tok)])
+                img_src = np.concatenate([np.arange(off[u], off[u + 1]) for u in image_map]).astype(np.int32)
+                users = [[] for _ in range(len(n_tok))]
+                pos0 = 0
+                for u in image_map:                              # positions (in image_rows order) of every user of image u
+                    users[u].append(pos0); pos0 += int(n_tok[u])
+                kmax = max(len(x_) for x_ in users)
+                dup_idx = -np.ones((n_feat, kmax), dtype=np.int32)
+                for u, starts in enumerate(users):
+                    for r_, st_ in enumerate(starts):
+                        dup_idx[off[u]:off[u + 1], r_] = st_ + np.arange(int(n_tok[u]))
+                assert len(img_src) == len(pk.image_rows), "image tokens != image features"
+            else:
+                assert n_feat == len(pk.image_rows), "image tokens != image features"
             N_pad = ix.round_up(plan.n_patches, 256)      # N_pad/4 (merger rows) stays a multiple of 64
             gather = np.zeros(N_pad, dtype=np.int32); gather[:plan.n_patches] = plan.patch_gather
             vcos = np.zeros((N_pad, c.v_head_dim // 2), np.float32); vcos[:plan.n_patches] = plan.cos
@@ -341,7 +362,8 @@ class Qwen25VL:
             px = pixel_values if torch.is_tensor(pixel_values) else torch.from_numpy(np.asarray(pixel_values))
             vis = dict(N=plan.n_patches, N_pad=N_pad, px=px.to(device=dev, dtype=F32, non_blocking=True), gather=t(gather, I32),
                        inverse=t(plan.merged_inverse, I32), cu_win=t(plan.cu_window, I32), cu_img=t(plan.cu_image, I32),
-                       max_win=plan.max_window, max_img=plan.max_image, cos=t(vcos, F32), sin=t(vsin, F32))
+                       max_win=plan.max_window, max_img=plan.max_image, cos=t(vcos, F32), sin=t(vsin, F32),
+                       img_src=None if img_src is None else t(img_src, I32), dup_idx=None if dup_idx is None else t(dup_idx, I32))
         return DeviceBatch(pk, t(pk.ids, I32), t(pk.embed_ids, I32), t(pk.cu_seqlens, I32), cos, sin, t(pk.image_rows, I32),
                            t(rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, vis)
 
@@ -430,6 +452,8 @@ class Qwen25VL:
         x = ops.embed_gather(self.p.w["embed"], b.ids)
         if b.vis is not None:
             img = self._vit_forward(b, save_vit)
+            if b.vis["img_src"] is not None:                                          # shared image: one feature row feeds several samples
+                img = ops.rows_gather(img, b.vis["img_src"])
             ops.rows_scatter_(x, b.image_rows, img)                                   # masked_scatter, HF :1209-1215
         if b.pk.T_pad > b.pk.T:
             x[b.pk.T:].zero_()
@@ -534,6 +558,8 @@ class Qwen25VL:
         ops.embed_grad_(g["embed"], b.embed_ids, dx)
         if b.vis is not None:
             d_img = ops.rows_gather(dx, b.image_rows)
+            if b.vis["dup_idx"] is not None:                                          # gradient of the shared features = sum over their users
+                d_img = ops.rows_gather_sum(d_img, b.vis["dup_idx"])
             self._vit_backward(b, vit_saved, d_img)
         return lp_full.view(b.pk.B, b.pk.R), metrics
 

@@ -368,6 +368,15 @@ def rows_scatter_(dst, rows_i32, src, add=False):
     return dst
 
 
+def rows_gather_sum(src, idx2d_i32, out=None):
+    """out[u] = sum_r src[idx2d[u, r]] (fp32 accumulate, fixed order; -1 entries skipped)."""
+    n_out, k = idx2d_i32.shape
+    H = src.shape[1]
+    o = torch.empty(n_out, H, dtype=BF16, device=src.device) if out is None else out
+    lib().st_rows_gather_sum(_p(src), src.stride(0), _p(idx2d_i32), k, _p(o), o.stride(0), n_out, H, _s())
+    return o
+
+
 def embed_grad_(dtable_f32, ids_i32, dx):
     lib().st_embed_grad(_p(dx), dx.stride(0), _p(ids_i32), _p(dtable_f32), dtable_f32.stride(0), ids_i32.numel(), dx.shape[1], _s())
 

@@ -137,3 +137,35 @@ def test_grpo_micro_batch_gradients_vs_oracle_autograd(env):
     vi, vip = cfg.v_intermediate, cfg.v_inter_pad
     assert float(store.g["v.0.gu_w"][vi:vip].abs().max()) == 0 and float(store.g["v.0.down_w"][:, vi:].abs().max()) == 0
     assert float(store.g["v.patch_embed"][:, cfg.patch_k:].abs().max()) == 0
+
+
+def test_shared_image_runs_the_vision_tower_once(env):
+    """Rollouts of one prompt share their image: staging with `image_map` runs the ViT once and sums the feature gradients;
+    log-probs are bit-identical to the per-sample path and the gradients agree up to bf16 summation order."""
+    z, cfg, params, store, eng, batch = env
+    R = batch["R"]
+    n0 = int(batch["patch_counts"][0])
+    ids = np.repeat(batch["input_ids"][:1], 3, 0); mask = np.repeat(batch["attention_mask"][:1], 3, 0)
+    pos = np.repeat(z["position_ids"][:1], 3, 0)
+    px0, g0 = batch["pixel_values"][:n0], batch["image_grid_thw"][:1]
+    rs = np.random.RandomState(3)
+    rmask = mask[:, -R:]
+    old = rs.standard_normal((3, R)).astype(np.float32) * 0.1 - 5.0
+    adv = rs.standard_normal((3, 1)).astype(np.float32).repeat(R, 1) * rmask
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    loss_in = dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64))
+    kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
+    out = []
+    for shared in (False, True):
+        if shared:
+            b = eng.stage(ids, mask, pos, R, px0, g0, image_map=[0, 0, 0])
+        else:
+            b = eng.stage(ids, mask, pos, R, np.concatenate([px0] * 3, 0), np.concatenate([g0] * 3, 0))
+        store.grad.zero_()
+        lp, _ = eng.forward_backward(b, loss_in, 1.0, **kw)
+        out.append((lp.clone(), store.grad.clone()))
+    assert torch.equal(out[0][0], out[1][0])
+    ga, gb = out[0][1], out[1][1]
+    rel = float((ga - gb).norm() / ga.norm())
+    assert rel < 5e-3, rel
+    store.grad.zero_()

@@ -239,13 +239,24 @@ def main():
             for k, v in zip(phase, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
                 phase[k] += v
             seqlens = mask_f.sum(1).tolist()
-            # the vision tower runs once per distinct image of a micro-batch (the G rollouts of a prompt share theirs): count
-            # only the ViT work actually done — ceil(mb / G) images per micro-batch
+            # FLOPs two ways: (i) as the reference's per-sequence packing would spend them (every rollout runs its own copy of the
+            # prompt and image: the "model FLOPs" of the workload), (ii) as actually executed here (prompt + image once per
+            # rollout group inside a micro-batch).  actor_mfu uses (ii): it is a hardware-utilisation number.
             n_patch = grid[0] * grid[1] * grid[2]
-            vit_passes = lambda mb: (B // mb) * max(1, -(-mb // G)) if B % mb == 0 else B
-            f_exp = cfg.flops_forward(seqlens, [n_patch] * vit_passes(hyper.micro_batch_size_per_device_for_experience), logit_rows=int(rmask.sum()))
-            f_upd = cfg.flops_forward(seqlens, [n_patch] * vit_passes(micro), logit_rows=int(rmask.sum()))
+            f_ref = cfg.flops_forward(seqlens, [n_patch] * B, logit_rows=int(rmask.sum()))
+            plen = mask[:, :].sum(1)                                         # valid prompt tokens per prompt
+            rlen = rmask.sum(1).tolist()
+
+            def executed(mb):
+                groups = []
+                for s0 in range(0, B, mb):
+                    rows = list(range(s0, min(B, s0 + mb)))
+                    for pr in sorted(set(r // G for r in rows)):
+                        groups.append((int(plen[pr]), [rlen[r] for r in rows if r // G == pr]))
+                return cfg.flops_forward_grouped(groups, [n_patch] * len(groups), logit_rows=int(rmask.sum()))
+            f_exp, f_upd = executed(hyper.micro_batch_size_per_device_for_experience), executed(micro)
             flops["old"] += f_exp; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
+            flops["reference_formulation"] = flops.get("reference_formulation", 0.0) + 5 * f_ref
             tokens_total[0] += int(mask_f.sum())
         return metrics
 
@@ -283,6 +294,7 @@ def main():
             "timing_s": {k: v / a.steps for k, v in phase.items()},
             "perf_throughput_tokens_per_s_per_gpu": tokens_total[0] / elapsed,
             "actor_mfu": (flops["old"] + flops["ref"] + flops["update"]) / actor_t / PEAK_BF16 if actor_t > 0 else None,
+            "actor_mfu_reference_flops": flops.get("reference_formulation", 0.0) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "roofline": {"bound": "mfma", "kernel": "st_gemm_nt family: gemm_tile_kernel<256,256> / gemm_nt_kernel<128,128> (bf16 MFMA 16x16x32, LDS-DMA staged)", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": gemm_flops / (gemm_ms * 1e-3) / PEAK_BF16 if gemm_ms > 0 else None, "traffic": None,

@@ -159,6 +159,22 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                 st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv,
                 float* delta, void* workspace, int64_t workspace_bytes, int max_seqlen, st_stream_t stream);
+/* Shared-prefix ("segment") attention of a packed GRPO micro-batch (D = 128, causal).  The G rollouts of a prompt are packed
+ * as [prompt][response_1]...[response_k]: segment s owns rows [seg_b[s], seg_e[s]); its queries see the prefix rows
+ * [pre_b[s], pre_e[s]) entirely (empty for prompts / stand-alone sequences) and then their own rows causally — the prompt is
+ * stored and computed ONCE per group where the reference runs it once per rollout (dp_actor.py:86-104 packs whole sequences).
+ * Backward: dep_e[s] >= seg_e[s], rows [seg_e[s], dep_e[s]) = the queries outside the segment that see all its keys (the
+ * group's response rows); T_valid = number of packed rows in use.  Same deterministic kernels and workspace as st_attn_bwd. */
+int st_attn_fwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e, int n_seg, int T,
+                    int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse, int max_seg,
+                    st_stream_t stream);
+int st_attn_bwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                    const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
+                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e,
+                    const int32_t* dep_e, int n_seg, int T, int T_valid, int n_q, int n_kv, int D, float scale,
+                    st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv, float* delta,
+                    void* workspace, int64_t workspace_bytes, int max_seg, st_stream_t stream);
 /* Attention over explicit row ranges (rollout decode; replaces vLLM paged attention,
  * verl/workers/rollout/vllm_rollout_spmd.py:141-143): sequence s has query rows [q_beg[s], q_end[s]) of q and key
  * rows [k_beg[s], k_end[s]) of k/v (device int32 arrays, read at run time so a captured hipGraph replays with

@@ -47,6 +47,10 @@ def _rows(x, sl):
     return x[sl] if x is not None else None
 
 
+def _to_np(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
 class PolicyEngine:
     """Holds one model replica (actor with optimizer, or frozen reference when hyper is None)."""
 
@@ -55,6 +59,7 @@ class PolicyEngine:
         self.model = Qwen25VL(cfg, store)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.share_prompts = True     # pack the prompt of a rollout group once (see _stage)
         self.opt_steps = 0            # t of AdamW (state["step"])
         self.sched_steps = 0          # lr_scheduler.step() calls so far: once per update_policy call (fsdp_workers.py:453)
         self._norm_buf = torch.zeros(1, dtype=F32, device=store.device) if hyper is not None else None
@@ -68,29 +73,33 @@ class PolicyEngine:
 
     # ------------------------------------------------------------------ micro-batch plumbing
     def _stage(self, data: Dict[str, Any], sl: slice):
-        mm = data.get("multi_modal_inputs")
-        px = gr = image_map = None
-        if mm is not None:
-            items = [it for it in mm[sl] if it is not None and "pixel_values" in it]
-            if items:                                            # dp_actor.py:78-83 concatenates over the samples
-                # The G rollouts of a prompt carry the SAME image object (DataProto.repeat / np.repeat keep references): the vision
-                # tower runs once per distinct image of the micro-batch and its features (and their gradient sum) are shared.
-                uniq, image_map = {}, []
-                for it in items:
-                    key = id(it["pixel_values"])
-                    if key not in uniq:
-                        uniq[key] = (len(uniq), it)
-                    image_map.append(uniq[key][0])
-                order = [it for _, it in sorted(uniq.values(), key=lambda kv: kv[0])]
-                px = torch.cat([torch.as_tensor(it["pixel_values"]) for it in order], 0)
-                gr = np.concatenate([np.asarray(it["image_grid_thw"]).reshape(-1, 3) for it in order], 0)
-                if any(len(np.asarray(it["image_grid_thw"]).reshape(-1, 3)) != 1 for it in order) or len(order) == len(items):
-                    if len(order) != len(items):                 # several images per sample: keep the plain per-sample path
-                        px = torch.cat([torch.as_tensor(it["pixel_values"]) for it in items], 0)
-                        gr = np.concatenate([np.asarray(it["image_grid_thw"]).reshape(-1, 3) for it in items], 0)
-                    image_map = None
+        """Stage one micro-batch.  Rows that are rollouts of the same prompt (identical prompt columns AND the same image
+        object — DataProto.repeat / np.repeat keep references) form a group: the prompt (and its image) is packed and computed
+        once per group (SURVEY 8a11's per-sequence packing computes it G times); single-member groups are plain sequences."""
+        ids, am = data["input_ids"][sl], data["attention_mask"][sl]
         R = data["responses"].shape[1]
-        return self.model.stage(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R, px, gr, image_map=image_map)
+        ids_np, am_np = _to_np(ids), _to_np(am)
+        n, Pc = ids_np.shape[0], ids_np.shape[1] - R
+        mm = data.get("multi_modal_inputs")
+        items = list(mm[sl]) if mm is not None else [None] * n
+        img_key = [id(it["pixel_values"]) if (it is not None and "pixel_values" in it) else None for it in items]
+        groups, keys = [], {}
+        for r in range(n):
+            key = (img_key[r], ids_np[r, :Pc].tobytes(), am_np[r, :Pc].tobytes()) if self.share_prompts else r
+            groups.append(keys.setdefault(key, len(keys)))
+        px = gr = None
+        multi = any(it is not None and "image_grid_thw" in it and len(np.asarray(it["image_grid_thw"]).reshape(-1, 3)) != 1 for it in items)
+        first = {}
+        for r, gid in enumerate(groups):
+            first.setdefault(gid, r)
+        lead = sorted(first.values())                           # pack_batch orders the groups by first appearance
+        owners = [r for r in (lead if not multi else range(n)) if items[r] is not None and "pixel_values" in items[r]]
+        if multi:                                               # several images per sample: no sharing, the per-sample path
+            groups = list(range(n))
+        if owners:                                              # dp_actor.py:78-83 concatenates over the samples
+            px = torch.cat([torch.as_tensor(items[r]["pixel_values"]) for r in owners], 0)
+            gr = np.concatenate([np.asarray(items[r]["image_grid_thw"]).reshape(-1, 3) for r in owners], 0)
+        return self.model.stage(ids, am, data["position_ids"][sl], R, px, gr, groups=groups)
 
     @torch.no_grad()
     def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None) -> torch.Tensor:

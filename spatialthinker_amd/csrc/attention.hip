@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
                                                             const int32_t* __restrict__ k_beg, const int32_t* __restrict__ k_end,
                                                             const int32_t* __restrict__ o_beg, int qgroup, int T, int n_q, int n_kv,
                                                             float scale_log2, uint16_t* __restrict__ out, int64_t ldo,
-                                                            float* __restrict__ lse) {
+                                                            float* __restrict__ lse, const int32_t* __restrict__ pre_beg,
+                                                            const int32_t* __restrict__ pre_end) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(1024))) char smem[2 * F2_STAGE];
     const int seq = blockIdx.z, h = blockIdx.y;
@@ -286,27 +287,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
 
+    // keys = an optional shared PREFIX range (rows [pre_beg, pre_end) of k/v: the prompt the G rollouts of a group have in common,
+    // fully visible) followed by the sequence's own range (causal).  Tiles 0..n_pre-1 walk the prefix, the rest the own keys.
+    const int pb = pre_beg ? pre_beg[seq] : 0, Lp = pre_beg ? pre_end[seq] - pb : 0;
+    const int n_pre = (Lp + KV_TILE - 1) / KV_TILE;
     const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
-    const int n_tiles = (kv_end + KV_TILE - 1) / KV_TILE;
-    const uint16_t* kbase = k + (int64_t)sk * ldk + kvh * D;
-    const uint16_t* vbase = v + (int64_t)sk * ldv + kvh * D;
+    const int n_tiles = n_pre + (kv_end + KV_TILE - 1) / KV_TILE;
+    const uint16_t* kbase = k + kvh * D;
+    const uint16_t* vbase = v + kvh * D;
 
     auto stage = [&](int t, char* dst) {
-        const int kt0 = t * KV_TILE;
+        const bool pre = t < n_pre;
+        const int kt0 = (pre ? t : t - n_pre) * KV_TILE, row0 = pre ? pb : sk, Lc = pre ? Lp : L;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                       // K: instruction = 4 rows x 16 chunks
             const int inst = wave * 4 + j;
             const int row = inst * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
-            int key = kt0 + row; key = key < L ? key : L - 1;
-            st_glds16(kbase + (int64_t)key * ldk + c * 8, dst + inst * 1024);
+            int key = kt0 + row; key = key < Lc ? key : Lc - 1;
+            st_glds16(kbase + (int64_t)(row0 + key) * ldk + c * 8, dst + inst * 1024);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                       // V: instruction = 2 sub-tiles of [8 keys][32 d]
             const int inst = wave * 4 + j;
             const int u = 2 * inst + (lane >> 5), slot = lane & 31;
-            int key = kt0 + (u >> 2) * 8 + (slot >> 2); key = key < L ? key : L - 1;
-            st_glds16(vbase + (int64_t)key * ldv + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
+            int key = kt0 + (u >> 2) * 8 + (slot >> 2); key = key < Lc ? key : Lc - 1;
+            st_glds16(vbase + (int64_t)(row0 + key) * ldv + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
         }
     };
     if (n_tiles > 0) stage(0, smem);
@@ -317,12 +323,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
 
     for (int t = 0; t < n_tiles; ++t) {
-        const int kt0 = t * KV_TILE;
+        const bool pre = t < n_pre;
+        const int kt0 = (pre ? t : t - n_pre) * KV_TILE, Lc = pre ? Lp : L;
+        const bool causal_t = CAUSAL && !pre;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < n_tiles) stage(t + 1, smem + ((t + 1) & 1) * F2_STAGE);
-        if (CAUSAL && kt0 > q_base + wave * 32 + 31) continue;          // tile entirely above this wave's diagonal
+        if (causal_t && kt0 > q_base + wave * 32 + 31) continue;        // tile entirely above this wave's diagonal
         const char* ks = smem + (t & 1) * F2_STAGE;
         const uint32_t vaddr = smem_lds + (t & 1) * F2_STAGE + F2_V_OFF + v_lane_off;
         uint2 va[8], vb[8];
@@ -341,13 +349,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
             }
         }
         // mask only where the tile meets the diagonal or the end of the keys (wave-uniform test)
-        if ((kt0 + KV_TILE > L) || (CAUSAL && kt0 + KV_TILE - 1 > q_base + wave * 32)) {
+        if ((kt0 + KV_TILE > Lc) || (causal_t && kt0 + KV_TILE - 1 > q_base + wave * 32)) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const bool ok = (key < L) && (!CAUSAL || key <= q_idx);
+                    const bool ok = (key < Lc) && (!causal_t || key <= q_idx);
                     sacc[kb][r] = ok ? sacc[kb][r] : -INFINITY;
                 }
         }
@@ -773,12 +781,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
                                                                const uint16_t* __restrict__ dout, int64_t lddo,
                                                                const uint16_t* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
-                                                               const int32_t* __restrict__ cu, int T, int n_q, int n_kv,
+                                                               const int32_t* __restrict__ seg_b, const int32_t* __restrict__ seg_e,
+                                                               const int32_t* __restrict__ pre_b, const int32_t* __restrict__ pre_e,
+                                                               int T, int n_q, int n_kv,
                                                                float scale, uint16_t* __restrict__ dq, int64_t lddq) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(1024))) char smem[2 * B2_KV_STAGE];
     const int seq = blockIdx.z, h = blockIdx.y;
-    const int s0 = cu[seq], L = cu[seq + 1] - s0;
+    const int s0 = seg_b[seq], L = seg_e[seq] - s0;
     const int q_base = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * Q_TILE;
     if (q_base >= L) return;
     const int kvh = h / (n_q / n_kv);
@@ -819,13 +829,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
+    // keys: shared prefix rows [pre_b, pre_e) (fully visible) then the own rows (causal) — see attn_fwd128_kernel
+    const int pb = pre_b ? pre_b[seq] : 0, Lp = pre_b ? pre_e[seq] - pb : 0;
+    const int n_pre = (Lp + KV_TILE - 1) / KV_TILE;
     const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
-    const int n_tiles = (kv_end + KV_TILE - 1) / KV_TILE;
-    const uint16_t* kbase = k + (int64_t)s0 * ldk + kvh * D;
-    const uint16_t* vbase = v + (int64_t)s0 * ldv + kvh * D;
+    const int n_tiles = n_pre + (kv_end + KV_TILE - 1) / KV_TILE;
     auto stage = [&](int t, char* dst) {
-        stage_dual<KV_TILE>(kbase, ldk, t * KV_TILE, L, dst, wave, lane);
-        stage_dual<KV_TILE>(vbase, ldv, t * KV_TILE, L, dst + 16384, wave, lane);
+        const bool pre = t < n_pre;
+        const int kt0 = (pre ? t : t - n_pre) * KV_TILE, row0 = pre ? pb : s0, Lc = pre ? Lp : L;
+        stage_dual<KV_TILE>(k + (int64_t)row0 * ldk + kvh * D, ldk, kt0, Lc, dst, wave, lane);
+        stage_dual<KV_TILE>(v + (int64_t)row0 * ldv + kvh * D, ldv, kt0, Lc, dst + 16384, wave, lane);
     };
     if (n_tiles > 0) stage(0, smem);
 
@@ -835,16 +848,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
 
     for (int t = 0; t < n_tiles; ++t) {
-        const int kt0 = t * KV_TILE;
+        const bool pre = t < n_pre;
+        const int kt0 = (pre ? t : t - n_pre) * KV_TILE, Lc = pre ? Lp : L;
+        const bool causal_t = CAUSAL && !pre;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < n_tiles) stage(t + 1, smem + ((t + 1) & 1) * B2_KV_STAGE);
-        if (CAUSAL && kt0 > q_base + wave * 32 + 31) continue;
+        if (causal_t && kt0 > q_base + wave * 32 + 31) continue;
         const char* ks = smem + (t & 1) * B2_KV_STAGE;
         const char* vs = ks + 16384;
         const uint32_t kaddr = smem_lds + (t & 1) * B2_KV_STAGE;
-        const bool need_mask = (kt0 + KV_TILE > L) || (CAUSAL && kt0 + KV_TILE - 1 > q_base + wave * 32);
+        const bool need_mask = (kt0 + KV_TILE > Lc) || (causal_t && kt0 + KV_TILE - 1 > q_base + wave * 32);
 
         uint2 ta[8], tb[8];
         tr_issue8_dual<0>(ta, tro, kaddr);                               // K^T of keys 0..15
@@ -867,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
                 float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -lse2));
                 if (need_mask) {
                     const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    p = ((key < L) && (!CAUSAL || key <= q_idx)) ? p : 0.f;
+                    p = ((key < Lc) && (!causal_t || key <= q_idx)) ? p : 0.f;
                 }
                 sacc[r] = p * (pacc[r] - dlt) * scale;                                         // dS^T
             }
@@ -925,21 +940,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
                                                                const uint16_t* __restrict__ v, int64_t ldv,
                                                                const uint16_t* __restrict__ dout, int64_t lddo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               const int32_t* __restrict__ cu, int T, int n_q, int n_kv,
+                                                               const int32_t* __restrict__ seg_b, const int32_t* __restrict__ seg_e,
+                                                               const int32_t* __restrict__ dep_e, int T, int n_q, int n_kv,
                                                                float scale, uint16_t* __restrict__ part) {
     constexpr int D = 128;
     constexpr int IMG = QR * 256, SLOT = 2 * IMG + 1024;
     constexpr int PER = 2 * (QR / 16), EXTRA = QR / 32;      // LDS-DMA instructions per wave per slot (+ wave 0: lse/delta)
     __shared__ __attribute__((aligned(1024))) char smem[NST * SLOT];
     const int seq = blockIdx.z, hq = blockIdx.y;
-    const int s0 = cu[seq], L = cu[seq + 1] - s0;
+    // keys = rows [seg_b, seg_e) (Lk of them); queries that see them = the own rows (causal) followed, for a shared prefix
+    // segment, by its dependents [seg_e, dep_e): every response row of the group, all of which see every prefix key.
+    const int s0 = seg_b[seq], Lk = seg_e[seq] - s0;
+    const int L = (dep_e ? dep_e[seq] : seg_e[seq]) - s0;          // length of the query stream
     const int k_base = blockIdx.x * 128;
-    if (k_base >= L) return;
+    if (k_base >= Lk) return;
     const int kvh = hq / (n_q / n_kv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kc = lane & 31, half = lane >> 5;
     const int key_idx = k_base + wave * 32 + kc;
-    const bool k_ok = key_idx < L;
+    const bool k_ok = key_idx < Lk;
     const float scale_log2 = scale * LOG2E;
 
     bf16x8 kf[8], vf[MODE == 0 ? 8 : 1];      // MFMA B operands: n = key, k = 8 contiguous d
@@ -1029,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
                     pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, vf[s], pacc, 0, 0, 0);      // dP = dO V^T
                 }
             }
-            const bool need_mask = (qt0 + 32 > L) || (k_base + wave * 32 + 32 > L) || (CAUSAL && qt0 < k_base + wave * 32 + 31);
+            const bool need_mask = (qt0 + 32 > L) || (k_base + wave * 32 + 32 > Lk) || (CAUSAL && qt0 < k_base + wave * 32 + 31);
             uint32_t pk[8];                                    // packed bf16 P (dV) or dS (dK), rows 2i, 2i+1
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1043,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
                     float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -l4[j] * LOG2E));
                     if (need_mask) {
                         const int qi = qt0 + 8 * g + 4 * half + j;
-                        p = (k_ok && (qi < L) && (!CAUSAL || key_idx <= qi)) ? p : 0.f;
+                        p = (k_ok && (qi < L) && (!CAUSAL || qi >= Lk || key_idx <= qi)) ? p : 0.f;
                     }
                     x[j] = MODE == 0 ? p * (pacc[r] - d4[j]) * scale : p;
                 }
@@ -1081,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
 
 // dk[t][kvh*128 + d] = sum over the group's query heads of the bf16 partials (fp32 accumulate, fixed order); same for dv.
 __global__ void attn_bwd128_reduce_kernel(const uint16_t* __restrict__ pk, const uint16_t* __restrict__ pv,
-                                          const int32_t* __restrict__ t_end, int T, int n_kv, int group, uint16_t* __restrict__ dk, int64_t lddk, uint16_t* __restrict__ dv,
+                                          const int32_t* __restrict__ t_end_ptr, int t_end_val, int T, int n_kv, int group, uint16_t* __restrict__ dk, int64_t lddk, uint16_t* __restrict__ dv,
                                           int64_t lddv) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte chunk of one (tensor, kv head, token)
     const int64_t per = (int64_t)n_kv * T * 16;
@@ -1090,7 +1109,7 @@ __global__ void attn_bwd128_reduce_kernel(const uint16_t* __restrict__ pk, const
     const int64_t i = is_v ? idx - per : idx;
     const int c = (int)(i & 15);
     const int64_t t = (i >> 4) % T;
-    if (t >= *t_end) return;                               // rows after the last sequence (padding) hold no partials: left untouched
+    if (t >= (t_end_ptr ? *t_end_ptr : t_end_val)) return; // rows after the last sequence (padding) hold no partials: left untouched
     const int kvh = (int)((i >> 4) / T);
     const uint16_t* src = (is_v ? pv : pk) + (((int64_t)kvh * group) * T + t) * 128 + c * 8;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1112,7 +1131,9 @@ extern "C" {
 static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                            const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
                            const int32_t* o_beg, int qgroup, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
-                           st_bf16* out, int64_t ldo, float* lse, int max_q, int klass, st_stream_t stream) {
+                           st_bf16* out, int64_t ldo, float* lse, int max_q, int klass, st_stream_t stream,
+                           const int32_t* pre_beg = nullptr, const int32_t* pre_end = nullptr) {
+    if (pre_beg && D != 128) return ST_EINVAL;             // shared-prefix ranges exist for the LM head dim only
     if (!q || !k || !v || !q_beg || !q_end || !k_beg || !k_end || !out || !lse || n_seq <= 0 || T <= 0 || n_q <= 0 || n_kv <= 0 ||
         (n_q % n_kv) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || max_q <= 0)
         return ST_EINVAL;
@@ -1121,11 +1142,8 @@ static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int6
     const float sl2 = scale * LOG2E;
     StProfScope ps(klass, s, 0.0);
 #define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
-    static const bool old128 = getenv("ST_ATTN_OLD") != nullptr;       // development A/B switch
-#define ST_FWD2(CC) hipLaunchKernelGGL((attn_fwd128_kernel<CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
-    if (D == 128 && !old128) { if (causal) ST_FWD2(true); else ST_FWD2(false); }
-    else if (D == 128 && causal) ST_FWD(128, true);
-    else if (D == 128) ST_FWD(128, false);
+#define ST_FWD2(CC) hipLaunchKernelGGL((attn_fwd128_kernel<CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse, pre_beg, pre_end)
+    if (D == 128) { if (causal) ST_FWD2(true); else ST_FWD2(false); }
     else if (D == 80 && !causal) ST_FWD(80, false);
     else if (D == 80) ST_FWD(80, true);
     else return ST_EINVAL;
@@ -1154,6 +1172,32 @@ int64_t st_attn_bwd_workspace_bytes(int T, int n_q, int D) {
     return D == 128 ? (int64_t)2 * n_q * T * 128 * (int64_t)sizeof(uint16_t) : 0;
 }
 
+// D = 128 backward over segments: dQ (+ delta), per-head dK and dV partials, group reduce
+static int attn_bwd128_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                              const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
+                              const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e,
+                              const int32_t* dep_e, const int32_t* t_end_ptr, int t_end_val, int n_seg, int T, int n_q, int n_kv,
+                              float scale, int causal, st_bf16* dq, int64_t lddq, st_bf16* dk, int64_t lddk, st_bf16* dv, int64_t lddv,
+                              float* delta, void* workspace, int64_t workspace_bytes, int max_seg, hipStream_t s) {
+    if (!workspace || workspace_bytes < st_attn_bwd_workspace_bytes(T, n_q, 128)) return ST_EINVAL;
+    uint16_t* part_k = (uint16_t*)workspace;
+    uint16_t* part_v = part_k + (int64_t)n_q * T * 128;
+    const dim3 gq(st_cdiv(max_seg, Q_TILE), n_q, n_seg), gkv(st_cdiv(max_seg, 128), n_q, n_seg);
+#define ST_BWD2(CC)                                                                                                            \
+    hipLaunchKernelGGL((attn_bwd128_dq_kernel<CC>), gq, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, out, ldo, lse,     \
+                       delta, seg_b, seg_e, pre_b, pre_e, T, n_q, n_kv, scale, dq, lddq);                                      \
+    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 0, 64, 2>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse,    \
+                       delta, seg_b, seg_e, dep_e, T, n_q, n_kv, scale, part_k);                                               \
+    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 1, 64, 2>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse,    \
+                       delta, seg_b, seg_e, dep_e, T, n_q, n_kv, scale, part_v);                                               \
+    hipLaunchKernelGGL(attn_bwd128_reduce_kernel, dim3(st_cdiv((int64_t)2 * n_kv * T * 16, 256)), dim3(256), 0, s, part_k,     \
+                       part_v, t_end_ptr, t_end_val, T, n_kv, n_q / n_kv, dk, lddk, dv, lddv)
+    if (causal) { ST_BWD2(true); } else { ST_BWD2(false); }
+#undef ST_BWD2
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
 int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                 const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
@@ -1165,41 +1209,50 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     StProfScope ps(D == 128 ? ST_K_ATTN_BWD : ST_K_VIT_ATTN, s, 0.0);
+    if (D == 128)
+        return attn_bwd128_launch(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, cu_seqlens, cu_seqlens + 1, nullptr, nullptr, nullptr,
+                                  cu_seqlens + n_seq, 0, n_seq, T, n_q, n_kv, scale, causal, dq, lddq, dk, lddk, dv, lddv, delta, workspace,
+                                  workspace_bytes, max_seqlen, s);
     const dim3 gq(st_cdiv(max_seqlen, Q_TILE), n_q, n_seq), gk(st_cdiv(max_seqlen, 128), n_kv, n_seq);
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(st_cdiv((int64_t)T * n_q, 256)), dim3(256), 0, s, out, ldo, dout, lddo, T, n_q, D, delta);
 #define ST_BWD(DD, CC)                                                                                                         \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, CC>), gq, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,       \
                        cu_seqlens, T, n_q, n_kv, scale, dq, lddq);                                                             \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, CC>), gk, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,      \
                        cu_seqlens, T, n_q, n_kv, scale, dk, lddk, dv, lddv)
-    static const bool old128 = getenv("ST_ATTN_OLD") != nullptr;       // development A/B switch
-    if (D != 128 || old128)
-        hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(st_cdiv((int64_t)T * n_q, 256)), dim3(256), 0, s, out, ldo, dout, lddo, T, n_q, D, delta);
-    const int64_t ws_need = st_attn_bwd_workspace_bytes(T, n_q, D);
-    if (D == 128 && !old128 && (!workspace || workspace_bytes < ws_need)) return ST_EINVAL;
-    uint16_t* part_k = (uint16_t*)workspace;
-    uint16_t* part_v = part_k + (int64_t)n_q * T * 128;
-    const dim3 gkv(st_cdiv(max_seqlen, 128), n_q, n_seq);
-#define ST_BWD2(CC, KVQ, KVS)                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd128_dq_kernel<CC>), gq, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, out, ldo, lse,     \
-                       delta, cu_seqlens, T, n_q, n_kv, scale, dq, lddq);                                                      \
-    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 0, KVQ, KVS>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,    \
-                       cu_seqlens, T, n_q, n_kv, scale, part_k);                                                               \
-    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 1, KVQ, KVS>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse, delta,    \
-                       cu_seqlens, T, n_q, n_kv, scale, part_v);                                                               \
-    hipLaunchKernelGGL(attn_bwd128_reduce_kernel, dim3(st_cdiv((int64_t)2 * n_kv * T * 16, 256)), dim3(256), 0, s, part_k,     \
-                       part_v, cu_seqlens + n_seq, T, n_kv, n_q / n_kv, dk, lddk, dv, lddv)
-    static const int kv_cfg = getenv("ST_ATTN_KV_CFG") ? atoi(getenv("ST_ATTN_KV_CFG")) : 1;    // development switch
-    if (D == 128 && !old128) {
-        if (kv_cfg == 0) { if (causal) { ST_BWD2(true, 32, 3); } else { ST_BWD2(false, 32, 3); } }
-        else { if (causal) { ST_BWD2(true, 64, 2); } else { ST_BWD2(false, 64, 2); } }
-    }
-    else if (D == 128 && causal) { ST_BWD(128, true); }
-    else if (D == 128) { ST_BWD(128, false); }
-    else if (causal) { ST_BWD(80, true); }
-    else { ST_BWD(80, false); }
+    if (causal) { ST_BWD(80, true); } else { ST_BWD(80, false); }
 #undef ST_BWD
     ST_CHECK_LAUNCH();
     return 0;
+}
+
+/* ---- shared-prefix ("segment") attention of the packed GRPO micro-batch, D = 128 -------------------------------------------
+ * Segment s owns rows [seg_b[s], seg_e[s]) of q/k/v.  Its queries see the prefix rows [pre_b[s], pre_e[s]) entirely (the prompt
+ * that the rollouts of one group share; empty range for a prompt or a stand-alone sequence) and then their own rows causally.
+ * Backward additionally needs dep_e[s] >= seg_e[s]: rows [seg_e[s], dep_e[s]) are the queries OUTSIDE the segment that see all of
+ * its keys (the group's response rows, packed right behind their prompt); dep_e[s] == seg_e[s] for segments nobody depends on. */
+int st_attn_fwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e, int n_seg, int T, int n_q,
+                    int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse, int max_seg, st_stream_t stream) {
+    if (D != 128 || !pre_b || !pre_e) return ST_EINVAL;
+    return attn_fwd_launch(q, ldq, k, ldk, v, ldv, seg_b, seg_e, seg_b, seg_e, nullptr, 0, n_seg, T, n_q, n_kv, D, scale, 1, out, ldo, lse,
+                           max_seg, ST_K_ATTN_FWD, stream, pre_b, pre_e);
+}
+
+int st_attn_bwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                    const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,
+                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e, const int32_t* dep_e,
+                    int n_seg, int T, int T_valid, int n_q, int n_kv, int D, float scale, st_bf16* dq, int64_t lddq, st_bf16* dk,
+                    int64_t lddk, st_bf16* dv, int64_t lddv, float* delta, void* workspace, int64_t workspace_bytes, int max_seg,
+                    st_stream_t stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !seg_b || !seg_e || !pre_b || !pre_e || !dep_e || !dq || !dk || !dv || !delta ||
+        n_seg <= 0 || T <= 0 || T_valid < 0 || T_valid > T || n_q <= 0 || n_kv <= 0 || (n_q % n_kv) || (ldq & 7) || (ldk & 7) ||
+        (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || max_seg <= 0 || D != 128)
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_ATTN_BWD, s, 0.0);
+    return attn_bwd128_launch(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, seg_b, seg_e, pre_b, pre_e, dep_e, nullptr, T_valid, n_seg,
+                              T, n_q, n_kv, scale, 1, dq, lddq, dk, lddk, dv, lddv, delta, workspace, workspace_bytes, max_seg, s);
 }
 
 }  // extern "C"

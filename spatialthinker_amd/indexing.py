@@ -142,45 +142,116 @@ class PackedBatch:
     out_index: np.ndarray           # (Tr,) int64 flat index into (B, R) where each log-prob lands
     B: int
     R: int
+    # segment view of the packed stream for the shared-prefix attention (st_attn_fwd_seg / st_attn_bwd_seg)
+    seg_b: np.ndarray = None         # (n_seg,) int32 own rows [seg_b, seg_e)
+    seg_e: np.ndarray = None
+    pre_b: np.ndarray = None         # prefix rows every query of the segment sees (the shared prompt), empty when pre_b == pre_e
+    pre_e: np.ndarray = None
+    dep_e: np.ndarray = None         # rows [seg_e, dep_e) are queries outside the segment that see all of its keys
+    max_seg: int = 0
+    logit_dup: Optional[np.ndarray] = None     # (n_distinct, kmax) int32: positions in logit_rows sharing one packed row, -1 padded
+    logit_distinct: Optional[np.ndarray] = None  # (n_distinct,) int32 the distinct packed rows
 
 
 def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: np.ndarray, response_length: int, *,
-               image_token_id: int, pad_multiple: int = 128) -> PackedBatch:
+               image_token_id: int, pad_multiple: int = 128, groups: Optional[Sequence[int]] = None) -> PackedBatch:
     """The padding-free transformation of verl/workers/actor/dp_actor.py:86-104,136-139 done once on
     the host: valid tokens are concatenated; log-probs are only needed at [:, -R-1:-1] of every row,
-    and only where the response mask is set, so the lm_head runs on exactly those rows."""
+    and only where the response mask is set, so the lm_head runs on exactly those rows.
+
+    groups (optional, one id per row): rows with the same id are rollouts of ONE prompt (identical prompt columns — verified
+    here).  Such a group is packed as [prompt][response_1]...[response_k] with the prompt stored once; the segment arrays tell
+    the attention which rows each query sees.  Every other row-wise op (norms, projections, MLP) then simply runs on ~half the
+    tokens.  Without groups every row is its own stand-alone sequence (one segment, the reference's layout)."""
     ids = np.asarray(input_ids)
     mask = np.asarray(attention_mask).astype(bool)
     B, S = ids.shape
     R = response_length
+    Pc = S - R                                           # prompt columns
     pos = np.asarray(position_ids)
     if pos.ndim == 2:                                   # text-only (B, S) -> replicate on the 3 rows
         pos = np.repeat(pos[:, None, :], 3, axis=1)
-    lens = mask.sum(1)
-    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    T = int(cu[-1])
+    # ---- group structure: members (row lists) in order of first appearance; only rows with identical prompts may share
+    if groups is None:
+        members = [[b] for b in range(B)]
+    else:
+        by_id = {}
+        for b, gid in enumerate(groups):
+            by_id.setdefault(gid, []).append(b)
+        members = []
+        for rows in by_id.values():
+            r0 = rows[0]
+            same = [r for r in rows if np.array_equal(ids[r, :Pc], ids[r0, :Pc]) and np.array_equal(mask[r, :Pc], mask[r0, :Pc])
+                    and np.array_equal(pos[r, :, :Pc], pos[r0, :, :Pc])]
+            members.append(same)
+            members.extend([r] for r in rows if r not in same)       # a row that does not really share the prompt stands alone
+        members.sort(key=lambda m: m[0])
+    packed_row = -np.ones((B, S), dtype=np.int64)
+    p_ids_l, p_pos_l = [], []
+    seg = []                                            # (b, e, pre_b, pre_e, dep_e)
+    lens_full = mask.sum(1)
+    cur = 0
+    for rows in members:
+        r0 = rows[0]
+        pcols = np.nonzero(mask[r0, :Pc])[0]
+        P = len(pcols)
+        shared = len(rows) > 1 and P > 0
+        g_start = cur
+        p_ids_l.append(ids[r0, pcols]); p_pos_l.append(pos[r0][:, pcols])
+        for r in rows:
+            packed_row[r, pcols] = cur + np.arange(P)
+        cur += P
+        resp_ranges = []
+        for r in rows:
+            rcols = Pc + np.nonzero(mask[r, Pc:])[0]
+            n = len(rcols)
+            p_ids_l.append(ids[r, rcols]); p_pos_l.append(pos[r][:, rcols])
+            packed_row[r, rcols] = cur + np.arange(n)
+            resp_ranges.append((cur, cur + n))
+            cur += n
+        if shared:
+            seg.append((g_start, g_start + P, 0, 0, cur))
+            for b_, e_ in resp_ranges:
+                if e_ > b_:
+                    seg.append((b_, e_, g_start, g_start + P, e_))
+        elif cur > g_start:                              # stand-alone sequence: one causal segment over prompt + response
+            seg.append((g_start, cur, 0, 0, cur))
+    T = cur
     T_pad = max(round_up(T, pad_multiple), pad_multiple)
-    flat = np.nonzero(mask.reshape(-1))[0]
     p_ids = np.zeros(T_pad, dtype=np.int32)
-    p_ids[:T] = ids.reshape(-1)[flat]
     p_pos = np.zeros((3, T_pad), dtype=np.int32)
-    p_pos[:, :T] = pos.transpose(1, 0, 2).reshape(3, -1)[:, flat]
-    packed_row = -np.ones(B * S, dtype=np.int64)
-    packed_row[flat] = np.arange(T)
-    packed_row = packed_row.reshape(B, S)
+    if T:
+        p_ids[:T] = np.concatenate(p_ids_l)
+        p_pos[:, :T] = np.concatenate(p_pos_l, axis=1)
+    # per-row cumulative lengths keep their historical meaning (full sequence lengths): metrics / FLOP counters use them
+    cu = np.concatenate([[0], np.cumsum(lens_full)]).astype(np.int32)
     # response slot j of row b sits at column S-R+j; its log-prob comes from the logits of column S-R+j-1
-    cols = np.arange(S - R, S)
+    cols = np.arange(Pc, S)
     valid = mask[:, cols] & mask[:, cols - 1]
     bb, jj = np.nonzero(valid)
     logit_rows = packed_row[bb, cols[jj] - 1]
     labels = ids[bb, cols[jj]].astype(np.int64)
     # image placeholders live in the prompt part only; a sampled response token that happens to equal the placeholder id is
     # ordinary text (HF's masked_scatter would raise on such a row; random-weight synthetic models do sample it)
-    in_prompt = np.zeros((B, S), dtype=bool)
-    in_prompt[:, :S - R] = True
-    img_rows = np.nonzero((p_ids[:T] == image_token_id) & in_prompt.reshape(-1)[flat])[0].astype(np.int32)
+    is_prompt_row = np.zeros(T_pad, dtype=bool)
+    prow = packed_row[:, :Pc]
+    is_prompt_row[prow[prow >= 0]] = True
+    img_rows = np.nonzero((p_ids[:T] == image_token_id) & is_prompt_row[:T])[0].astype(np.int32)
     embed_ids = p_ids.copy()
     embed_ids[img_rows] = -1
     embed_ids[T:] = -1
-    return PackedBatch(T, T_pad, p_ids, p_pos, cu, int(lens.max()) if B else 0, img_rows, embed_ids,
-                       logit_rows.astype(np.int32), labels, (bb * R + jj).astype(np.int64), B, R)
+    sa = np.asarray(seg, dtype=np.int32).reshape(-1, 5)
+    # duplicates in logit_rows: the last prompt row of a group predicts the first response token of every member
+    dup = distinct = None
+    if len(logit_rows) and len(np.unique(logit_rows)) != len(logit_rows):
+        distinct, inv = np.unique(logit_rows, return_inverse=True)
+        counts = np.bincount(inv)
+        dup = -np.ones((len(distinct), int(counts.max())), dtype=np.int32)
+        fill = np.zeros(len(distinct), dtype=np.int64)
+        for i_, u in enumerate(inv):
+            dup[u, fill[u]] = i_; fill[u] += 1
+        distinct = distinct.astype(np.int32)
+    return PackedBatch(T, T_pad, p_ids, p_pos, cu, int((sa[:, 1] - sa[:, 0]).max()) if len(sa) else 0, img_rows, embed_ids,
+                       logit_rows.astype(np.int32), labels, (bb * R + jj).astype(np.int64), B, R,
+                       seg_b=sa[:, 0].copy(), seg_e=sa[:, 1].copy(), pre_b=sa[:, 2].copy(), pre_e=sa[:, 3].copy(), dep_e=sa[:, 4].copy(),
+                       max_seg=int((sa[:, 1] - sa[:, 0]).max()) if len(sa) else 0, logit_dup=dup, logit_distinct=distinct)

@@ -128,6 +128,19 @@ class VLConfig:
         return float(fl)
 
 
+    def flops_forward_grouped(self, groups: List[Tuple[int, List[int]]], patches_per_image: List[int], logit_rows: int) -> float:
+        """Forward FLOPs actually executed with shared-prompt packing: groups = [(prompt_len, [response_len, ...]), ...] — the
+        prompt is computed once per group; a response row attends to the whole prompt plus its own causal part."""
+        H, I, D = self.hidden_size, self.intermediate_size, self.head_dim
+        T = sum(P + sum(rs) for P, rs in groups)
+        fl = 2 * (H * self.qkv_width + H * H + 3 * H * I) * T * self.num_layers
+        att = sum(P * P + sum(2 * r * P + r * r for r in rs) for P, rs in groups)          # (query, key) pairs x 2, causal halves
+        fl += 2 * D * self.num_heads * att * self.num_layers
+        fl += 2 * H * self.vocab_size * logit_rows
+        return float(fl) + self.flops_forward([], patches_per_image, logit_rows=0)
+
+
+
 # ------------------------------------------------------------------------------------------
 def param_layout(c: VLConfig) -> "Dict[str, Tuple[int, ...]]":
     """name -> shape of the engine's own (fused / padded) parameter tensors, in flat-buffer order."""
@@ -309,6 +322,9 @@ class DeviceBatch:
     out_index: torch.Tensor
     Tr_pad: int
     vis: Optional[dict] = None
+    seg: Optional[tuple] = None          # (seg_b, seg_e, pre_b, pre_e, dep_e) int32 device arrays (shared-prefix attention)
+    logit_dup: Optional[torch.Tensor] = None
+    logit_distinct: Optional[torch.Tensor] = None
 
 
 class Qwen25VL:
@@ -321,11 +337,12 @@ class Qwen25VL:
 
     # ---------------------------------------------------------------- batch staging
     def stage(self, input_ids, attention_mask, position_ids, response_length: int, pixel_values=None, image_grid_thw=None,
-              image_map=None) -> DeviceBatch:
+              image_map=None, groups=None) -> DeviceBatch:
         """image_map (optional): pixel_values / image_grid_thw hold each DISTINCT image once and image_map[j] names the image of the
         j-th image-bearing sample (one image per sample); the features are gathered per sample and their gradients summed."""
         c, dev = self.cfg, self.p.device
-        pk = ix.pack_batch(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, image_token_id=c.image_token_id)
+        pk = ix.pack_batch(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, image_token_id=c.image_token_id,
+                           groups=groups)
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
         pos = t(pk.pos, I32)
         cos, sin = ops.mrope_table(pos, self.inv_freq, c.head_dim, c.mrope_section)
@@ -364,8 +381,11 @@ class Qwen25VL:
                        inverse=t(plan.merged_inverse, I32), cu_win=t(plan.cu_window, I32), cu_img=t(plan.cu_image, I32),
                        max_win=plan.max_window, max_img=plan.max_image, cos=t(vcos, F32), sin=t(vsin, F32),
                        img_src=None if img_src is None else t(img_src, I32), dup_idx=None if dup_idx is None else t(dup_idx, I32))
+        seg = tuple(t(a, I32) for a in (pk.seg_b, pk.seg_e, pk.pre_b, pk.pre_e, pk.dep_e))
         return DeviceBatch(pk, t(pk.ids, I32), t(pk.embed_ids, I32), t(pk.cu_seqlens, I32), cos, sin, t(pk.image_rows, I32),
-                           t(rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, vis)
+                           t(rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, vis, seg,
+                           None if pk.logit_dup is None else t(pk.logit_dup, I32),
+                           None if pk.logit_distinct is None else t(pk.logit_distinct, I32))
 
     # ---------------------------------------------------------------- vision tower
     def _vit_forward(self, b: DeviceBatch, save: Optional[list]):
@@ -471,7 +491,7 @@ class Qwen25VL:
         if kv_out is not None:
             kv_out(i, k, v)
         a = torch.zeros(x0.shape[0], nq * D, dtype=BF16, device=x0.device)
-        _, lse = ops.attn_fwd(q, k, v, b.cu, b.pk.max_seqlen, nq, nkv, D, self.scale, True, out=a)
+        _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a)
         x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x0)
         h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
         gu = ops.gemm_nt(h2, w[p + "gu_w"])
@@ -496,8 +516,8 @@ class Qwen25VL:
         da = ops.gemm_nt(dx1, wT[p + "o_w"])
         dqkv = torch.zeros_like(qkv)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
-        ops.attn_bwd(q, k, v, a, da, lse, b.cu, b.pk.max_seqlen, nq, nkv, D, self.scale, True,
-                     dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:])
+        ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
+                         self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:])
         ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
         self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
         dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
@@ -552,7 +572,10 @@ class Qwen25VL:
         dhn = ops.gemm_nt(logits, wT[head_name])
         dxr = ops.rmsnorm_bwd(xr, self.p.w["final_norm"], rn, dhn, dw_accum=g["final_norm"])
         dx = torch.zeros_like(x)
-        ops.rows_scatter_(dx, b.logit_rows[:Tr], dxr[:Tr])
+        if b.logit_dup is not None:                         # the last prompt row of a group predicts every member's first token
+            ops.rows_scatter_(dx, b.logit_distinct, ops.rows_gather_sum(dxr, b.logit_dup))
+        else:
+            ops.rows_scatter_(dx, b.logit_rows[:Tr], dxr[:Tr])
         for i in reversed(range(c.num_layers)):
             dx = self._lm_layer_bwd(i, dx, b, saved.pop())
         ops.embed_grad_(g["embed"], b.embed_ids, dx)

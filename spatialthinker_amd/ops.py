@@ -325,6 +325,30 @@ def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, c
     return dq, dk, dv
 
 
+def attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, scale, out=None):
+    """Shared-prefix causal attention over packed segments (st_attn_fwd_seg)."""
+    T = q.shape[0]
+    o = torch.empty(T, n_q * D, dtype=BF16, device=q.device) if out is None else out
+    lse = torch.empty(n_q, T, dtype=F32, device=q.device)
+    lib().st_attn_fwd_seg(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(seg_b), _p(seg_e), _p(pre_b), _p(pre_e),
+                          seg_b.numel(), T, n_q, n_kv, D, scale, _p(o), o.stride(0), _p(lse), int(max_seg), _s())
+    return o, lse
+
+
+def attn_bwd_seg(q, k, v, o, do, lse, seg_b, seg_e, pre_b, pre_e, dep_e, T_valid, max_seg, n_q, n_kv, D, scale, dq, dk, dv):
+    T = q.shape[0]
+    delta = torch.empty(n_q, T, dtype=F32, device=q.device)
+    need = int(lib().st_attn_bwd_workspace_bytes(T, n_q, D))
+    ws = _attn_ws.get(q.device)
+    if ws is None or ws.numel() < need:
+        ws = _attn_ws[q.device] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    lib().st_attn_bwd_seg(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), _p(do), do.stride(0),
+                          _p(lse), _p(seg_b), _p(seg_e), _p(pre_b), _p(pre_e), _p(dep_e), seg_b.numel(), T, int(T_valid), n_q, n_kv, D,
+                          scale, _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(delta), _p(ws), need,
+                          int(max_seg), _s())
+    return dq, dk, dv
+
+
 # ------------------------------------------------------------------ optimizer
 def adamw_scalars(t: int, lr: float, beta1: float, beta2: float):
     """step_size and denom-correction exactly as torch forms them on a float32 0-d `step` tensor

@@ -441,3 +441,62 @@ def test_decode_fused_ops_bit_identical(ops, M, B):
     ref = ops.swiglu_fwd(ops.gemm_nt(h, wgu))
     got = ops.gemm_swiglu_decode(h, wgu)
     assert torch.equal(ref, got)
+
+
+# ------------------------------------------------------------------ shared-prefix (segment) attention
+@pytest.mark.parametrize("groups", [[(70, [33, 1, 64])], [(200, [150, 129]), (65, [5]), (0, [90])], [(333, [257, 64, 100, 31])]])
+def test_attn_seg_shared_prefix_fwd_bwd(ops, groups):
+    """Packed [prompt][resp_1]..[resp_k] with the prompt stored once vs dense fp32 attention over every full sequence
+    (autograd sums the prompt gradients of the k rollouts)."""
+    n_q, n_kv, D = 4, 2, 128
+    g = n_q // n_kv
+    rs = np.random.RandomState(sum(p for p, _ in groups))
+    segs = []          # (b, e, pre_b, pre_e, dep_e)
+    row = 0
+    for P, resps in groups:
+        pb, pe = row, row + P
+        gend = pe + sum(resps)
+        if P:
+            segs.append((pb, pe, 0, 0, gend))
+        row = pe
+        for R in resps:
+            segs.append((row, row + R, pb, pe, row + R))
+            row += R
+    T = row
+    T_pad = (T + 127) // 128 * 128
+    W = (n_q + 2 * n_kv) * D
+    qkv_np = rs.standard_normal((T_pad, W)).astype(np.float32)
+    qkv = bf(qkv_np).cuda()
+    do = bf(rs.standard_normal((T_pad, n_q * D))).cuda()
+    q, k, v = qkv[:, :n_q * D], qkv[:, n_q * D:(n_q + n_kv) * D], qkv[:, (n_q + n_kv) * D:]
+    ti = lambda i: torch.tensor([s_[i] for s_ in segs], dtype=torch.int32, device="cuda")
+    seg_b, seg_e, pre_b, pre_e, dep_e = (ti(i) for i in range(5))
+    max_seg = max(e - b for b, e, *_ in segs)
+    scale = D ** -0.5
+    out, lse = ops.attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, scale)
+    dq = torch.zeros(T_pad, n_q * D, dtype=torch.bfloat16, device="cuda")
+    dk = torch.zeros(T_pad, n_kv * D, dtype=torch.bfloat16, device="cuda"); dv = torch.zeros_like(dk)
+    ops.attn_bwd_seg(q, k, v, out, do, lse, seg_b, seg_e, pre_b, pre_e, dep_e, T, max_seg, n_q, n_kv, D, scale, dq, dk, dv)
+    # dense reference with autograd
+    leaf = qkv.float().cpu().clone().requires_grad_(True)
+    ref_out = torch.zeros(T_pad, n_q * D)
+    loss = 0.0
+    for (b, e, pb, pe, _) in segs:
+        rows = list(range(pb, pe)) + list(range(b, e))
+        x = leaf[rows]
+        L = len(rows)
+        qq = x[:, :n_q * D].view(L, n_q, D).transpose(0, 1)
+        kk = x[:, n_q * D:(n_q + n_kv) * D].view(L, n_kv, D).transpose(0, 1).repeat_interleave(g, 0)
+        vv = x[:, (n_q + n_kv) * D:].view(L, n_kv, D).transpose(0, 1).repeat_interleave(g, 0)
+        sc = (qq @ kk.transpose(1, 2)) * scale
+        sc = sc.masked_fill(~torch.ones(L, L, dtype=torch.bool).tril(), float("-inf"))
+        o = (sc.softmax(-1) @ vv).transpose(0, 1).reshape(L, n_q * D)
+        own = o[pe - pb:]                                       # only the segment's own rows are outputs of this segment
+        ref_out[b:e] = own.detach()
+        loss = loss + (own * do.float().cpu()[b:e]).sum()
+    loss.backward()
+    gr = leaf.grad
+    assert float((out.float().cpu()[:T] - ref_out[:T]).abs().max()) < 2e-2
+    for name, got, want in (("dq", dq, gr[:, :n_q * D]), ("dk", dk, gr[:, n_q * D:(n_q + n_kv) * D]), ("dv", dv, gr[:, (n_q + n_kv) * D:])):
+        err = float((got.float().cpu()[:T] - want[:T]).abs().max())
+        assert err < 0.02 * float(want.abs().max()) + 1e-2, (name, err, float(want.abs().max()))

@@ -169,3 +169,43 @@ def test_shared_image_runs_the_vision_tower_once(env):
     rel = float((ga - gb).norm() / ga.norm())
     assert rel < 5e-3, rel
     store.grad.zero_()
+
+
+def test_shared_prompt_packing_matches_per_sequence_packing(env):
+    """Rollouts of one prompt packed as [prompt][resp_1]..[resp_k] (prompt + image computed once, shared-prefix attention)
+    vs the reference's per-sequence packing: same log-probs and gradients up to bf16 reduction order."""
+    z, cfg, params, store, eng, batch = env
+    R, k = batch["R"], 3
+    n0 = int(batch["patch_counts"][0])
+    rs = np.random.RandomState(11)
+    ids = np.repeat(batch["input_ids"][:1], k, 0).copy(); mask = np.repeat(batch["attention_mask"][:1], k, 0).copy()
+    pos = np.repeat(z["position_ids"][:1], k, 0)
+    S = ids.shape[1]
+    for r in range(1, k):                                    # different responses (and lengths) behind the same prompt
+        ids[r, S - R:] = rs.randint(3, 900, R)
+        mask[r, S - R + rs.randint(2, R):] = 0
+    px0, g0 = batch["pixel_values"][:n0], batch["image_grid_thw"][:1]
+    rmask = mask[:, -R:]
+    old = rs.standard_normal((k, R)).astype(np.float32) * 0.1 - 6.0
+    adv = rs.standard_normal((k, 1)).astype(np.float32).repeat(R, 1) * rmask
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    loss_in = dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64))
+    kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
+    res = []
+    for shared in (False, True):
+        if shared:
+            b = eng.stage(ids, mask, pos, R, px0, g0, groups=[0] * k)
+            assert b.pk.T < 0.6 * int(mask.sum())            # the prompt is stored once
+        else:
+            b = eng.stage(ids, mask, pos, R, np.concatenate([px0] * k, 0), np.concatenate([g0] * k, 0))
+        store.grad.zero_()
+        lp, _ = eng.forward_backward(b, loss_in, 1.0, **kw)
+        lp_ng = eng.log_probs(b, 1.0)
+        assert torch.equal(lp, lp_ng)
+        res.append((lp.clone(), store.grad.clone()))
+    m = torch.from_numpy(rmask.astype(bool)).cuda()
+    assert float((res[0][0] - res[1][0])[m].abs().max()) < 3e-2
+    ga, gb = res[0][1], res[1][1]
+    rel = float((ga - gb).norm() / ga.norm())
+    assert rel < 2e-2, rel
+    store.grad.zero_()

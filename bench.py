@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--rollouts", type=int, default=8)
     ap.add_argument("--response-cap", type=int, default=1024, help="max_response_length of the synthetic batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -194,6 +195,8 @@ def main():
     ref_store.flat.copy_(actor_store.flat)
     actor = PolicyEngine(cfg, actor_store, hyper)
     ref = PolicyEngine(cfg, ref_store, None)
+    if a.fuse_micro_batches is not None:
+        actor.fuse_micro_batches = a.fuse_micro_batches
     gen = Generator(actor.model)
     rs = np.random.RandomState(a.seed + rank)
     eos_id, pad_id = (1014, 1013) if tiny else (151645, 151643)
@@ -254,7 +257,8 @@ def main():
                     for pr in sorted(set(r // G for r in rows)):
                         groups.append((int(plen[pr]), [rlen[r] for r in rows if r // G == pr]))
                 return cfg.flops_forward_grouped(groups, [n_patch] * len(groups), logit_rows=int(rmask.sum()))
-            f_exp, f_upd = executed(hyper.micro_batch_size_per_device_for_experience), executed(micro)
+            f_exp = executed(hyper.micro_batch_size_per_device_for_experience)
+            f_upd = executed(micro * max(1, min(actor.fuse_micro_batches, (B // n_opt) // micro)))
             flops["old"] += f_exp; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
             flops["reference_formulation"] = flops.get("reference_formulation", 0.0) + 5 * f_ref
             tokens_total[0] += int(mask_f.sum())

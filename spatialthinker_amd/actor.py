@@ -60,6 +60,7 @@ class PolicyEngine:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.share_prompts = True     # pack the prompt of a rollout group once (see _stage)
+        self.fuse_micro_batches = 2   # reference micro-batches per forward/backward pass (update_policy)
         self.opt_steps = 0            # t of AdamW (state["step"])
         self.sched_steps = 0          # lr_scheduler.step() calls so far: once per update_policy call (fsdp_workers.py:453)
         self._norm_buf = torch.zeros(1, dtype=F32, device=store.device) if hyper is not None else None
@@ -157,10 +158,16 @@ class PolicyEngine:
         mini, micro = h.global_batch_size_per_device, h.micro_batch_size_per_device_for_update
         assert N % mini == 0 and mini % micro == 0, (N, mini, micro)
         accum = mini // micro
+        # several reference micro-batches per forward/backward pass (each keeps its own loss normalisation, see
+        # Qwen25VL.forward_backward): with micro = 4 and G = 8 a pass then holds a whole rollout group behind ONE prompt copy
+        fuse = max(1, min(self.fuse_micro_batches, accum))
+        while accum % fuse:
+            fuse -= 1
+        rows = micro * fuse
         for _ in range(h.ppo_epochs):
             for m0 in range(0, N, mini):
-                for s in range(m0, m0 + mini, micro):
-                    sl = slice(s, s + micro)
+                for s in range(m0, m0 + mini, rows):
+                    sl = slice(s, s + rows)
                     b = self._stage(data, sl)
                     to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
                     loss_in = dict(old_log_probs=to("old_log_probs"), advantages=to("advantages"),
@@ -168,8 +175,8 @@ class PolicyEngine:
                                    response_mask=torch.as_tensor(data["attention_mask"][sl])[:, -R:].to(dev, I64))
                     _, met = self.model.forward_backward(b, loss_in, temperature, clip_low=h.clip_ratio_low, clip_high=h.clip_ratio_high,
                                                          clip_dual=h.clip_ratio_dual, kl_kind=h.kl_penalty, kl_coef=h.kl_coef,
-                                                         grad_accum=float(accum))
-                    pending.append(met)
+                                                         grad_accum=float(accum), loss_rows=micro)
+                    pending.extend(met if met.dim() == 2 else [met])
                 norm = self.optimizer_step()
                 metrics["actor/grad_norm"].append(norm)
         for met in torch.stack(pending).cpu().tolist():           # one device->host transfer for all micro-batches

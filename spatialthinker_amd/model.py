@@ -562,8 +562,21 @@ class Qwen25VL:
         lp_full.index_copy_(0, b.out_index, logp[:Tr])
         flat = lambda k: loss_inputs[k].reshape(-1).contiguous()
         ref = flat("ref_log_probs") if loss_inputs.get("ref_log_probs") is not None else None
-        gfull, metrics = ops.grpo_loss(lp_full, flat("old_log_probs").float(), ref.float() if ref is not None else None,
-                                       flat("advantages").float(), flat("response_mask").to(I64), **loss_kw)
+        # loss_rows: the reference's micro-batch size when several of its micro-batches ride in one pass (PolicyEngine fuses
+        # them so a whole rollout group shares its prompt): every block of loss_rows rows gets its own masked means, exactly as if
+        # it had been a separate forward/backward — gradients add up linearly in the shared backward.
+        loss_rows = loss_kw.pop("loss_rows", None) or b.pk.B
+        old_f, adv_f, msk_f = flat("old_log_probs").float(), flat("advantages").float(), flat("response_mask").to(I64)
+        ref_f = ref.float() if ref is not None else None
+        if loss_rows >= b.pk.B:
+            gfull, metrics = ops.grpo_loss(lp_full, old_f, ref_f, adv_f, msk_f, **loss_kw)
+        else:
+            gs, ms = [], []
+            for r0 in range(0, b.pk.B, loss_rows):
+                sl = slice(r0 * b.pk.R, min(b.pk.B, r0 + loss_rows) * b.pk.R)
+                g_i, m_i = ops.grpo_loss(lp_full[sl], old_f[sl], None if ref_f is None else ref_f[sl], adv_f[sl], msk_f[sl], **loss_kw)
+                gs.append(g_i); ms.append(m_i)
+            gfull, metrics = torch.cat(gs), torch.stack(ms)
         grow = torch.zeros(b.Tr_pad, dtype=F32, device=x.device)
         grow[:Tr] = gfull.index_select(0, b.out_index)
         ops.logprob_bwd_(logits, b.labels, lse, grow, temperature)                       # logits buffer now holds dlogits

@@ -209,3 +209,43 @@ def test_shared_prompt_packing_matches_per_sequence_packing(env):
     rel = float((ga - gb).norm() / ga.norm())
     assert rel < 2e-2, rel
     store.grad.zero_()
+
+
+def test_fused_micro_batches_keep_per_micro_batch_loss_normalisation(env):
+    """Two reference micro-batches in ONE pass (loss_rows = micro-batch size) == two separate passes: same metrics per
+    micro-batch, same accumulated gradient up to bf16 reduction order."""
+    z, cfg, params, store, eng, batch = env
+    R = batch["R"]
+    rs = np.random.RandomState(5)
+    ids = np.concatenate([batch["input_ids"], batch["input_ids"]], 0).copy()
+    mask = np.concatenate([batch["attention_mask"], batch["attention_mask"]], 0).copy()
+    pos = np.concatenate([z["position_ids"], z["position_ids"]], 0)
+    S = ids.shape[1]
+    ids[2:, S - R:] = rs.randint(3, 900, (2, R))
+    mask[2, S - 3:] = 0
+    px = np.concatenate([batch["pixel_values"], batch["pixel_values"]], 0)
+    gr = np.concatenate([batch["image_grid_thw"], batch["image_grid_thw"]], 0)
+    n_patch = batch["patch_counts"]
+    rmask = mask[:, -R:]
+    old = rs.standard_normal((4, R)).astype(np.float32) * 0.1 - 6.0
+    adv = rs.standard_normal((4, 1)).astype(np.float32).repeat(R, 1) * rmask
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=2.0)
+    li = lambda sl: dict(old_log_probs=dv(old[sl]), ref_log_probs=dv(old[sl]), advantages=dv(adv[sl]), response_mask=dv(rmask[sl], torch.int64))
+    store.grad.zero_()
+    mets = []
+    off = int(n_patch[0] + n_patch[1])
+    for sl, ps in ((slice(0, 2), slice(0, off)), (slice(2, 4), slice(off, 2 * off))):
+        b = eng.stage(ids[sl], mask[sl], pos[sl], R, px[ps], gr[sl])
+        _, m = eng.forward_backward(b, li(sl), 1.0, **kw)
+        mets.append(m)
+    g_sep = store.grad.clone()
+    store.grad.zero_()
+    b = eng.stage(ids, mask, pos, R, px, gr)
+    _, m2 = eng.forward_backward(b, li(slice(0, 4)), 1.0, loss_rows=2, **kw)
+    g_fused = store.grad.clone()
+    assert m2.shape == (2, 8)
+    assert torch.allclose(torch.stack(mets), m2, rtol=2e-2, atol=2e-3)
+    rel = float((g_sep - g_fused).norm() / g_sep.norm())
+    assert rel < 2e-2, rel
+    store.grad.zero_()

@@ -206,7 +206,8 @@ int st_decode_finish_norm(const float* slabs, int splits, const st_bf16* residua
                           const st_bf16* norm_w, float eps, st_bf16* h_out, int64_t ldh, int M, int N, st_stream_t stream);
 int st_decode_finish_qkv(const float* slabs, int splits, const st_bf16* bias, const float* cos_tab, const float* sin_tab,
                          st_bf16* q_out, int64_t ldq, st_bf16* kg, st_bf16* vg, int64_t gen_stride, const int32_t* gen_len,
-                         int B, int M, int n_q, int n_kv, int D, st_stream_t stream);
+                         const int32_t* row_map /* NULL or (B,): cache slot (sample id) of row b */, int B, int M, int n_q,
+                         int n_kv, int D, st_stream_t stream);
 /* KV-cache append: for each sample b (active[b] != 0 or active NULL) copy the K and V column slices of qkv row b
  * into kg/vg[b, gen_len[b], :width]; if increment, gen_len[b] += 1 afterwards. */
 int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width, st_bf16* kg, st_bf16* vg,
@@ -251,9 +252,9 @@ int st_add_bf16(const st_bf16* a, const st_bf16* b, st_bf16* out, int64_t n, st_
  * temperature == 0: argmax.  forced (B,) int32 or NULL: entries >= 0 override the sampled token (EOS forcing
  * of the synthetic benchmark / max-length handling).  top_k > 0 or top_p < 1 return -38 (not built yet). */
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p,
-              uint64_t seed, uint64_t step, const int64_t* step_dev /* device counter overriding `step`, or NULL */,
-              const int32_t* forced, int32_t* out_ids, float* scratch /* B*32 floats or NULL: splits each row over 16 workgroups */,
-              st_stream_t stream);
+              uint64_t seed, uint64_t step, const int64_t* step_dev, const int32_t* forced,
+              const int32_t* row_ids /* NULL or (B,): identity of each row for the RNG key (stable under batch compaction) */,
+              int32_t* out_ids, float* scratch, st_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -71,13 +71,16 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {          // splitmix64 f
 __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict__ logits, int64_t ldl, int V, float inv_temp,
                                                     int greedy, uint64_t seed, uint64_t step_host, const int64_t* __restrict__ step_dev,
                                                     const int32_t* __restrict__ forced, int32_t* __restrict__ out_ids,
-                                                    float* __restrict__ scratch) {
+                                                    float* __restrict__ scratch, const int32_t* __restrict__ row_ids) {
     const int row = blockIdx.x;
     const uint16_t* x = logits + (int64_t)row * ldl;
     float best = -INFINITY;
     int besti = 0x7fffffff;
     const uint64_t step = step_dev ? (uint64_t)step_dev[0] : step_host;
-    const uint64_t key = (seed * 0x100000001B3ull) ^ (step << 32) ^ ((uint64_t)row * 0x9E3779B1ull);
+    // the stream is keyed by the sample's identity, not by its row in this launch: compacting the decode batch (dropping
+    // finished samples) does not change what the survivors sample
+    const uint64_t rid = row_ids ? (uint64_t)row_ids[row] : (uint64_t)row;
+    const uint64_t key = (seed * 0x100000001B3ull) ^ (step << 32) ^ (rid * 0x9E3779B1ull);
     const int per = (V + gridDim.y - 1) / gridDim.y;
     const int v0 = blockIdx.y * per, v1 = min(V, v0 + per);
     for (int i = v0 + threadIdx.x; i < v1; i += 256) {
@@ -228,14 +231,15 @@ __global__ __launch_bounds__(256) void decode_finish_qkv_kernel(const float* __r
                                                                const uint16_t* __restrict__ bias, const float* __restrict__ cosb,
                                                                const float* __restrict__ sinb, uint16_t* __restrict__ q_out,
                                                                int64_t ldq, uint16_t* __restrict__ kg, uint16_t* __restrict__ vg,
-                                                               int64_t gen_stride, const int32_t* __restrict__ gen_len, int B,
+                                                               int64_t gen_stride, const int32_t* __restrict__ gen_len,
+                                                               const int32_t* __restrict__ row_map, int B,
                                                                int M, int n_q, int n_kv, int D) {
     const int b = blockIdx.x;
     const int N = (n_q + 2 * n_kv) * D;
     const int64_t slab_stride = (int64_t)M * N;
     const int half = D >> 1, chunks = half >> 3;
     const int width = n_kv * D;
-    const int64_t cache_row = (int64_t)b * gen_stride + (int64_t)gen_len[b] * width;
+    const int64_t cache_row = (int64_t)(row_map ? row_map[b] : b) * gen_stride + (int64_t)gen_len[b] * width;   // row b holds sample row_map[b]
     // rotary heads: item = (head, chunk of 8 inside the first half); partner chunk at +half
     for (int it = threadIdx.x; it < (n_q + n_kv) * chunks; it += 256) {
         const int hd = it / chunks, ch = it % chunks;
@@ -299,13 +303,13 @@ int st_decode_finish_norm(const float* slabs, int splits, const st_bf16* residua
 }
 
 int st_decode_finish_qkv(const float* slabs, int splits, const st_bf16* bias, const float* cos_tab, const float* sin_tab,
-                         st_bf16* q_out, int64_t ldq, st_bf16* kg, st_bf16* vg, int64_t gen_stride, const int32_t* gen_len, int B,
-                         int M, int n_q, int n_kv, int D, st_stream_t stream) {
+                         st_bf16* q_out, int64_t ldq, st_bf16* kg, st_bf16* vg, int64_t gen_stride, const int32_t* gen_len,
+                         const int32_t* row_map, int B, int M, int n_q, int n_kv, int D, st_stream_t stream) {
     if (!slabs || splits <= 0 || !cos_tab || !sin_tab || !q_out || !kg || !vg || !gen_len || B <= 0 || B > M || n_q <= 0 || n_kv <= 0 ||
         (D & 15) || (ldq & 7))
         return ST_EINVAL;
     hipLaunchKernelGGL(decode_finish_qkv_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, slabs, splits, bias, cos_tab, sin_tab, q_out,
-                       ldq, kg, vg, gen_stride, gen_len, B, M, n_q, n_kv, D);
+                       ldq, kg, vg, gen_stride, gen_len, row_map, B, M, n_q, n_kv, D);
     ST_CHECK_LAUNCH();
     return 0;
 }
@@ -331,13 +335,14 @@ int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_par
 }
 
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
-              uint64_t step, const int64_t* step_dev, const int32_t* forced, int32_t* out_ids, float* scratch, st_stream_t stream) {
+              uint64_t step, const int64_t* step_dev, const int32_t* forced, const int32_t* row_ids, int32_t* out_ids, float* scratch,
+              st_stream_t stream) {
     if (!logits || !out_ids || B <= 0 || V <= 0 || temperature < 0.f) return ST_EINVAL;
     if (top_k > 0 || top_p < 1.f) return -38;        // top-k / top-p filtering: not built yet (shipped configs use -1 / 1.0)
     const int greedy = temperature == 0.f;
     const int splits = scratch ? 16 : 1;                       // scratch: B * 16 * 2 floats
     hipLaunchKernelGGL(sample_kernel, dim3(B, splits), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature,
-                       greedy, seed, step, step_dev, forced, out_ids, scratch);
+                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids);
     if (scratch)
         hipLaunchKernelGGL(sample_finish_kernel, dim3(st_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, scratch, splits, forced, out_ids, B);
     ST_CHECK_LAUNCH();

@@ -25,6 +25,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -364,7 +365,7 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
 // slabs [split][M][N] (ldc = N) that gemm_skinny_finish sums in a fixed order.
 //   10 = 64x64 1x4   11 = 64x128 1x4   12 = 64x256 1x4   13 = 128x64 2x2   14 = 128x128 2x2   15 = 256x64 4x1
 //   16 = 256x128 4x2 (3 slots)   17 = 256x128 4x2 (2 slots)   18 = 256x256 4x2 (2 slots)   19 = 128x128 2x2 (2 slots)
-//   20 = 128x256 2x4 (2 slots)   21 = 64x128 1x4 (2 slots)
+//   20 = 128x256 2x4 (2 slots)   21 = 64x128 1x4 (2 slots)   22 = 256x192 4x2 (2 slots)
 int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
                         const uint16_t* res, int64_t ldr, uint16_t* Cb, float* slabs, int M, int N, int K, int64_t ldc, hipStream_t s) {
 #define DEC_GO(BM, BN, WM, WN, ST)                                                                                               \
@@ -388,6 +389,7 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
         case 19: DEC_GO(128, 128, 2, 2, 2);
         case 20: DEC_GO(128, 256, 2, 4, 2);
         case 21: DEC_GO(64, 128, 1, 4, 2);
+        case 22: DEC_GO(256, 192, 4, 2, 2);
         default: return ST_EINVAL;
     }
 #undef DEC_GO
@@ -418,7 +420,8 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
     hipStream_t s = (hipStream_t)stream;
     if (M <= 64) return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     if (M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
-    return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    // 256x192: 198 workgroups for the 7B gate/up (I = 18944) instead of 148 with 256x256 — fills 77 % of the CUs, -10 % time
+    return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
 }
 
 extern "C" int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,

@@ -257,9 +257,9 @@ def decode_finish_norm(slabs, splits, M, N, *, residual, x_out, norm_w=None, eps
                                 x_out.stride(0), _p(norm_w), eps, _p(h_out), h_out.stride(0) if h_out is not None else 0, M, N, _s())
 
 
-def decode_finish_qkv(slabs, splits, M, bias, cos, sin, q_out, kg, vg, gen_len, B, n_q, n_kv, D):
+def decode_finish_qkv(slabs, splits, M, bias, cos, sin, q_out, kg, vg, gen_len, B, n_q, n_kv, D, row_map=None):
     lib().st_decode_finish_qkv(_p(slabs), splits, _p(bias), _p(cos), _p(sin), _p(q_out), q_out.stride(0), _p(kg), _p(vg), kg.stride(0),
-                               _p(gen_len), B, M, n_q, n_kv, D, _s())
+                               _p(gen_len), _p(row_map), B, M, n_q, n_kv, D, _s())
 
 
 def gemm_swiglu_decode(a, gate_up_w, out=None):
@@ -451,12 +451,12 @@ def kv_append_(qkv, col_k, col_v, width, kg, vg, gen_len, active=None, increment
                        int(increment), _s())
 
 
-def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, step_dev=None, out=None):
+def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, step_dev=None, out=None, row_ids=None):
     B, V = logits.shape
     out = torch.empty(B, dtype=I32, device=logits.device) if out is None else out
     scratch = torch.empty(B * 32, dtype=F32, device=logits.device)
     lib().st_sample(_p(logits), logits.stride(0), B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step), _p(step_dev),
-                    _p(forced), _p(out), _p(scratch), _s())
+                    _p(forced), _p(row_ids), _p(out), _p(scratch), _s())
     return out
 
 

@@ -25,6 +25,7 @@ class Generator:
     def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False, fused_decode: bool = True):
         self.m = model
         self.max_decode_batch = 256       # sequences decoded together (rows of the decode GEMMs)
+        self.compact = True               # restart the decode graph on the survivors once half of a phase's rows have finished
         self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
         self.autotune = autotune          # time the decode GEMM tile/split-K candidates once per (batch, weight shape)
@@ -101,131 +102,165 @@ class Generator:
             ops.rows_gather(x, rows, out=last_h[i0:i1])
             i0 = i1
         head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
-        # ---------------- decode state
+        # ---------------- decode state (per SAMPLE, global over the phases below)
         rep = torch.arange(nb, device=dev, dtype=I32).repeat_interleave(n)
         hn, _ = ops.rmsnorm_fwd(ops.rows_gather(last_h, rep), w["final_norm"], c.rms_eps, want_rstd=False)
-        Bp = ix.round_up(B, 32) if B <= 256 else ix.round_up(B, 128)     # decode GEMMs take the skinny path for M <= 256
         out = torch.full((B, R), pad_token_id, dtype=I64, device=dev)
         kg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
         vg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
-        gen_len = torch.zeros(B, dtype=I32, device=dev)
-        active = torch.ones(B, dtype=I32, device=dev)
+        gen_len_g = torch.zeros(B, dtype=I32, device=dev)
         last_pos = torch.from_numpy(np.ascontiguousarray(pos_np[:, :, -1].T)).to(dev, I32).repeat_interleave(n, dim=1)   # (3, B)
+        pos_g = (last_pos + 1).contiguous()                    # position of the token sampled at response index 0
         eos_t = torch.tensor(eos, device=dev, dtype=I64)
-        forced_len = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I64)
-        ar = torch.arange(B, device=dev, dtype=I32)
-        # prompt partial: one "sequence" per (key chunk c, prompt p) -> slab c of the partial buffer (flash-decoding split-KV)
+        forced_len_g = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I64)
         CK = 256
         C = max(1, int(-(-int(lens.max()) // CK)))
-        rows_all = B * g
-        pb, pe = p_off[:-1].astype(np.int64), p_off[1:].astype(np.int64)
-        kb1_np = np.concatenate([np.minimum(pb + c * CK, pe) for c in range(C)])
-        ke1_np = np.concatenate([np.minimum(pb + (c + 1) * CK, pe) for c in range(C)])
-        qb1_np = np.tile(np.arange(nb) * (n * g), C)
-        ob1_np = np.concatenate([c * rows_all + np.arange(nb) * (n * g) for c in range(C)])
-        ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
-        qb1, kb1, ke1, ob1 = ti(qb1_np), ti(kb1_np), ti(ke1_np), ti(ob1_np)
-        qe1 = qb1 + n * g
-        # generated partial: one "sequence" per (key chunk c, sample b); chunks beyond the current length are empty ranges
         Cg = max(1, -(-R // CK))
-        qb2 = (ar * g).repeat(Cg).contiguous(); qe2 = qb2 + g
-        kbase = (ar * R).repeat(Cg)
-        kb2 = (kbase + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(B) * CK).contiguous()
-        ob2 = ((C + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(B)) * rows_all + (ar * g).repeat(Cg)).contiguous()
         NP = C + Cg
-        parts = torch.empty(NP * rows_all, width, dtype=BF16, device=dev)
-        lse_parts = torch.empty(nkv, NP * rows_all, dtype=F32, device=dev)
-        xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
-        abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)              # attention output, pad rows stay zero
-        logits = torch.empty(Bp if Bp <= 256 else B, c.vocab_size, dtype=BF16, device=dev)
-        ops.gemm_nt(hn, head, out=logits[:B])
+        pb, pe = p_off[:-1].astype(np.int64), p_off[1:].astype(np.int64)
+        ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
+        Bfull = ix.round_up(B, 32) if B <= 256 else ix.round_up(B, 128)   # decode GEMMs take the skinny path for M <= 256
+        logits0 = torch.empty(B, c.vocab_size, dtype=BF16, device=dev)
+        ops.gemm_nt(hn, head, out=logits0)
         step_t = torch.zeros(1, dtype=I64, device=dev)
-        pos = (last_pos + 1).contiguous()                      # position of the token sampled at response index 0
-        tok32 = torch.zeros(B, dtype=I32, device=dev)
-        pad_t = torch.full((B,), pad_token_id, dtype=I64, device=dev)
+        can_fuse = self.fused_decode and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
+        if self.autotune and Bfull <= 256:
+            self._tune_decode(Bfull)
 
-        if self.autotune and Bp <= 256:
-            self._tune_decode(Bp)
-        fused = self.fused_decode and Bp <= 256 and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
-        qbuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)             # roped queries of the fused path (pad rows stay zero)
+        def decode_phase(S_np: np.ndarray, logits_in: torch.Tensor, step0: int):
+            """Decode the samples S_np (sorted ids) from response index step0 until they are all finished, the length cap is hit,
+            or fewer than half of the phase's rows are still live (then the caller starts a new, narrower phase with the
+            survivors: finished rows would otherwise keep occupying the GEMM tiles for the rest of the generation).
+            Returns (next_step, survivors (np ids), their pending logits)."""
+            Ba = len(S_np)
+            Bp = ix.round_up(Ba, 32) if Ba <= 256 else ix.round_up(Ba, 128)
+            fused = can_fuse and Bp <= 256
+            S_t = ti(S_np)
+            S_l = S_t.long()
+            rows_all = Ba * g
+            gen_len = gen_len_g[S_l].contiguous()
+            pos = pos_g[:, S_l].contiguous()
+            active = torch.ones(Ba, dtype=I32, device=dev)
+            forced_len = None if forced_len_g is None else forced_len_g[S_l].contiguous()
+            out_l = out[S_l].contiguous()
+            ar = torch.arange(Ba, device=dev, dtype=I32)
+            # prompt partial: one "sequence" per (key chunk c, prompt p present in this phase) -> slab c (flash-decoding split-KV);
+            # the samples of a prompt are consecutive local rows
+            prom = S_np // n
+            pids, first, cnt = np.unique(prom, return_index=True, return_counts=True)
+            kb1_np = np.concatenate([np.minimum(pb[pids] + c_ * CK, pe[pids]) for c_ in range(C)])
+            ke1_np = np.concatenate([np.minimum(pb[pids] + (c_ + 1) * CK, pe[pids]) for c_ in range(C)])
+            qb1_np = np.tile(first * g, C)
+            qe1_np = np.tile((first + cnt) * g, C)
+            ob1_np = np.concatenate([c_ * rows_all + first * g for c_ in range(C)])
+            qb1, qe1, kb1, ke1, ob1 = ti(qb1_np), ti(qe1_np), ti(kb1_np), ti(ke1_np), ti(ob1_np)
+            max_q1 = int(cnt.max()) * g
+            # generated partial: one "sequence" per (key chunk c, local row); chunks beyond the current length are empty ranges
+            qb2 = (ar * g).repeat(Cg).contiguous(); qe2 = qb2 + g
+            kbase = (S_t * R).repeat(Cg)
+            kb2 = (kbase + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(Ba) * CK).contiguous()
+            ob2 = ((C + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(Ba)) * rows_all + (ar * g).repeat(Cg)).contiguous()
+            parts = torch.empty(NP * rows_all, width, dtype=BF16, device=dev)
+            lse_parts = torch.empty(nkv, NP * rows_all, dtype=F32, device=dev)
+            xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
+            abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # attention output, pad rows stay zero
+            qbuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # roped queries of the fused path (pad rows stay zero)
+            logits = torch.empty(Bp if Bp <= 256 else Ba, c.vocab_size, dtype=BF16, device=dev)
+            logits[:Ba].copy_(logits_in)
+            tok32 = torch.zeros(Ba, dtype=I32, device=dev)
+            pad_t = torch.full((Ba,), pad_token_id, dtype=I64, device=dev)
+            kgv, vgv = kg.view(L, B * R, width), vg.view(L, B * R, width)
 
-        def iteration():
-            """sample -> record -> one decode forward for all B rows -> next logits.  Device state only (graph-capturable).
-            Finished rows keep computing on their last token; their output is ignored (cheaper than re-packing every step)."""
-            nonlocal active
-            forced = None
-            if forced_len is not None:
-                forced = torch.where(forced_len == step_t + 1, int(eos[0]), -1).to(I32)
-            ops.sample(logits[:B], temperature, seed, forced=forced, step_dev=step_t, out=tok32)
-            tok = tok32.to(I64)
-            live = active.bool()
-            out.scatter_(1, step_t.expand(B, 1), torch.where(live, tok, pad_t)[:, None])
-            if not ignore_eos:
-                active.copy_((live & ~(tok[:, None] == eos_t[None, :]).any(1)).to(I32))
-            cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
-            ops.embed_gather(w["embed"], tok32, out=xbuf[:B])
-            x = xbuf
-            ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (gen_len + 1).repeat(Cg)), kb2).contiguous()
-            if fused:
-                # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE + cache
-                # append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue
-                H = c.hidden_size
-                h1, _ = ops.rmsnorm_fwd(x, w["l.0.in_norm"], c.rms_eps, want_rstd=False)
-                for layer in range(L):
-                    p = f"l.{layer}."
-                    slabs, sp = ops.gemm_nt_decode_slabs(h1, w[p + "qkv_w"])
-                    ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], gen_len, B, nq, nkv, D)
-                    ops.attn_fwd_ranges(qbuf, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts,
-                                        o_beg=ob1, q_group=g)
-                    ops.attn_fwd_ranges(qbuf, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
-                                        nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
-                    ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)
-                    slabs, sp = ops.gemm_nt_decode_slabs(abuf, w[p + "o_w"])
-                    x1 = torch.empty(Bp, H, dtype=BF16, device=dev); h2 = torch.empty(Bp, H, dtype=BF16, device=dev)
-                    ops.decode_finish_norm(slabs, sp, Bp, H, residual=x, x_out=x1, norm_w=w[p + "post_norm"], eps=c.rms_eps, h_out=h2)
-                    mm = ops.gemm_swiglu_decode(h2, w[p + "gu_w"])
-                    slabs, sp = ops.gemm_nt_decode_slabs(mm, w[p + "down_w"])
-                    x = torch.empty(Bp, H, dtype=BF16, device=dev); h1 = torch.empty(Bp, H, dtype=BF16, device=dev)
-                    nxt = w[f"l.{layer + 1}.in_norm"] if layer + 1 < L else w["final_norm"]
-                    ops.decode_finish_norm(slabs, sp, Bp, H, residual=x1, x_out=x, norm_w=nxt, eps=c.rms_eps, h_out=h1)
-                hn2 = h1
-            else:
-                for layer in range(L):
-                    p = f"l.{layer}."
-                    h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
-                    qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
-                    ops.rope_apply_(qkv[:B], cos, sin, nq + nkv, D)
-                    ops.kv_append_(qkv[:B], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
-                    ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, n * g, nkv, nkv, D, m.scale, parts, lse_parts,
-                                        o_beg=ob1, q_group=g)
-                    ops.attn_fwd_ranges(qkv, kg[layer].view(B * R, width), vg[layer].view(B * R, width), qb2, qe2, kb2, ke2, g,
-                                        nkv, nkv, D, m.scale, parts, lse_parts, o_beg=ob2, q_group=g)
-                    ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
-                    x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
-                    h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
-                    mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
-                    x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
-                hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
-            ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits)
-            gen_len.add_(1); pos.add_(1); step_t.add_(1)
+            def iteration():
+                """sample -> record -> one decode forward for the phase's rows -> next logits.  Device state only (graph-capturable).
+                Finished rows keep computing on their last token until the phase is compacted; their output is ignored."""
+                forced = None
+                if forced_len is not None:
+                    forced = torch.where(forced_len == step_t + 1, int(eos[0]), -1).to(I32)
+                ops.sample(logits[:Ba], temperature, seed, forced=forced, step_dev=step_t, out=tok32, row_ids=S_t)
+                tok = tok32.to(I64)
+                live = active.bool()
+                out_l.scatter_(1, step_t.expand(Ba, 1), torch.where(live, tok, pad_t)[:, None])
+                if not ignore_eos:
+                    active.copy_((live & ~(tok[:, None] == eos_t[None, :]).any(1)).to(I32))
+                cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
+                ops.embed_gather(w["embed"], tok32, out=xbuf[:Ba])
+                x = xbuf
+                ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (gen_len + 1).repeat(Cg)), kb2).contiguous()
+                if fused:
+                    # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE +
+                    # cache append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue
+                    H = c.hidden_size
+                    h1, _ = ops.rmsnorm_fwd(x, w["l.0.in_norm"], c.rms_eps, want_rstd=False)
+                    for layer in range(L):
+                        p = f"l.{layer}."
+                        slabs, sp = ops.gemm_nt_decode_slabs(h1, w[p + "qkv_w"])
+                        ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], gen_len, Ba, nq, nkv, D,
+                                              row_map=S_t)
+                        ops.attn_fwd_ranges(qbuf, kp[layer], vp[layer], qb1, qe1, kb1, ke1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
+                                            o_beg=ob1, q_group=g)
+                        ops.attn_fwd_ranges(qbuf, kgv[layer], vgv[layer], qb2, qe2, kb2, ke2, g, nkv, nkv, D, m.scale, parts, lse_parts,
+                                            o_beg=ob2, q_group=g)
+                        ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)
+                        slabs, sp = ops.gemm_nt_decode_slabs(abuf, w[p + "o_w"])
+                        x1 = torch.empty(Bp, H, dtype=BF16, device=dev); h2 = torch.empty(Bp, H, dtype=BF16, device=dev)
+                        ops.decode_finish_norm(slabs, sp, Bp, H, residual=x, x_out=x1, norm_w=w[p + "post_norm"], eps=c.rms_eps, h_out=h2)
+                        mm = ops.gemm_swiglu_decode(h2, w[p + "gu_w"])
+                        slabs, sp = ops.gemm_nt_decode_slabs(mm, w[p + "down_w"])
+                        x = torch.empty(Bp, H, dtype=BF16, device=dev); h1 = torch.empty(Bp, H, dtype=BF16, device=dev)
+                        nxt = w[f"l.{layer + 1}.in_norm"] if layer + 1 < L else w["final_norm"]
+                        ops.decode_finish_norm(slabs, sp, Bp, H, residual=x1, x_out=x, norm_w=nxt, eps=c.rms_eps, h_out=h1)
+                    hn2 = h1
+                else:
+                    for layer in range(L):
+                        p = f"l.{layer}."
+                        h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
+                        qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+                        ops.rope_apply_(qkv[:Ba], cos, sin, nq + nkv, D)
+                        ops.kv_append_(qkv[:Ba], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
+                        ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
+                                            o_beg=ob1, q_group=g)
+                        ops.attn_fwd_ranges(qkv, kgv[layer], vgv[layer], qb2, qe2, kb2, ke2, g, nkv, nkv, D, m.scale, parts, lse_parts,
+                                            o_beg=ob2, q_group=g)
+                        ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
+                        x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
+                        h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
+                        mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
+                        x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
+                    hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
+                ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits)
+                gen_len.add_(1); pos.add_(1); step_t.add_(1)
 
-        # the decode iteration is launch-bound (~20 launches x layers): capture it once into a hipGraph and replay
-        graph = None
-        if use_graph and R > 2:
-            iteration()                                            # eager warm-up iteration (response index 0)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                iteration()
-            first = 2                                              # capture itself does not execute: replay from index 1
-            graph.replay()
-        else:
-            first = 0
-        for step in range(first, R):
-            if graph is not None:
-                graph.replay()
-            else:
-                iteration()
-            if step % sync_every == sync_every - 1 and int(active.sum().item()) == 0:
-                break
+            # the decode iteration is launch-bound (~10 launches x layers): capture it once per phase into a hipGraph and replay
+            step, graph = step0, None
+            if use_graph and R - step0 > 2:
+                iteration()                                        # eager warm-up iteration
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    iteration()
+                step += 1                                          # capture itself does not execute
+            n_live = Ba
+            while step < R:
+                if graph is not None:
+                    graph.replay()
+                else:
+                    iteration()
+                step += 1
+                if (step - step0) % sync_every == 0 or step == R:
+                    n_live = int(active.sum().item())
+                    # compaction needs the sample-indexed cache append of the fused path; the unfused path keeps its rows
+                    if n_live == 0 or (self.compact and fused and Bp > 32 and n_live <= Bp // 2 and R - step > sync_every):
+                        break
+            out[S_l] = out_l
+            gen_len_g[S_l] = gen_len
+            pos_g[:, S_l] = pos
+            if n_live == 0 or step >= R:
+                return step, np.zeros(0, dtype=S_np.dtype), None
+            keep = active.bool()
+            return step, S_np[keep.cpu().numpy()], logits[:Ba][keep].contiguous()
+
+        S, lg, step = np.arange(B, dtype=np.int64), logits0, 0
+        while len(S):
+            step, S, lg = decode_phase(S, lg, step)
         return out

@@ -74,6 +74,31 @@ def test_fused_decode_epilogues_are_bit_identical_to_unfused_chain(env):
     np.testing.assert_array_equal(a, b)
 
 
+def test_decode_batch_compaction_keeps_samples_and_layout(env):
+    """Finished samples leave the decode batch (new, narrower phase on the survivors).  The RNG is keyed by the sample id, so a
+    sample's tokens do not depend on who else is still running — up to last-bit logit differences between GEMM tile plans of
+    different batch widths, which may flip a near-tie: most rows must agree exactly, all must keep the response layout."""
+    from spatialthinker_amd.rollout import Generator
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    n, R = 40, 24
+    rs = np.random.RandomState(0)
+    lens = np.where(rs.rand(2 * n) < 0.6, rs.randint(2, 6, 2 * n), rs.randint(16, R + 1, 2 * n)).astype(np.int64)
+    kw = dict(n=n, max_new_tokens=R, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID, seed=9,
+              pixel_values=pix, image_grid_thw=grids, forced_lengths=lens, sync_every=4)
+    g1 = Generator(eng); g1.compact = True
+    g0 = Generator(eng); g0.compact = False
+    a = g1.generate(ids, mask, pos, **kw).cpu().numpy()
+    b = g0.generate(ids, mask, pos, **kw).cpu().numpy()
+    for o in (a, b):
+        for r in range(2 * n):
+            L_ = int(lens[r])
+            e = int(np.argmax(o[r] == tiny.EOS_ID))             # first EOS: forced at L_-1 unless the random model emitted one earlier
+            assert o[r, e] == tiny.EOS_ID and e <= L_ - 1 and np.all(o[r, e + 1:] == tiny.PAD_ID)
+    same = np.mean([np.array_equal(a[r], b[r]) for r in range(2 * n)])
+    assert same >= 0.9, same
+
+
 def test_eos_stops_and_pads_and_forced_lengths(env):
     cfg, params, eng, gen = env
     ids, mask, pos, pix, grids = _prompts()

@@ -13,7 +13,7 @@ from spatialthinker_amd import ops  # noqa: E402
 from spatialthinker_amd.lib import lib  # noqa: E402
 
 SHAPES = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gateup", 37888, 3584), ("down", 3584, 18944), ("lmhead", 152064, 3584)]
-VARIANTS = {64: [10, 11, 12, 21], 128: [13, 14, 19, 20], 256: [15, 16, 17, 18, 13, 14, 19, 20]}
+VARIANTS = {64: [10, 11, 12, 21], 128: [13, 14, 19, 20], 256: [16, 18, 22, 13, 14]}
 
 
 def timeit(fn, n=32):

@@ -65,8 +65,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     constexpr int TM = WTM / 16, TN = WTN / 16;            // MFMA tiles per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INST = BM / 8, B_INST = BN / 8;        // 1 KiB wave-instructions per operand tile
-    constexpr int PER_WAVE = (A_INST + B_INST) / NW;       // LDS-DMA instructions each wave issues per K-tile
-    static_assert(A_INST % NW == 0 && B_INST % NW == 0, "tile rows must split evenly over the waves");
+    constexpr int A_PER = (A_INST + NW - 1) / NW, B_PER = (B_INST + NW - 1) / NW;
+    constexpr int PER_WAVE = A_PER + B_PER;                // LDS-DMA instructions a wave issues per K-tile (upper bound if uneven)
+    constexpr bool EVEN_DMA = (A_INST % NW == 0) && (B_INST % NW == 0);
+    static_assert(EVEN_DMA || STAGES == 2, "counted vmcnt waits (3-slot ring, mid-tile barrier) need the same DMA count in every wave");
+    static_assert(EVEN_DMA || !MIDBAR, "mid-tile barrier prologue counts DMA instructions");
     static_assert(!SWIGLU || (WTN % 32 == 0 && OUT_BF16 && !HAS_BIAS && !HAS_RES), "SwiGLU epilogue pairs 16-column MFMA tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -90,15 +93,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 
     auto stage = [&](int kt, char* dst) {
 #pragma unroll
-        for (int j = 0; j < A_INST / NW; ++j) {
-            const int inst = wave * (A_INST / NW) + j;
+        for (int j = 0; j < A_PER; ++j) {
+            const int inst = wave * A_PER + j;
+            if (!EVEN_DMA && inst >= A_INST) break;
             const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
             int gr = m0 + r; gr = gr < M ? gr : M - 1;
             glds16t(A + (int64_t)gr * lda + kt * 64 + kc * 8, dst + inst * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < B_INST / NW; ++j) {
-            const int inst = wave * (B_INST / NW) + j;
+        for (int j = 0; j < B_PER; ++j) {
+            const int inst = wave * B_PER + j;
+            if (!EVEN_DMA && inst >= B_INST) break;
             const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
             int gr;
             if (SWIGLU) {
@@ -420,8 +425,12 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
     hipStream_t s = (hipStream_t)stream;
     if (M <= 64) return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     if (M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
-    // 256x192: 198 workgroups for the 7B gate/up (I = 18944) instead of 148 with 256x256 — fills 77 % of the CUs, -10 % time
-    return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    // One row tile (M <= 256): the only freedom is the column tile.  Cost ~ rounds over 256 CUs x tile width; the 7B gate/up
+    // (I = 18944) gives 148 tiles at 128 output columns (0.58 of the CUs) and 198 at 96 (-10 % time).  A 256x160 tile as 8x1
+    // waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
+    auto cost = [&](int cols) { const int t = st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
+    if (cost(96) <= cost(128)) return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
 }
 
 extern "C" int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,

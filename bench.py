@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--rollouts", type=int, default=8)
     ap.add_argument("--response-cap", type=int, default=1024, help="max_response_length of the synthetic batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
@@ -187,7 +188,7 @@ def main():
     B = G * npr
     micro = 4
     n_opt = 4 if B % (4 * micro) == 0 else 1
-    hyper = ActorHyper(micro_batch_size_per_device_for_update=micro, micro_batch_size_per_device_for_experience=16,
+    hyper = ActorHyper(micro_batch_size_per_device_for_update=micro, micro_batch_size_per_device_for_experience=a.experience_micro_batch,
                        global_batch_size_per_device=B // n_opt)
     actor_store = ParamStore(cfg, trainable=True)
     actor_store.init_random(seed=7)

@@ -250,7 +250,9 @@ int st_add_bf16(const st_bf16* a, const st_bf16* b, st_bf16* out, int64_t n, st_
  * logits (B, V) bf16 -> one token per row.  temperature > 0: exact multinomial sampling of softmax(z/T) by the
  * Gumbel-max trick with a counter-based RNG keyed by (seed, step, row, index) — reproducible, no state;
  * temperature == 0: argmax.  forced (B,) int32 or NULL: entries >= 0 override the sampled token (EOS forcing
- * of the synthetic benchmark / max-length handling).  top_k > 0 or top_p < 1 return -38 (not built yet). */
+ * of the synthetic benchmark / max-length handling).  top_k > 0 / top_p < 1: vLLM order (top-k mask, then top-p on the rest);
+ * the cut is exact over the 65536 possible bf16 values (two-level histogram), ties with the threshold value are kept; needs
+ * scratch of B*33 floats. */
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p,
               uint64_t seed, uint64_t step, const int64_t* step_dev, const int32_t* forced,
               const int32_t* row_ids /* NULL or (B,): identity of each row for the RNG key (stable under batch compaction) */,

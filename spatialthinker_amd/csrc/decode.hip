@@ -66,14 +66,120 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {          // splitmix64 f
     x ^= x >> 31;
     return (uint32_t)(x >> 16);
 }
+// ---- top-k / top-p (vLLM sampler semantics: top-k mask first, then top-p on the renormalised rest; temperature applied
+// before both).  Logits are bf16, so there are only 65536 distinct values: the cut is found EXACTLY by a two-level histogram over
+// an order-preserving 16-bit key (count for top-k, integer-scaled probability mass for top-p — integer LDS atomics keep the
+// sums order-independent).  Result: one threshold key per row; sample_kernel skips tokens whose key is below it.  All tokens
+// that tie with the threshold value are kept.
+__device__ __forceinline__ uint32_t bf16_order_key(uint16_t b) { return (b & 0x8000u) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000u); }
+
+__global__ __launch_bounds__(256) void sample_filter_kernel(const uint16_t* __restrict__ logits, int64_t ldl, int V, float inv_temp,
+                                                           int top_k, float top_p, uint32_t* __restrict__ thr_out) {
+    __shared__ uint32_t cnt[256];
+    __shared__ unsigned long long mass[256];
+    __shared__ uint32_t s_max, s_sel[2];
+    __shared__ double s_target;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const uint16_t* x = logits + (int64_t)row * ldl;
+    // row maximum (as key)
+    uint32_t mk = 0;
+    for (int i = tid; i < V; i += 256) {
+        const uint16_t b = x[i];
+        if ((b & 0x7fffu) > 0x7f80u) continue;                        // NaN never wins
+        mk = max(mk, bf16_order_key(b));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, o, 64));
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicMax(&s_max, mk);
+    __syncthreads();
+    const uint32_t maxkey = s_max;
+    const uint16_t maxbits = (maxkey & 0x8000u) ? (uint16_t)(maxkey & 0x7fffu) : (uint16_t)~maxkey;
+    const float zmax = bf2f(maxbits) * inv_temp;
+    auto weight = [&](uint16_t b) -> unsigned long long {              // exp(z - zmax) scaled to 2^44, >= 1 so no token vanishes
+        const float e = __expf(bf2f(b) * inv_temp - zmax);
+        return (unsigned long long)(e * 17592186044416.0f) + 1ull;
+    };
+    uint32_t key_k = 0;
+    // ---------------- top-k: the k-th largest key
+    if (top_k > 0 && top_k < V) {
+        cnt[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) atomicAdd(&cnt[bf16_order_key(x[i]) >> 8], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0; int hb = 255;
+            for (; hb > 0; --hb) { if (cum + cnt[hb] >= (uint32_t)top_k) break; cum += cnt[hb]; }
+            s_sel[0] = hb; s_sel[1] = (uint32_t)top_k - cum;           // rank still needed inside bucket hb
+        }
+        __syncthreads();
+        const uint32_t hb = s_sel[0], need = s_sel[1];
+        __syncthreads();
+        cnt[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) { const uint32_t k = bf16_order_key(x[i]); if ((k >> 8) == hb) atomicAdd(&cnt[k & 255], 1u); }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0; int lb = 255;
+            for (; lb > 0; --lb) { cum += cnt[lb]; if (cum >= need) break; }
+            s_sel[0] = (hb << 8) | (uint32_t)lb;
+        }
+        __syncthreads();
+        key_k = s_sel[0];
+        __syncthreads();
+    }
+    uint32_t thr = key_k;
+    // ---------------- top-p over the tokens that survived top-k
+    if (top_p < 1.f) {
+        mass[tid] = 0ull;
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) {
+            const uint16_t b = x[i];
+            const uint32_t k = bf16_order_key(b);
+            if (k >= key_k && (b & 0x7fffu) <= 0x7f80u) atomicAdd(&mass[k >> 8], weight(b));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int h = 0; h < 256; ++h) tot += (double)mass[h];
+            const double target = (double)top_p * tot;
+            double cum = 0.0; int hb = 255;
+            for (; hb > 0; --hb) { if (cum + (double)mass[hb] >= target) break; cum += (double)mass[hb]; }
+            s_sel[0] = hb; s_target = target - cum;                    // mass still needed inside bucket hb
+        }
+        __syncthreads();
+        const uint32_t hb = s_sel[0];
+        __syncthreads();
+        mass[tid] = 0ull;
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) {
+            const uint16_t b = x[i];
+            const uint32_t k = bf16_order_key(b);
+            if (k >= key_k && (k >> 8) == hb && (b & 0x7fffu) <= 0x7f80u) atomicAdd(&mass[k & 255], weight(b));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double cum = 0.0; int lb = 255;
+            for (; lb > 0; --lb) { cum += (double)mass[lb]; if (cum >= s_target) break; }
+            s_sel[0] = (hb << 8) | (uint32_t)lb;
+        }
+        __syncthreads();
+        thr = max(thr, s_sel[0]);
+    }
+    if (tid == 0) thr_out[row] = thr;
+}
+
 // argmax_i ( z_i / T + Gumbel_i ),  Gumbel_i = -log(-log(u_i)), u_i from a counter hash.  Each row is split over gridDim.y
 // workgroups (partials -> scratch), reduced by sample_finish_kernel; with scratch == NULL one workgroup does the whole row.
 __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict__ logits, int64_t ldl, int V, float inv_temp,
                                                     int greedy, uint64_t seed, uint64_t step_host, const int64_t* __restrict__ step_dev,
                                                     const int32_t* __restrict__ forced, int32_t* __restrict__ out_ids,
-                                                    float* __restrict__ scratch, const int32_t* __restrict__ row_ids) {
+                                                    float* __restrict__ scratch, const int32_t* __restrict__ row_ids,
+                                                    const uint32_t* __restrict__ thr) {
     const int row = blockIdx.x;
     const uint16_t* x = logits + (int64_t)row * ldl;
+    const uint32_t min_key = thr ? thr[row] : 0u;                      // top-k / top-p cut (0 = keep everything)
     float best = -INFINITY;
     int besti = 0x7fffffff;
     const uint64_t step = step_dev ? (uint64_t)step_dev[0] : step_host;
@@ -84,6 +190,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict_
     const int per = (V + gridDim.y - 1) / gridDim.y;
     const int v0 = blockIdx.y * per, v1 = min(V, v0 + per);
     for (int i = v0 + threadIdx.x; i < v1; i += 256) {
+        if (min_key && bf16_order_key(x[i]) < min_key) continue;
         float z = bf2f(x[i]) * inv_temp;
         if (!greedy) {
             const uint32_t r = mix32(key + (uint64_t)i * 0xD6E8FEB86659FD93ull);
@@ -338,11 +445,15 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
               uint64_t step, const int64_t* step_dev, const int32_t* forced, const int32_t* row_ids, int32_t* out_ids, float* scratch,
               st_stream_t stream) {
     if (!logits || !out_ids || B <= 0 || V <= 0 || temperature < 0.f) return ST_EINVAL;
-    if (top_k > 0 || top_p < 1.f) return -38;        // top-k / top-p filtering: not built yet (shipped configs use -1 / 1.0)
     const int greedy = temperature == 0.f;
-    const int splits = scratch ? 16 : 1;                       // scratch: B * 16 * 2 floats
+    const int splits = scratch ? 16 : 1;                       // scratch: B * 16 * 2 floats (+ B threshold words when filtering)
+    const bool filter = !greedy && ((top_k > 0 && top_k < V) || top_p < 1.f);
+    if (filter && (!scratch || top_p <= 0.f)) return ST_EINVAL;
+    uint32_t* thr = filter ? reinterpret_cast<uint32_t*>(scratch + (int64_t)B * 32) : nullptr;
+    if (filter)
+        hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, 1.f / temperature, top_k, top_p, thr);
     hipLaunchKernelGGL(sample_kernel, dim3(B, splits), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature,
-                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids);
+                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids, thr);
     if (scratch)
         hipLaunchKernelGGL(sample_finish_kernel, dim3(st_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, scratch, splits, forced, out_ids, B);
     ST_CHECK_LAUNCH();

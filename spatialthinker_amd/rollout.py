@@ -42,7 +42,7 @@ class Generator:
     def generate(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
                  eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
                  image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
-                 sync_every: int = 32, use_graph: bool = True) -> torch.Tensor:
+                 sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0) -> torch.Tensor:
         """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
         pixel_values[i] (N_i, 1176) / image_grid_thw[i] (1, 3).  Returns responses (b*n, max_new_tokens) int64 on the
         device, prompt-major, padded with pad_token_id after the first EOS (vllm_rollout_spmd.py:144-147).
@@ -65,7 +65,7 @@ class Generator:
                                           pixel_values=None if pixel_values is None else pixel_values[i0:i1],
                                           image_grid_thw=None if image_grid_thw is None else image_grid_thw[i0:i1],
                                           forced_lengths=None if forced_lengths is None else np.asarray(forced_lengths)[i0 * n:i1 * n],
-                                          ignore_eos=ignore_eos, sync_every=sync_every, use_graph=use_graph))
+                                          ignore_eos=ignore_eos, sync_every=sync_every, use_graph=use_graph, top_k=top_k, top_p=top_p))
             return torch.cat(outs, 0)
         if pos_np.ndim == 2:
             pos_np = np.repeat(pos_np[:, None, :], 3, 1)
@@ -177,7 +177,7 @@ class Generator:
                 forced = None
                 if forced_len is not None:
                     forced = torch.where(forced_len == step_t + 1, int(eos[0]), -1).to(I32)
-                ops.sample(logits[:Ba], temperature, seed, forced=forced, step_dev=step_t, out=tok32, row_ids=S_t)
+                ops.sample(logits[:Ba], temperature, seed, forced=forced, step_dev=step_t, out=tok32, row_ids=S_t, top_k=top_k, top_p=top_p)
                 tok = tok32.to(I64)
                 live = active.bool()
                 out_l.scatter_(1, step_t.expand(Ba, 1), torch.where(live, tok, pad_t)[:, None])

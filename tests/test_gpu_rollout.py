@@ -137,3 +137,37 @@ def test_sampler_distribution():
     forced = torch.full((B,), -1, dtype=torch.int32); forced[5] = 6
     t = ops.sample(logits, 1.0, seed=3, step=0, forced=forced.cuda()).cpu().numpy()
     assert t[5] == 6
+
+
+@pytest.mark.parametrize("top_k,top_p", [(5, 1.0), (-1, 0.7), (20, 0.9), (1, 1.0)])
+def test_top_k_top_p_sampling_support_and_distribution(top_k, top_p):
+    """vLLM filter order (top-k, then top-p on the renormalised rest, ties with the cut value kept): every sample lies in the
+    numpy-derived support and the empirical distribution matches the renormalised softmax (chi-square)."""
+    from spatialthinker_amd import ops
+    rs = np.random.RandomState(top_k * 7 + int(top_p * 100))
+    V, N, T = 300, 6000, 0.8
+    z = torch.from_numpy((rs.standard_normal(V) * 2.0).astype(np.float32)).bfloat16()
+    zf = z.float().numpy().astype(np.float64) / T
+    p = np.exp(zf - zf.max()); p /= p.sum()
+    keep = np.ones(V, dtype=bool)
+    if top_k > 0:
+        kth = np.sort(zf)[::-1][top_k - 1]
+        keep &= zf >= kth
+    if top_p < 1.0:
+        q = np.where(keep, p, 0.0); q /= q.sum()
+        vals = np.unique(zf[keep])[::-1]                       # distinct values, descending; whole value-buckets are kept
+        cum, cut = 0.0, vals[-1]
+        for v_ in vals:
+            cum += q[(zf == v_) & keep].sum()
+            if cum >= top_p - 1e-12:
+                cut = v_; break
+        keep &= zf >= cut
+    q = np.where(keep, p, 0.0); q /= q.sum()
+    logits = z[None, :].repeat(N, 1).cuda().contiguous()
+    tok = ops.sample(logits, T, seed=3, step=1, top_k=top_k, top_p=top_p).cpu().numpy()
+    assert keep[tok].all(), (np.unique(tok[~keep[tok]]), keep.sum())
+    cnt = np.bincount(tok, minlength=V).astype(np.float64)
+    sel = q * N >= 5
+    chi2 = ((cnt[sel] - q[sel] * N) ** 2 / (q[sel] * N)).sum()
+    dof = max(int(sel.sum()) - 1, 1)
+    assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)

@@ -109,8 +109,7 @@ class FSDPWorker:
         over = {k: prompts.meta_info[k] for k in ("temperature", "n", "top_p", "top_k", "ignore_eos") if k in prompts.meta_info}
         n = int(over.get("n", r.n))
         temperature = float(over.get("temperature", r.temperature))
-        if float(over.get("top_p", r.top_p)) < 1.0 or int(over.get("top_k", r.top_k)) > 0:
-            raise NotImplementedError("top_p < 1 / top_k > 0 sampling is not built yet (shipped configs use 1.0 / -1)")
+        top_p, top_k = float(over.get("top_p", r.top_p)), int(over.get("top_k", r.top_k))
         ids, mask, pos = prompts.batch["input_ids"], prompts.batch["attention_mask"], prompts.batch["position_ids"]
         mm = prompts.non_tensor_batch.get("multi_modal_inputs")
         px = gr = None
@@ -122,7 +121,7 @@ class FSDPWorker:
         resp = self.generator.generate(ids, mask, pos, n=n, max_new_tokens=r.response_length, temperature=temperature,
                                        eos_token_id=eos, pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls,
                                        pixel_values=px, image_grid_thw=gr, ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)),
-                                       forced_lengths=prompts.meta_info.get("synthetic_response_lengths")).cpu()
+                                       forced_lengths=prompts.meta_info.get("synthetic_response_lengths"), top_k=top_k, top_p=top_p).cpu()
         # post-processing of vllm_rollout_spmd.py:144-188
         if n > 1:
             ids, mask, pos = (t.repeat_interleave(n, dim=0) for t in (ids, mask, pos))

@@ -31,7 +31,7 @@ PEAK_HBM = 8.0e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="7b", choices=["7b", "3b", "tiny"])
     ap.add_argument("--prompts-per-gpu", type=int, default=64,

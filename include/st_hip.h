@@ -256,6 +256,7 @@ int st_add_bf16(const st_bf16* a, const st_bf16* b, st_bf16* out, int64_t n, st_
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p,
               uint64_t seed, uint64_t step, const int64_t* step_dev, const int32_t* forced,
               const int32_t* row_ids /* NULL or (B,): identity of each row for the RNG key (stable under batch compaction) */,
+              const int32_t* row_steps /* NULL or (B,): per-row step overriding step/step_dev (rows at different response indices) */,
               int32_t* out_ids, float* scratch, st_stream_t stream);
 
 #ifdef __cplusplus

@@ -176,13 +176,15 @@ __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict_
                                                     int greedy, uint64_t seed, uint64_t step_host, const int64_t* __restrict__ step_dev,
                                                     const int32_t* __restrict__ forced, int32_t* __restrict__ out_ids,
                                                     float* __restrict__ scratch, const int32_t* __restrict__ row_ids,
-                                                    const uint32_t* __restrict__ thr) {
+                                                    const uint32_t* __restrict__ thr, const int32_t* __restrict__ row_steps) {
     const int row = blockIdx.x;
     const uint16_t* x = logits + (int64_t)row * ldl;
     const uint32_t min_key = thr ? thr[row] : 0u;                      // top-k / top-p cut (0 = keep everything)
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    const uint64_t step = step_dev ? (uint64_t)step_dev[0] : step_host;
+    // response index of this row's token: per-row (rows of one launch may be at different positions once survivors of several
+    // waves are decoded together), else a device counter, else the host value
+    const uint64_t step = row_steps ? (uint64_t)row_steps[row] : (step_dev ? (uint64_t)step_dev[0] : step_host);
     // the stream is keyed by the sample's identity, not by its row in this launch: compacting the decode batch (dropping
     // finished samples) does not change what the survivors sample
     const uint64_t rid = row_ids ? (uint64_t)row_ids[row] : (uint64_t)row;
@@ -442,8 +444,8 @@ int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_par
 }
 
 int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
-              uint64_t step, const int64_t* step_dev, const int32_t* forced, const int32_t* row_ids, int32_t* out_ids, float* scratch,
-              st_stream_t stream) {
+              uint64_t step, const int64_t* step_dev, const int32_t* forced, const int32_t* row_ids, const int32_t* row_steps,
+              int32_t* out_ids, float* scratch, st_stream_t stream) {
     if (!logits || !out_ids || B <= 0 || V <= 0 || temperature < 0.f) return ST_EINVAL;
     const int greedy = temperature == 0.f;
     const int splits = scratch ? 16 : 1;                       // scratch: B * 16 * 2 floats (+ B threshold words when filtering)
@@ -453,7 +455,7 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
     if (filter)
         hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, 1.f / temperature, top_k, top_p, thr);
     hipLaunchKernelGGL(sample_kernel, dim3(B, splits), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature,
-                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids, thr);
+                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids, thr, row_steps);
     if (scratch)
         hipLaunchKernelGGL(sample_finish_kernel, dim3(st_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, scratch, splits, forced, out_ids, B);
     ST_CHECK_LAUNCH();

@@ -451,12 +451,12 @@ def kv_append_(qkv, col_k, col_v, width, kg, vg, gen_len, active=None, increment
                        int(increment), _s())
 
 
-def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, step_dev=None, out=None, row_ids=None):
+def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, step_dev=None, out=None, row_ids=None, row_steps=None):
     B, V = logits.shape
     out = torch.empty(B, dtype=I32, device=logits.device) if out is None else out
     scratch = torch.empty(B * 33, dtype=F32, device=logits.device)
     lib().st_sample(_p(logits), logits.stride(0), B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step), _p(step_dev),
-                    _p(forced), _p(row_ids), _p(out), _p(scratch), _s())
+                    _p(forced), _p(row_ids), _p(row_steps), _p(out), _p(scratch), _s())
     return out
 
 

@@ -51,22 +51,6 @@ class Generator:
         dev = self.m.p.device
         ids_np, mask_np, pos_np = (np.asarray(x.cpu() if torch.is_tensor(x) else x) for x in (input_ids, attention_mask, position_ids))
         nb, P = ids_np.shape
-        # The decode GEMMs stream the weights once per step for up to 256 rows (above that they turn MFMA-bound and a second
-        # wave costs the same as a wider one): larger rollout batches run as waves of <= 256 sequences, each with its own
-        # prompt KV, caches and decode graph.
-        per_wave = max(1, self.max_decode_batch // n)
-        if nb > per_wave:
-            outs = []
-            for wv, i0 in enumerate(range(0, nb, per_wave)):
-                i1 = min(nb, i0 + per_wave)
-                outs.append(self.generate(ids_np[i0:i1], mask_np[i0:i1], pos_np[i0:i1], n=n, max_new_tokens=max_new_tokens,
-                                          temperature=temperature, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
-                                          seed=seed + 7919 * wv,
-                                          pixel_values=None if pixel_values is None else pixel_values[i0:i1],
-                                          image_grid_thw=None if image_grid_thw is None else image_grid_thw[i0:i1],
-                                          forced_lengths=None if forced_lengths is None else np.asarray(forced_lengths)[i0 * n:i1 * n],
-                                          ignore_eos=ignore_eos, sync_every=sync_every, use_graph=use_graph, top_k=top_k, top_p=top_p))
-            return torch.cat(outs, 0)
         if pos_np.ndim == 2:
             pos_np = np.repeat(pos_np[:, None, :], 3, 1)
         B, R = nb * n, max_new_tokens
@@ -108,30 +92,28 @@ class Generator:
         out = torch.full((B, R), pad_token_id, dtype=I64, device=dev)
         kg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
         vg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
-        gen_len_g = torch.zeros(B, dtype=I32, device=dev)
+        gen_len_g = torch.zeros(B, dtype=I32, device=dev)      # tokens generated so far = response index of the next token
         last_pos = torch.from_numpy(np.ascontiguousarray(pos_np[:, :, -1].T)).to(dev, I32).repeat_interleave(n, dim=1)   # (3, B)
         pos_g = (last_pos + 1).contiguous()                    # position of the token sampled at response index 0
         eos_t = torch.tensor(eos, device=dev, dtype=I64)
-        forced_len_g = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I64)
+        forced_len_g = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I32)
         CK = 256
         C = max(1, int(-(-int(lens.max()) // CK)))
         Cg = max(1, -(-R // CK))
         NP = C + Cg
         pb, pe = p_off[:-1].astype(np.int64), p_off[1:].astype(np.int64)
         ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
-        Bfull = ix.round_up(B, 32) if B <= 256 else ix.round_up(B, 128)   # decode GEMMs take the skinny path for M <= 256
-        logits0 = torch.empty(B, c.vocab_size, dtype=BF16, device=dev)
-        ops.gemm_nt(hn, head, out=logits0)
-        step_t = torch.zeros(1, dtype=I64, device=dev)
+        logits_g = torch.empty(B, c.vocab_size, dtype=BF16, device=dev)        # pending logits of every sample
+        ops.gemm_nt(hn, head, out=logits_g)
         can_fuse = self.fused_decode and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
-        if self.autotune and Bfull <= 256:
-            self._tune_decode(Bfull)
+        wave = max(1, self.max_decode_batch)
+        if self.autotune and wave <= 256:
+            self._tune_decode(ix.round_up(min(B, wave), 32))
 
-        def decode_phase(S_np: np.ndarray, logits_in: torch.Tensor, step0: int):
-            """Decode the samples S_np (sorted ids) from response index step0 until they are all finished, the length cap is hit,
-            or fewer than half of the phase's rows are still live (then the caller starts a new, narrower phase with the
-            survivors: finished rows would otherwise keep occupying the GEMM tiles for the rest of the generation).
-            Returns (next_step, survivors (np ids), their pending logits)."""
+        def decode_phase(S_np: np.ndarray, until_half: bool):
+            """Decode the samples S_np (sorted ids; they may sit at different response indices) until none is live or — with
+            until_half — at most half of the phase's rows are (finished rows would otherwise keep occupying the GEMM tiles; the
+            caller re-batches the survivors, possibly together with those of other waves).  Returns the surviving ids."""
             Ba = len(S_np)
             Bp = ix.round_up(Ba, 32) if Ba <= 256 else ix.round_up(Ba, 128)
             fused = can_fuse and Bp <= 256
@@ -166,27 +148,33 @@ class Generator:
             abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # attention output, pad rows stay zero
             qbuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # roped queries of the fused path (pad rows stay zero)
             logits = torch.empty(Bp if Bp <= 256 else Ba, c.vocab_size, dtype=BF16, device=dev)
-            logits[:Ba].copy_(logits_in)
+            logits[:Ba].copy_(logits_g[S_l])
             tok32 = torch.zeros(Ba, dtype=I32, device=dev)
             pad_t = torch.full((Ba,), pad_token_id, dtype=I64, device=dev)
             kgv, vgv = kg.view(L, B * R, width), vg.view(L, B * R, width)
+            s_first = int(S_np[0])
+            assert fused or np.array_equal(S_np, np.arange(s_first, s_first + Ba)), "the unfused path decodes contiguous waves only"
 
             def iteration():
                 """sample -> record -> one decode forward for the phase's rows -> next logits.  Device state only (graph-capturable).
-                Finished rows keep computing on their last token until the phase is compacted; their output is ignored."""
+                Finished rows keep computing on their last token until the phase is re-batched; their output is ignored."""
                 forced = None
                 if forced_len is not None:
-                    forced = torch.where(forced_len == step_t + 1, int(eos[0]), -1).to(I32)
-                ops.sample(logits[:Ba], temperature, seed, forced=forced, step_dev=step_t, out=tok32, row_ids=S_t, top_k=top_k, top_p=top_p)
+                    forced = torch.where(forced_len == gen_len + 1, int(eos[0]), -1).to(I32)
+                ops.sample(logits[:Ba], temperature, seed, forced=forced, row_steps=gen_len, out=tok32, row_ids=S_t, top_k=top_k, top_p=top_p)
                 tok = tok32.to(I64)
                 live = active.bool()
-                out_l.scatter_(1, step_t.expand(Ba, 1), torch.where(live, tok, pad_t)[:, None])
+                col = gen_len.clamp(max=R - 1).long()[:, None]
+                out_l.scatter_(1, col, torch.where(live, tok, out_l.gather(1, col)[:, 0])[:, None])
+                stop = gen_len + 1 >= R                                             # the length cap ends a sample like an EOS
                 if not ignore_eos:
-                    active.copy_((live & ~(tok[:, None] == eos_t[None, :]).any(1)).to(I32))
+                    stop = stop | (tok[:, None] == eos_t[None, :]).any(1)
+                active.copy_((live & ~stop).to(I32))
                 cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
                 ops.embed_gather(w["embed"], tok32, out=xbuf[:Ba])
                 x = xbuf
-                ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (gen_len + 1).repeat(Cg)), kb2).contiguous()
+                glen = gen_len.clamp(max=R - 1)                                     # finished rows at the cap rewrite their last slot
+                ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (glen + 1).repeat(Cg)), kb2).contiguous()
                 if fused:
                     # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE +
                     # cache append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue
@@ -195,7 +183,7 @@ class Generator:
                     for layer in range(L):
                         p = f"l.{layer}."
                         slabs, sp = ops.gemm_nt_decode_slabs(h1, w[p + "qkv_w"])
-                        ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], gen_len, Ba, nq, nkv, D,
+                        ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], glen, Ba, nq, nkv, D,
                                               row_map=S_t)
                         ops.attn_fwd_ranges(qbuf, kp[layer], vp[layer], qb1, qe1, kb1, ke1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
                                             o_beg=ob1, q_group=g)
@@ -217,7 +205,7 @@ class Generator:
                         h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
                         qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
                         ops.rope_apply_(qkv[:Ba], cos, sin, nq + nkv, D)
-                        ops.kv_append_(qkv[:Ba], nq * D, nq * D + width, width, kg[layer], vg[layer], gen_len)
+                        ops.kv_append_(qkv[:Ba], nq * D, nq * D + width, width, kg[layer][s_first:s_first + Ba], vg[layer][s_first:s_first + Ba], glen)
                         ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
                                             o_beg=ob1, q_group=g)
                         ops.attn_fwd_ranges(qkv, kgv[layer], vgv[layer], qb2, qe2, kb2, ke2, g, nkv, nkv, D, m.scale, parts, lse_parts,
@@ -229,38 +217,47 @@ class Generator:
                         x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
                     hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
                 ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits)
-                gen_len.add_(1); pos.add_(1); step_t.add_(1)
+                gen_len.add_(1); pos.add_(1)
 
             # the decode iteration is launch-bound (~10 launches x layers): capture it once per phase into a hipGraph and replay
-            step, graph = step0, None
-            if use_graph and R - step0 > 2:
+            graph, done = None, 0
+            if use_graph:
                 iteration()                                        # eager warm-up iteration
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     iteration()
-                step += 1                                          # capture itself does not execute
+                done = 1                                           # capture itself does not execute
             n_live = Ba
-            while step < R:
+            while True:
+                if done % sync_every == 0 or done >= R:
+                    n_live = int(active.sum().item())
+                    if n_live == 0 or (until_half and Bp > 32 and n_live <= Bp // 2):
+                        break
                 if graph is not None:
                     graph.replay()
                 else:
                     iteration()
-                step += 1
-                if (step - step0) % sync_every == 0 or step == R:
-                    n_live = int(active.sum().item())
-                    # compaction needs the sample-indexed cache append of the fused path; the unfused path keeps its rows
-                    if n_live == 0 or (self.compact and fused and Bp > 32 and n_live <= Bp // 2 and R - step > sync_every):
-                        break
+                done += 1
             out[S_l] = out_l
             gen_len_g[S_l] = gen_len
             pos_g[:, S_l] = pos
-            if n_live == 0 or step >= R:
-                return step, np.zeros(0, dtype=S_np.dtype), None
+            if n_live == 0:
+                return np.zeros(0, dtype=S_np.dtype)
             keep = active.bool()
-            return step, S_np[keep.cpu().numpy()], logits[:Ba][keep].contiguous()
+            logits_g[S_l[keep]] = logits[:Ba][keep]
+            return S_np[keep.cpu().numpy()]
 
-        S, lg, step = np.arange(B, dtype=np.int64), logits0, 0
-        while len(S):
-            step, S, lg = decode_phase(S, lg, step)
+        # ---------------- scheduler: fresh waves of <= max_decode_batch samples run until half of their rows have finished; the
+        # survivors of all waves are then decoded TOGETHER (they sit at different response indices: every row carries its own
+        # step), re-batched again each time half of them are done — one short tail for the whole rollout batch instead of one
+        # per wave.  (The unfused path has no sample-indexed cache append: its waves simply run to completion.)
+        compact = self.compact and can_fuse and wave <= 256
+        pool = np.zeros(0, dtype=np.int64)
+        for s0 in range(0, B, wave):
+            S = np.arange(s0, min(B, s0 + wave), dtype=np.int64)
+            pool = np.concatenate([pool, decode_phase(S, until_half=compact)])
+        while len(pool):
+            S, pool = np.sort(pool[:wave]), pool[wave:]
+            pool = np.concatenate([pool, decode_phase(S, until_half=len(S) > 32)])
         return out

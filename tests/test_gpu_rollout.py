@@ -99,6 +99,29 @@ def test_decode_batch_compaction_keeps_samples_and_layout(env):
     assert same >= 0.9, same
 
 
+def test_waves_and_pooled_survivors_match_single_wave(env):
+    """Rollout batches wider than max_decode_batch run as waves whose survivors are pooled and decoded together (rows at
+    different response indices): same samples as one wide wave up to last-bit GEMM-plan differences."""
+    from spatialthinker_amd.rollout import Generator
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    n, R = 48, 20
+    rs = np.random.RandomState(1)
+    lens = np.where(rs.rand(2 * n) < 0.5, rs.randint(2, 7, 2 * n), rs.randint(12, R + 1, 2 * n)).astype(np.int64)
+    kw = dict(n=n, max_new_tokens=R, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID, seed=4,
+              pixel_values=pix, image_grid_thw=grids, forced_lengths=lens, sync_every=4)
+    g_waves = Generator(eng); g_waves.max_decode_batch = 64
+    g_one = Generator(eng); g_one.compact = False
+    a = g_waves.generate(ids, mask, pos, **kw).cpu().numpy()
+    b = g_one.generate(ids, mask, pos, **kw).cpu().numpy()
+    for o in (a, b):
+        for r in range(2 * n):
+            e = int(np.argmax(o[r] == tiny.EOS_ID))
+            assert o[r, e] == tiny.EOS_ID and e <= int(lens[r]) - 1 and np.all(o[r, e + 1:] == tiny.PAD_ID)
+    same = np.mean([np.array_equal(a[r], b[r]) for r in range(2 * n)])
+    assert same >= 0.9, same
+
+
 def test_eos_stops_and_pads_and_forced_lengths(env):
     cfg, params, eng, gen = env
     ids, mask, pos, pix, grids = _prompts()

@@ -12,6 +12,7 @@ graph = (sys.argv[3] == "graph") if len(sys.argv) > 3 else True
 cfg = VLConfig.qwen2_5_vl_7b()
 st = ParamStore(cfg, trainable=False); st.init_random(1)
 gen = Generator(Qwen25VL(cfg, st), autotune=(os.environ.get("ST_TUNE", "0") == "1"))
+gen.max_decode_batch = int(os.environ.get("ST_MAX_DECODE", "256"))
 rs = np.random.RandomState(0)
 ids, mask, pos, pix, grids = synth_prompts(cfg, npr, rs, 1152, (1, 32, 42))
 for it in range(2):

@@ -125,6 +125,11 @@ int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16
 int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                       const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc, float* scratch,
                       int64_t scratch_elems, int M, int N, int K, st_stream_t stream);
+/* gate/up projection + SwiGLU in one kernel for any M (training forward, no-grad log-prob passes, prefill):
+ * m_out[M, I] = silu(A gate_w^T) * (A up_w^T); gu_out (NULL or [M, 2I]) also receives the bf16 gate|up projections the
+ * backward needs (st_swiglu_bwd).  Bit-identical to st_gemm_nt + st_swiglu_fwd (HF Qwen2MLP.forward). */
+int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* gu_out, int64_t ldgu,
+                   st_bf16* m_out, int64_t ldm, int M, int I, int K, st_stream_t stream);
 /* Decode MLP up-projection with the SwiGLU fused into the GEMM epilogue (M <= 256):
  * out[M, I] = silu(A gate_w^T) * (A up_w^T) with gate_up_w = [gate_w ; up_w] (2I x K, the fused layout of ParamStore);
  * same bf16 rounding points as st_gemm_nt + st_swiglu_fwd (HF Qwen2MLP.forward), bit-identical to that pair. */

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     const int nk = min(K / 64 - kt_begin, kt_per_split);
     A += kt_begin * 64;
     B += kt_begin * 64;
-    if (!OUT_BF16) Cf += blockIdx.y * slab_stride;
+    if (!OUT_BF16 && !SWIGLU) Cf += blockIdx.y * slab_stride;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);
 
@@ -257,11 +257,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             for (int ni = 0; ni < TN; ni += 2) {
                 const int n = n0 + wn * (WTN / 2) + (ni / 2) * 16 + (lane >> 4) * 4;
                 if (n >= N) continue;
-                uint16_t o[4];
+                uint16_t o[4], gq[4], uq[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {               // same roundings as the unfused path: bf16 gate/up, bf16 act(gate)
-                    const float g = bfround(acc[ni][mi][r]), u = bfround(acc[ni + 1][mi][r]);
+                    gq[r] = f2bf(acc[ni][mi][r]); uq[r] = f2bf(acc[ni + 1][mi][r]);
+                    const float g = bf2f(gq[r]), u = bf2f(uq[r]);
                     o[r] = f2bf(bfround(g * sigmoidf_(g)) * u);
+                }
+                if (Cf) {                                    // training: keep gate|up (N + N columns) for the backward; ld in `ldr`
+                    uint16_t* gp = reinterpret_cast<uint16_t*>(Cf) + (int64_t)m * ldr + n;
+                    if (n + 3 < N && ((ldr & 3) == 0) && ((N & 3) == 0)) {
+                        uint2 w;
+                        w.x = (uint32_t)gq[0] | ((uint32_t)gq[1] << 16); w.y = (uint32_t)gq[2] | ((uint32_t)gq[3] << 16);
+                        *reinterpret_cast<uint2*>(gp) = w;
+                        w.x = (uint32_t)uq[0] | ((uint32_t)uq[1] << 16); w.y = (uint32_t)uq[2] | ((uint32_t)uq[3] << 16);
+                        *reinterpret_cast<uint2*>(gp + N) = w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < N) { gp[r] = gq[r]; gp[N + r] = uq[r]; }
+                    }
                 }
                 uint16_t* cp = Cb + (int64_t)m * ldc + n;
                 if (n + 3 < N && ((ldc & 3) == 0)) {
@@ -400,21 +414,34 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
 #undef DEC_GO
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool MB = false>
 static int launch_tile_swiglu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N,
-                              int K, hipStream_t s) {
+                              int K, hipStream_t s, uint16_t* gu = nullptr, int64_t ldgu = 0) {
     constexpr int smem = STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true, MB>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
     const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN / 2);
+    // SWIGLU mode: the fp32-output pointer slot carries the optional bf16 gate|up buffer, the residual stride slot its row stride
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr,
-                       (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0);
+                       (const uint16_t*)nullptr, ldgu, Cb, reinterpret_cast<float*>(gu), ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+/* gate/up projection with the SwiGLU in the epilogue for any M (training / prefill): m_out[M, I] = silu(A gate_w^T) * (A up_w^T);
+ * gu_out (optional, [M, 2I]) additionally receives the bf16 gate|up values the backward needs. */
+extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* gu_out, int64_t ldgu,
+                              st_bf16* m_out, int64_t ldm, int M, int I, int K, st_stream_t stream) {
+    if (!A || !gate_up_w || !m_out || M <= 0 || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldm < I ||
+        (gu_out && ldgu < 2 * (int64_t)I) || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)(2 * I) * (double)K);
+    return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, m_out, ldm, M, I, K, s, gu_out, ldgu);
 }
 
 extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,

@@ -494,8 +494,7 @@ class Qwen25VL:
         _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a)
         x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x0)
         h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
-        gu = ops.gemm_nt(h2, w[p + "gu_w"])
-        m = ops.swiglu_fwd(gu)
+        gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)      # SwiGLU in the epilogue; gate|up kept only for backward
         x2 = ops.gemm_nt(m, w[p + "down_w"], residual=x1)
         if save is not None:
             save.append((x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m))

@@ -271,6 +271,18 @@ def gemm_swiglu_decode(a, gate_up_w, out=None):
     return out
 
 
+def gemm_swiglu(a, gate_up_w, want_gu=True):
+    """(gu, m): m[M, I] = silu(a @ gate_w^T) * (a @ up_w^T) with the SwiGLU in the GEMM epilogue; gu [M, 2I] (bf16 gate|up) only
+    when the backward needs it."""
+    M, K = a.shape
+    I = gate_up_w.shape[0] // 2
+    m = torch.empty(M, I, dtype=BF16, device=a.device)
+    gu = torch.empty(M, 2 * I, dtype=BF16, device=a.device) if want_gu else None
+    lib().st_gemm_swiglu(_p(a), a.stride(0), _p(gate_up_w), gate_up_w.stride(0), _p(gu), gu.stride(0) if gu is not None else 0,
+                         _p(m), m.stride(0), M, I, K, _s())
+    return gu, m
+
+
 def gemm_nt_variant(variant, a, b, out=None, out_f32=None, accumulate=False, bias=None, residual=None):
     M, K = a.shape
     N = b.shape[0]

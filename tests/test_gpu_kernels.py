@@ -500,3 +500,17 @@ def test_attn_seg_shared_prefix_fwd_bwd(ops, groups):
     for name, got, want in (("dq", dq, gr[:, :n_q * D]), ("dk", dk, gr[:, n_q * D:(n_q + n_kv) * D]), ("dv", dv, gr[:, (n_q + n_kv) * D:])):
         err = float((got.float().cpu()[:T] - want[:T]).abs().max())
         assert err < 0.02 * float(want.abs().max()) + 1e-2, (name, err, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("M_,I,K", [(517, 1216, 256), (300, 200, 128), (1024, 4096, 512)])
+def test_gemm_swiglu_fused_epilogue_bit_identical(ops, M_, I, K):
+    """gate/up GEMM with the SwiGLU in the epilogue (training forward): m and the kept gate|up equal st_gemm_nt + st_swiglu_fwd."""
+    rs = np.random.RandomState(M_ + I)
+    a = bf(rs.standard_normal((M_, K))).cuda()
+    w = bf(rs.standard_normal((2 * I, K)) * 0.1).cuda()
+    gu_ref = ops.gemm_nt_variant(6, a, w) if M_ > 256 else ops.gemm_nt_variant(0, a, w)
+    m_ref = ops.swiglu_fwd(gu_ref)
+    gu, m = ops.gemm_swiglu(a, w, want_gu=True)
+    assert torch.equal(gu, gu_ref) and torch.equal(m, m_ref)
+    gu2, m2 = ops.gemm_swiglu(a, w, want_gu=False)
+    assert gu2 is None and torch.equal(m2, m_ref)

@@ -13,6 +13,9 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+import time
+
 import numpy as np
 import torch
 
@@ -253,11 +256,21 @@ class Generator:
         # step), re-batched again each time half of them are done — one short tail for the whole rollout batch instead of one
         # per wave.  (The unfused path has no sample-indexed cache append: its waves simply run to completion.)
         compact = self.compact and can_fuse and wave <= 256
+        debug = bool(os.environ.get("ST_GEN_DEBUG"))
         pool = np.zeros(0, dtype=np.int64)
+
+        def run(S, until_half):
+            if debug:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = decode_phase(S, until_half)
+            if debug:
+                torch.cuda.synchronize()
+                print(f"[gen] phase rows={len(S)} -> survivors={len(r)} in {time.perf_counter() - t0:.3f}s", flush=True)
+            return r
         for s0 in range(0, B, wave):
             S = np.arange(s0, min(B, s0 + wave), dtype=np.int64)
-            pool = np.concatenate([pool, decode_phase(S, until_half=compact)])
+            pool = np.concatenate([pool, run(S, compact)])
         while len(pool):
             S, pool = np.sort(pool[:wave]), pool[wave:]
-            pool = np.concatenate([pool, decode_phase(S, until_half=len(S) > 32)])
+            pool = np.concatenate([pool, run(S, len(S) > 32)])
         return out

@@ -1,0 +1,99 @@
+"""Parity at the REAL Qwen2.5-VL-7B dimensions (hidden 3584, 28/4 heads x 128, MLP 18944, vocab 152064, ViT 1280/16 heads/3420)
+on a depth-reduced model (1 LM layer, 2 ViT blocks): the kernels take their production dispatch paths (256x256 GEMM tiles,
+fused SwiGLU epilogue, shared-prefix attention over a rollout group, 152k-wide log-prob rows) and are checked against the fp32
+CPU oracle run sequence by sequence, forward and backward.  Tolerances as in test_gpu_model.py (bf16 evaluation error)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tiny  # noqa: E402
+from oracle import positions as P  # noqa: E402
+from oracle import qwen25vl as Q  # noqa: E402
+from oracle import rl_math as M  # noqa: E402
+
+FULL = dict(hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28, num_kv_heads=4, vocab_size=152064,
+            rms_eps=1e-6, rope_theta=1e6, mrope_section=[16, 24, 24], tie_word_embeddings=False,
+            v_depth=2, v_hidden=1280, v_heads=16, v_intermediate=3420, v_patch=14, v_temporal_patch=2, v_merge=2, v_window=112,
+            v_fullatt=[1], v_in_channels=3, image_token_id=151655, vision_start_token_id=151652)
+VISION_END, EOS = 151653, 151645
+
+
+def _params(seed=3):
+    """Cheap deterministic bf16-exact weights (the big tables from a ramp: value quality is irrelevant, cost is not)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shape in tiny.param_shapes(FULL).items():
+        n = int(np.prod(shape))
+        if "norm" in name or "ln_q" in name:
+            w = 1.0 + 0.1 * rs.standard_normal(shape)
+        elif name.endswith(".bias"):
+            w = 0.02 * rs.standard_normal(shape)
+        elif n > (1 << 24):
+            w = (((np.arange(n, dtype=np.int64) * 2654435761) % 2039).astype(np.float32) / 2039.0 - 0.5).reshape(shape) * 0.04
+        else:
+            w = 0.02 * rs.standard_normal(shape)
+        out[name] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).bfloat16().float().numpy()
+    return out
+
+
+def _group_batch(rs, n_roll=3, text=(40, 60), grid=(1, 16, 20), R=48, Pc=256):
+    """One prompt (text + 16x20-patch image = 80 image tokens) with n_roll rollouts of different lengths."""
+    n_img = grid[0] * grid[1] * grid[2] // 4
+    prompt = (rs.randint(0, 150000, text[0]).tolist() + [FULL["vision_start_token_id"]] + [FULL["image_token_id"]] * n_img + [VISION_END]
+              + rs.randint(0, 150000, text[1]).tolist())
+    ids = np.full((n_roll, Pc + R), 151643, dtype=np.int64)
+    mask = np.zeros((n_roll, Pc + R), dtype=np.int64)
+    for r in range(n_roll):
+        ids[r, Pc - len(prompt):Pc] = prompt; mask[r, Pc - len(prompt):Pc] = 1
+        L = int(rs.randint(8, R + 1))
+        ids[r, Pc:Pc + L] = rs.randint(0, 150000, L - 1).tolist() + [EOS]; mask[r, Pc:Pc + L] = 1
+    px = rs.standard_normal((grid[0] * grid[1] * grid[2], 1176)).astype(np.float32)
+    g = np.asarray([grid], dtype=np.int64)
+    pos = np.stack([P.mrope_position_ids(ids[r], g, mask[r], image_token_id=FULL["image_token_id"],
+                                         vision_start_token_id=FULL["vision_start_token_id"]) for r in range(n_roll)])
+    return ids, mask, pos, px, g, R
+
+
+def test_7b_dimension_layer_shared_prompt_vs_oracle_fwd_bwd():
+    from spatialthinker_amd import model as mdl
+    rs = np.random.RandomState(17)
+    params = _params()
+    cfg = mdl.VLConfig(**FULL)
+    store = mdl.ParamStore(cfg, trainable=True)
+    store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = mdl.Qwen25VL(cfg, store)
+    ids, mask, pos, px, g, R = _group_batch(rs)
+    k = ids.shape[0]
+    rmask = mask[:, -R:]
+    # ---- oracle: every rollout as its own full sequence (the reference's formulation), fp32 CPU autograd
+    p32 = {n_: torch.from_numpy(v).clone().requires_grad_(n_.endswith(("gate_proj.weight", "q_proj.weight", "o_proj.weight",
+                                                                         "input_layernorm.weight", "merger.mlp.2.weight")))
+           for n_, v in params.items()}
+    ocfg = Q.VLConfig(**FULL)
+    lp = Q.response_log_probs(p32, ocfg, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), R, 1.0,
+                              torch.from_numpy(np.concatenate([px] * k, 0)), np.concatenate([g] * k, 0))
+    old = (lp.detach().numpy() + 0.2 * rs.standard_normal((k, R))).astype(np.float32)
+    adv = rs.standard_normal((k, 1)).astype(np.float32).repeat(R, 1) * rmask
+    _, gl = M.actor_micro_batch_loss(lp.detach().numpy(), old, old, adv, rmask, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1)
+    lp.backward(torch.from_numpy(gl))
+    # ---- engine: one rollout group behind a single prompt copy
+    b = eng.stage(ids, mask, pos, R, px, g, groups=[0] * k)
+    assert b.pk.T < 0.55 * int(mask.sum())
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    store.grad.zero_()
+    lp_e, _ = eng.forward_backward(b, dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64)),
+                                   1.0, clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
+    m = rmask.astype(bool)
+    err = np.abs(lp_e.cpu().numpy()[m] - lp.detach().numpy()[m]).max()
+    print(f"7B-dimension layer: max |dlogp| vs fp32 oracle = {err:.4f}")
+    assert err < 6e-2
+    grads = store.export_hf(store.g)
+    for n_, t in p32.items():
+        if t.grad is None:
+            continue
+        want, got = t.grad.numpy(), grads[n_].float().cpu().numpy()
+        rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-20)
+        print(f"  grad {n_}: rel err {rel:.4f}")
+        assert rel < 8e-2, (n_, rel)

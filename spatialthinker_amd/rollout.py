@@ -100,9 +100,11 @@ class Generator:
         pos_g = (last_pos + 1).contiguous()                    # position of the token sampled at response index 0
         eos_t = torch.tensor(eos, device=dev, dtype=I64)
         forced_len_g = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I32)
-        CK = 256
+        # split-KV chunk sizes of the decode attention (keys per workgroup): prompt keys / generated keys
+        CK = int(os.environ.get("ST_DECODE_CKP", "256"))
+        CKG = int(os.environ.get("ST_DECODE_CKG", "256"))
         C = max(1, int(-(-int(lens.max()) // CK)))
-        Cg = max(1, -(-R // CK))
+        Cg = max(1, -(-R // CKG))
         NP = C + Cg
         pb, pe = p_off[:-1].astype(np.int64), p_off[1:].astype(np.int64)
         ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
@@ -143,7 +145,7 @@ class Generator:
             # generated partial: one "sequence" per (key chunk c, local row); chunks beyond the current length are empty ranges
             qb2 = (ar * g).repeat(Cg).contiguous(); qe2 = qb2 + g
             kbase = (S_t * R).repeat(Cg)
-            kb2 = (kbase + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(Ba) * CK).contiguous()
+            kb2 = (kbase + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(Ba) * CKG).contiguous()
             ob2 = ((C + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(Ba)) * rows_all + (ar * g).repeat(Cg)).contiguous()
             parts = torch.empty(NP * rows_all, width, dtype=BF16, device=dev)
             lse_parts = torch.empty(nkv, NP * rows_all, dtype=F32, device=dev)
@@ -177,7 +179,7 @@ class Generator:
                 ops.embed_gather(w["embed"], tok32, out=xbuf[:Ba])
                 x = xbuf
                 glen = gen_len.clamp(max=R - 1)                                     # finished rows at the cap rewrite their last slot
-                ke2 = torch.maximum(torch.minimum(kb2 + CK, kbase + (glen + 1).repeat(Cg)), kb2).contiguous()
+                ke2 = torch.maximum(torch.minimum(kb2 + CKG, kbase + (glen + 1).repeat(Cg)), kb2).contiguous()
                 if fused:
                     # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE +
                     # cache append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue

@@ -211,8 +211,9 @@ def main():
         lens = np.clip(rs.normal(16 if tiny else 512, 4 if tiny else 128, B), 4 if tiny else 64, R).astype(np.int64)
         tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
         t0 = tick()
-        resp = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=temperature, eos_token_id=eos_id, pad_token_id=pad_id,
-                            seed=a.seed * 1000 + step_idx, pixel_values=pix, image_grid_thw=grids, forced_lengths=lens)
+        resp, prompt_cache = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=temperature, eos_token_id=eos_id,
+                                          pad_token_id=pad_id, seed=a.seed * 1000 + step_idx, pixel_values=pix, image_grid_thw=grids,
+                                          forced_lengths=lens, return_prompt_cache=True)
         t1 = tick()
         # ---- assemble the (B, P+R) batch exactly as vllm_rollout_spmd.py:144-188 does
         resp_c = resp.cpu()
@@ -229,7 +230,8 @@ def main():
         rewards = torch.zeros(B, R)
         rewards[torch.arange(B), rmask.sum(1) - 1] = scores
         t2 = tick()
-        data["old_log_probs"] = actor.compute_log_prob(data, temperature)
+        data["old_log_probs"] = actor.compute_log_prob(data, temperature, prompt_cache=prompt_cache)   # as FSDPWorker.compute_log_probs
+        del prompt_cache
         t3 = tick()
         data["ref_log_probs"] = ref.compute_log_prob(data, temperature)
         t4 = tick()
@@ -251,16 +253,18 @@ def main():
             plen = mask[:, :].sum(1)                                         # valid prompt tokens per prompt
             rlen = rmask.sum(1).tolist()
 
-            def executed(mb):
+            def executed(mb, cached=False):
                 groups = []
                 for s0 in range(0, B, mb):
                     rows = list(range(s0, min(B, s0 + mb)))
                     for pr in sorted(set(r // G for r in rows)):
                         groups.append((int(plen[pr]), [rlen[r] for r in rows if r // G == pr]))
-                return cfg.flops_forward_grouped(groups, [n_patch] * len(groups), logit_rows=int(rmask.sum()))
+                return cfg.flops_forward_grouped(groups, [] if cached else [n_patch] * len(groups), logit_rows=int(rmask.sum()),
+                                                 prefix_cached=cached)
             f_exp = executed(hyper.micro_batch_size_per_device_for_experience)
             f_upd = executed(micro * max(1, min(actor.fuse_micro_batches, (B // n_opt) // micro)))
-            flops["old"] += f_exp; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
+            f_old = executed(hyper.micro_batch_size_per_device_for_experience, cached=True)      # prompt K/V re-used from the rollout
+            flops["old"] += f_old; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
             flops["reference_formulation"] = flops.get("reference_formulation", 0.0) + 5 * f_ref
             tokens_total[0] += int(mask_f.sum())
         return metrics

@@ -171,8 +171,10 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
  * Backward: dep_e[s] >= seg_e[s], rows [seg_e[s], dep_e[s]) = the queries outside the segment that see all its keys (the
  * group's response rows); T_valid = number of packed rows in use.  Same deterministic kernels and workspace as st_attn_bwd. */
 int st_attn_fwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
-                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e, int n_seg, int T,
-                    int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse, int max_seg,
+                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e,
+                    const st_bf16* k_pre, int64_t ldk_pre, const st_bf16* v_pre, int64_t ldv_pre /* NULL: the prefix rows index
+                    k / v themselves; else they index these tensors (the prompt K/V cache left by the rollout prefill) */,
+                    int n_seg, int T, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse, int max_seg,
                     st_stream_t stream);
 int st_attn_bwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                     const st_bf16* out, int64_t ldo, const st_bf16* dout, int64_t lddo, const float* lse,

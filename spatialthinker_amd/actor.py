@@ -104,15 +104,41 @@ class PolicyEngine:
         return self.model.stage(ids, am, data["position_ids"][sl], R, px, gr, groups=groups)
 
     @torch.no_grad()
-    def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None) -> torch.Tensor:
-        """dp_actor.py:169-210: (N, R) fp32 log-probs of the responses, micro-batched."""
+    def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None,
+                         prompt_cache: Optional[dict] = None) -> torch.Tensor:
+        """dp_actor.py:169-210: (N, R) fp32 log-probs of the responses, micro-batched.
+        prompt_cache (from Generator.generate(return_prompt_cache=True) with THESE weights, rows = its prompts x n, prompt-major):
+        the pass then runs on the response tokens only, on top of the cached prompt K/V — the old-policy log-probs of a GRPO step
+        need no second pass over the prompts and images."""
         N = data["input_ids"].shape[0]
         mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
+        R = data["responses"].shape[1]
+        if prompt_cache is not None and self._cache_matches(data, prompt_cache, R):
+            n = prompt_cache["n"]
+            outs = []
+            for s in range(0, N, mb):
+                sl = slice(s, min(N, s + mb))
+                rows = np.arange(sl.start, sl.stop)
+                b = self.model.stage_responses(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R,
+                                               rows // n, prompt_cache["p_off"])
+                outs.append(self.model.log_probs_cached(b, prompt_cache, temperature))
+            return torch.cat(outs, 0)
         outs = []
         for s in range(0, N, mb):
             b = self._stage(data, slice(s, min(N, s + mb)))
             outs.append(self.model.log_probs(b, temperature))
         return torch.cat(outs, 0)
+
+    def _cache_matches(self, data: Dict[str, Any], cache: dict, R: int) -> bool:
+        """The cache is usable only for exactly the prompts it was built from (row r <-> prompt r // n) and the current weights."""
+        ids, am = _to_np(data["input_ids"]), _to_np(data["attention_mask"])
+        n, Pc = cache["n"], ids.shape[1] - R
+        if cache.get("weights_version", 0) != getattr(self.store, "version", 0):
+            return False
+        if ids.shape[0] != cache["prompt_ids"].shape[0] * n or Pc != cache["prompt_ids"].shape[1]:
+            return False
+        return bool(np.array_equal(ids[::n, :Pc], cache["prompt_ids"]) and np.array_equal(am[::n, :Pc], cache["prompt_mask"])
+                    and np.array_equal(ids[:, :Pc], np.repeat(cache["prompt_ids"], n, 0)))
 
     # ------------------------------------------------------------------ optimizer
     def zero_grad(self):
@@ -142,6 +168,7 @@ class PolicyEngine:
         ops.adamw_kahan_step_(st.flat, st.grad, st.m, st.v, st.c, t=self.opt_steps, lr=self.current_lr(), betas=h.betas, eps=h.eps,
                               weight_decay=h.weight_decay, grad_scale=self._coef)
         st.refresh_transposes()
+        st.version = getattr(st, "version", 0) + 1          # invalidates prompt caches built from the previous weights
         self.zero_grad()
         return norm
 

@@ -254,7 +254,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
                                                             const int32_t* __restrict__ o_beg, int qgroup, int T, int n_q, int n_kv,
                                                             float scale_log2, uint16_t* __restrict__ out, int64_t ldo,
                                                             float* __restrict__ lse, const int32_t* __restrict__ pre_beg,
-                                                            const int32_t* __restrict__ pre_end) {
+                                                            const int32_t* __restrict__ pre_end,
+                                                            const uint16_t* __restrict__ k_pre, int64_t ldk_pre,
+                                                            const uint16_t* __restrict__ v_pre, int64_t ldv_pre) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(1024))) char smem[2 * F2_STAGE];
     const int seq = blockIdx.z, h = blockIdx.y;
@@ -293,26 +295,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
     const int n_pre = (Lp + KV_TILE - 1) / KV_TILE;
     const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
     const int n_tiles = n_pre + (kv_end + KV_TILE - 1) / KV_TILE;
+    // the prefix may live in other tensors than the own keys (k_pre / v_pre: the prompt K/V cache the generator filled)
     const uint16_t* kbase = k + kvh * D;
     const uint16_t* vbase = v + kvh * D;
+    const uint16_t* kpbase = (k_pre ? k_pre : k) + kvh * D;
+    const uint16_t* vpbase = (v_pre ? v_pre : v) + kvh * D;
+    const int64_t ldkp = k_pre ? ldk_pre : ldk, ldvp = v_pre ? ldv_pre : ldv;
 
     auto stage = [&](int t, char* dst) {
         const bool pre = t < n_pre;
         const int kt0 = (pre ? t : t - n_pre) * KV_TILE, row0 = pre ? pb : sk, Lc = pre ? Lp : L;
+        const uint16_t* kb_ = pre ? kpbase : kbase;
+        const uint16_t* vb_ = pre ? vpbase : vbase;
+        const int64_t ldk_ = pre ? ldkp : ldk, ldv_ = pre ? ldvp : ldv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                       // K: instruction = 4 rows x 16 chunks
             const int inst = wave * 4 + j;
             const int row = inst * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
             int key = kt0 + row; key = key < Lc ? key : Lc - 1;
-            st_glds16(kbase + (int64_t)(row0 + key) * ldk + c * 8, dst + inst * 1024);
+            st_glds16(kb_ + (int64_t)(row0 + key) * ldk_ + c * 8, dst + inst * 1024);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                       // V: instruction = 2 sub-tiles of [8 keys][32 d]
             const int inst = wave * 4 + j;
             const int u = 2 * inst + (lane >> 5), slot = lane & 31;
             int key = kt0 + (u >> 2) * 8 + (slot >> 2); key = key < Lc ? key : Lc - 1;
-            st_glds16(vbase + (int64_t)(row0 + key) * ldv + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
+            st_glds16(vb_ + (int64_t)(row0 + key) * ldv_ + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
         }
     };
     if (n_tiles > 0) stage(0, smem);
@@ -1132,7 +1141,9 @@ static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int6
                            const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
                            const int32_t* o_beg, int qgroup, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                            st_bf16* out, int64_t ldo, float* lse, int max_q, int klass, st_stream_t stream,
-                           const int32_t* pre_beg = nullptr, const int32_t* pre_end = nullptr) {
+                           const int32_t* pre_beg = nullptr, const int32_t* pre_end = nullptr, const st_bf16* k_pre = nullptr,
+                           int64_t ldk_pre = 0, const st_bf16* v_pre = nullptr, int64_t ldv_pre = 0) {
+    if ((k_pre == nullptr) != (v_pre == nullptr) || (k_pre && (!pre_beg || (ldk_pre & 7) || (ldv_pre & 7)))) return ST_EINVAL;
     if (pre_beg && D != 128) return ST_EINVAL;             // shared-prefix ranges exist for the LM head dim only
     if (!q || !k || !v || !q_beg || !q_end || !k_beg || !k_end || !out || !lse || n_seq <= 0 || T <= 0 || n_q <= 0 || n_kv <= 0 ||
         (n_q % n_kv) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || max_q <= 0)
@@ -1142,7 +1153,7 @@ static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int6
     const float sl2 = scale * LOG2E;
     StProfScope ps(klass, s, 0.0);
 #define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
-#define ST_FWD2(CC) hipLaunchKernelGGL((attn_fwd128_kernel<CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse, pre_beg, pre_end)
+#define ST_FWD2(CC) hipLaunchKernelGGL((attn_fwd128_kernel<CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre)
     if (D == 128) { if (causal) ST_FWD2(true); else ST_FWD2(false); }
     else if (D == 80 && !causal) ST_FWD(80, false);
     else if (D == 80) ST_FWD(80, true);
@@ -1232,11 +1243,12 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
  * Backward additionally needs dep_e[s] >= seg_e[s]: rows [seg_e[s], dep_e[s]) are the queries OUTSIDE the segment that see all of
  * its keys (the group's response rows, packed right behind their prompt); dep_e[s] == seg_e[s] for segments nobody depends on. */
 int st_attn_fwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
-                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e, int n_seg, int T, int n_q,
+                    const int32_t* seg_b, const int32_t* seg_e, const int32_t* pre_b, const int32_t* pre_e, const st_bf16* k_pre,
+                    int64_t ldk_pre, const st_bf16* v_pre, int64_t ldv_pre, int n_seg, int T, int n_q,
                     int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse, int max_seg, st_stream_t stream) {
     if (D != 128 || !pre_b || !pre_e) return ST_EINVAL;
     return attn_fwd_launch(q, ldq, k, ldk, v, ldv, seg_b, seg_e, seg_b, seg_e, nullptr, 0, n_seg, T, n_q, n_kv, D, scale, 1, out, ldo, lse,
-                           max_seg, ST_K_ATTN_FWD, stream, pre_b, pre_e);
+                           max_seg, ST_K_ATTN_FWD, stream, pre_b, pre_e, k_pre, ldk_pre, v_pre, ldv_pre);
 }
 
 int st_attn_bwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,

@@ -151,6 +151,7 @@ class PackedBatch:
     max_seg: int = 0
     logit_dup: Optional[np.ndarray] = None     # (n_distinct, kmax) int32: positions in logit_rows sharing one packed row, -1 padded
     logit_distinct: Optional[np.ndarray] = None  # (n_distinct,) int32 the distinct packed rows
+    first_prompt: Optional[np.ndarray] = None    # responses-only packing: prompt index whose cached last hidden state predicts slot 0
 
 
 def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: np.ndarray, response_length: int, *,
@@ -255,3 +256,57 @@ def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: 
                        logit_rows.astype(np.int32), labels, (bb * R + jj).astype(np.int64), B, R,
                        seg_b=sa[:, 0].copy(), seg_e=sa[:, 1].copy(), pre_b=sa[:, 2].copy(), pre_e=sa[:, 3].copy(), dep_e=sa[:, 4].copy(),
                        max_seg=int((sa[:, 1] - sa[:, 0]).max()) if len(sa) else 0, logit_dup=dup, logit_distinct=distinct)
+
+
+def pack_responses(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: np.ndarray, response_length: int,
+                   prompt_of_row: Sequence[int], prompt_offsets: np.ndarray, *, pad_multiple: int = 128) -> PackedBatch:
+    """Responses-only packing for a log-prob pass that re-uses the prompt K/V cache of the rollout prefill (same weights): only
+    the valid RESPONSE tokens are packed; row r's segment sees the cached keys [prompt_offsets[p], prompt_offsets[p+1]) of its
+    prompt p = prompt_of_row[r] as prefix.  The logits of response slot 0 come from the prompt's cached last hidden state
+    (`first_prompt`), all other slots from the packed row of the previous response token; log-prob rows are ordered
+    [slot-0 rows..., the rest] and `logit_rows` holds the packed rows of "the rest" only."""
+    ids = np.asarray(input_ids)
+    mask = np.asarray(attention_mask).astype(bool)
+    B, S = ids.shape
+    R = response_length
+    Pc = S - R
+    pos = np.asarray(position_ids)
+    if pos.ndim == 2:
+        pos = np.repeat(pos[:, None, :], 3, axis=1)
+    packed_row = -np.ones((B, S), dtype=np.int64)
+    p_ids_l, p_pos_l, seg = [], [], []
+    cur = 0
+    for r in range(B):
+        rcols = Pc + np.nonzero(mask[r, Pc:])[0]
+        n = len(rcols)
+        if n == 0:
+            continue
+        p_ids_l.append(ids[r, rcols]); p_pos_l.append(pos[r][:, rcols])
+        packed_row[r, rcols] = cur + np.arange(n)
+        pr = int(prompt_of_row[r])
+        seg.append((cur, cur + n, int(prompt_offsets[pr]), int(prompt_offsets[pr + 1]), cur + n))
+        cur += n
+    T = cur
+    T_pad = max(round_up(T, pad_multiple), pad_multiple)
+    p_ids = np.zeros(T_pad, dtype=np.int32)
+    p_pos = np.zeros((3, T_pad), dtype=np.int32)
+    if T:
+        p_ids[:T] = np.concatenate(p_ids_l)
+        p_pos[:, :T] = np.concatenate(p_pos_l, axis=1)
+    cols = np.arange(Pc, S)
+    valid = mask[:, cols] & mask[:, cols - 1]
+    b0 = np.nonzero(valid[:, 0])[0]                                  # rows whose slot 0 is predicted by the cached prompt state
+    bb, jj = np.nonzero(valid[:, 1:])
+    jj = jj + 1
+    logit_rows = packed_row[bb, cols[jj] - 1]
+    labels = np.concatenate([ids[b0, Pc], ids[bb, cols[jj]]]).astype(np.int64)
+    out_index = np.concatenate([b0 * R, bb * R + jj]).astype(np.int64)
+    embed_ids = p_ids.copy(); embed_ids[T:] = -1
+    sa = np.asarray(seg, dtype=np.int32).reshape(-1, 5)
+    lens_full = mask.sum(1)
+    return PackedBatch(T, T_pad, p_ids, p_pos, np.concatenate([[0], np.cumsum(lens_full)]).astype(np.int32),
+                       int((sa[:, 1] - sa[:, 0]).max()) if len(sa) else 0, np.zeros(0, dtype=np.int32), embed_ids,
+                       logit_rows.astype(np.int32), labels, out_index, B, R,
+                       seg_b=sa[:, 0].copy(), seg_e=sa[:, 1].copy(), pre_b=sa[:, 2].copy(), pre_e=sa[:, 3].copy(), dep_e=sa[:, 4].copy(),
+                       max_seg=int((sa[:, 1] - sa[:, 0]).max()) if len(sa) else 0,
+                       first_prompt=np.asarray([prompt_of_row[r] for r in b0], dtype=np.int32))

@@ -128,13 +128,15 @@ class VLConfig:
         return float(fl)
 
 
-    def flops_forward_grouped(self, groups: List[Tuple[int, List[int]]], patches_per_image: List[int], logit_rows: int) -> float:
+    def flops_forward_grouped(self, groups: List[Tuple[int, List[int]]], patches_per_image: List[int], logit_rows: int,
+                              prefix_cached: bool = False) -> float:
         """Forward FLOPs actually executed with shared-prompt packing: groups = [(prompt_len, [response_len, ...]), ...] — the
-        prompt is computed once per group; a response row attends to the whole prompt plus its own causal part."""
+        prompt is computed once per group; a response row attends to the whole prompt plus its own causal part.
+        prefix_cached: the prompt rows themselves are not computed at all (their K/V come from the rollout prefill)."""
         H, I, D = self.hidden_size, self.intermediate_size, self.head_dim
-        T = sum(P + sum(rs) for P, rs in groups)
+        T = sum((0 if prefix_cached else P) + sum(rs) for P, rs in groups)
         fl = 2 * (H * self.qkv_width + H * H + 3 * H * I) * T * self.num_layers
-        att = sum(P * P + sum(2 * r * P + r * r for r in rs) for P, rs in groups)          # (query, key) pairs x 2, causal halves
+        att = sum((0 if prefix_cached else P * P) + sum(2 * r * P + r * r for r in rs) for P, rs in groups)   # (q, k) pairs x 2
         fl += 2 * D * self.num_heads * att * self.num_layers
         fl += 2 * H * self.vocab_size * logit_rows
         return float(fl) + self.flops_forward([], patches_per_image, logit_rows=0)
@@ -325,6 +327,7 @@ class DeviceBatch:
     seg: Optional[tuple] = None          # (seg_b, seg_e, pre_b, pre_e, dep_e) int32 device arrays (shared-prefix attention)
     logit_dup: Optional[torch.Tensor] = None
     logit_distinct: Optional[torch.Tensor] = None
+    first_prompt: Optional[torch.Tensor] = None
 
 
 class Qwen25VL:
@@ -480,7 +483,7 @@ class Qwen25VL:
         return x
 
     # ---------------------------------------------------------------- language model
-    def _lm_layer_fwd(self, i: int, x0: torch.Tensor, b: DeviceBatch, save: Optional[list], kv_out=None):
+    def _lm_layer_fwd(self, i: int, x0: torch.Tensor, b: DeviceBatch, save: Optional[list], kv_out=None, prefix_kv=None):
         c, w = self.cfg, self.p.w
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
@@ -491,7 +494,9 @@ class Qwen25VL:
         if kv_out is not None:
             kv_out(i, k, v)
         a = torch.zeros(x0.shape[0], nq * D, dtype=BF16, device=x0.device)
-        _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a)
+        kpre, vpre = prefix_kv if prefix_kv is not None else (None, None)     # prompt K/V cached by the rollout prefill
+        _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a,
+                                  k_pre=kpre, v_pre=vpre)
         x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x0)
         h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
         gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)      # SwiGLU in the epilogue; gate|up kept only for backward
@@ -530,6 +535,47 @@ class Qwen25VL:
         logits = ops.gemm_nt(hn, head)
         logp, lse = ops.logprob_fwd(logits, b.labels, temperature)
         return xr, hn, rn, logits, logp, lse
+
+    # ---------------------------------------------------------------- log-probs on top of the rollout's prompt cache
+    def stage_responses(self, input_ids, attention_mask, position_ids, response_length: int, prompt_of_row, prompt_offsets) -> DeviceBatch:
+        c, dev = self.cfg, self.p.device
+        pk = ix.pack_responses(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, prompt_of_row, prompt_offsets)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
+        cos, sin = ops.mrope_table(t(pk.pos, I32), self.inv_freq, c.head_dim, c.mrope_section)
+        n_first, Tr = len(pk.first_prompt), len(pk.labels)
+        Tr_pad = max(ix.round_up(Tr, 128), 128)
+        labels = np.full(Tr_pad, -1, dtype=np.int64); labels[:Tr] = pk.labels
+        seg = tuple(t(a, I32) for a in (pk.seg_b, pk.seg_e, pk.pre_b, pk.pre_e, pk.dep_e))
+        b = DeviceBatch(pk, t(pk.ids, I32), t(pk.embed_ids, I32), t(pk.cu_seqlens, I32), cos, sin, t(pk.image_rows, I32),
+                        t(pk.logit_rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, None, seg)
+        b.first_prompt = t(pk.first_prompt, I32)
+        return b
+
+    @torch.no_grad()
+    def log_probs_cached(self, b: DeviceBatch, cache: dict, temperature: float = 1.0) -> torch.Tensor:
+        """(B, R) log-probs of the response tokens computed on the RESPONSE tokens only: the prompt part comes from `cache`
+        (kp/vp (L, Tp, n_kv*D) prompt K/V and last_h (n_prompts, H) left by Generator.generate with the SAME weights) — what
+        the no-grad pass would recompute, bit for bit."""
+        c, w = self.cfg, self.p.w
+        x = ops.embed_gather(w["embed"], b.ids)
+        if b.pk.T_pad > b.pk.T:
+            x[b.pk.T:].zero_()
+        for i in range(c.num_layers):
+            x = self._lm_layer_fwd(i, x, b, None, prefix_kv=(cache["kp"][i], cache["vp"][i]))
+        n_first, n_rest = b.first_prompt.numel(), b.logit_rows.numel()
+        xr = torch.zeros(b.Tr_pad, c.hidden_size, dtype=BF16, device=x.device)
+        if n_first:
+            ops.rows_gather(cache["last_h"], b.first_prompt, out=xr[:n_first])
+        if n_rest:
+            ops.rows_gather(x, b.logit_rows, out=xr[n_first:n_first + n_rest])
+        hn, _ = ops.rmsnorm_fwd(xr, w["final_norm"], c.rms_eps)
+        head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
+        logits = ops.gemm_nt(hn, head)
+        logp, _ = ops.logprob_fwd(logits, b.labels, temperature)
+        out = torch.zeros(b.pk.B * b.pk.R, dtype=F32, device=x.device)
+        out.index_copy_(0, b.out_index, logp[:len(b.out_index)])
+        return out.view(b.pk.B, b.pk.R)
+
 
     # ---------------------------------------------------------------- public entry points
     @torch.no_grad()

@@ -337,12 +337,13 @@ def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, c
     return dq, dk, dv
 
 
-def attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, scale, out=None):
-    """Shared-prefix causal attention over packed segments (st_attn_fwd_seg)."""
+def attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, scale, out=None, k_pre=None, v_pre=None):
+    """Shared-prefix causal attention over packed segments (st_attn_fwd_seg); k_pre / v_pre: external prefix K/V tensors."""
     T = q.shape[0]
     o = torch.empty(T, n_q * D, dtype=BF16, device=q.device) if out is None else out
     lse = torch.empty(n_q, T, dtype=F32, device=q.device)
     lib().st_attn_fwd_seg(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(seg_b), _p(seg_e), _p(pre_b), _p(pre_e),
+                          _p(k_pre), k_pre.stride(0) if k_pre is not None else 0, _p(v_pre), v_pre.stride(0) if v_pre is not None else 0,
                           seg_b.numel(), T, n_q, n_kv, D, scale, _p(o), o.stride(0), _p(lse), int(max_seg), _s())
     return o, lse
 

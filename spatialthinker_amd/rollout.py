@@ -45,11 +45,14 @@ class Generator:
     def generate(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
                  eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
                  image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
-                 sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0) -> torch.Tensor:
+                 sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
+                 return_prompt_cache: bool = False):
         """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
         pixel_values[i] (N_i, 1176) / image_grid_thw[i] (1, 3).  Returns responses (b*n, max_new_tokens) int64 on the
         device, prompt-major, padded with pad_token_id after the first EOS (vllm_rollout_spmd.py:144-147).
-        forced_lengths (b*n,): synthetic-benchmark mode — EOS is forced at exactly that response length."""
+        forced_lengths (b*n,): synthetic-benchmark mode — EOS is forced at exactly that response length.
+        return_prompt_cache: also return {kp, vp, last_h, p_off, prompt_ids, prompt_mask, n} — the prompt K/V and last hidden
+        states of the prefill; PolicyEngine.compute_log_prob re-uses them for the old-policy log-probs (same weights)."""
         m, c, w = self.m, self.m.cfg, self.m.p.w
         dev = self.m.p.device
         ids_np, mask_np, pos_np = (np.asarray(x.cpu() if torch.is_tensor(x) else x) for x in (input_ids, attention_mask, position_ids))
@@ -275,4 +278,7 @@ class Generator:
         while len(pool):
             S, pool = np.sort(pool[:wave]), pool[wave:]
             pool = np.concatenate([pool, run(S, len(S) > 32)])
+        if return_prompt_cache:
+            return out, dict(kp=kp, vp=vp, last_h=last_h, p_off=p_off.astype(np.int64), prompt_ids=ids_np, prompt_mask=mask_np, n=n,
+                             weights_version=getattr(self.m.p, "version", 0))
         return out

@@ -194,3 +194,32 @@ def test_top_k_top_p_sampling_support_and_distribution(top_k, top_p):
     chi2 = ((cnt[sel] - q[sel] * N) ** 2 / (q[sel] * N)).sum()
     dof = max(int(sel.sum()) - 1, 1)
     assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)
+
+
+def test_old_log_probs_from_prompt_cache_match_full_pass(env):
+    """The rollout prefill leaves the prompt K/V and last hidden states; the old-policy log-prob pass run on the response tokens
+    only (on top of that cache) must give what the full pass over prompt + image + response gives."""
+    from spatialthinker_amd.actor import PolicyEngine
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    n, R = 3, 10
+    resp, cache = gen.generate(ids, mask, pos, n=n, max_new_tokens=R, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                               seed=2, pixel_values=pix, image_grid_thw=grids, forced_lengths=np.array([10, 4, 7, 10, 2, 9]),
+                               return_prompt_cache=True)
+    resp = resp.cpu()
+    rmask = (torch.cumsum((resp == tiny.EOS_ID).long(), 1) - (resp == tiny.EOS_ID).long() == 0).long()
+    ids_f = torch.cat([torch.from_numpy(ids).repeat_interleave(n, 0), resp], 1)
+    mask_f = torch.cat([torch.from_numpy(mask).repeat_interleave(n, 0), rmask], 1)
+    pos_p = torch.from_numpy(pos).repeat_interleave(n, 0)
+    pos_f = torch.cat([pos_p, pos_p[..., -1:] + torch.arange(1, R + 1)], -1)
+    mm = np.repeat(np.array([{"pixel_values": p_, "image_grid_thw": g_} for p_, g_ in zip(pix, grids)], dtype=object), n)
+    data = dict(input_ids=ids_f, attention_mask=mask_f, position_ids=pos_f, responses=resp, multi_modal_inputs=mm)
+    pe = PolicyEngine(cfg, eng.p, None)
+    full = pe.compute_log_prob(data, 1.0)
+    cached = pe.compute_log_prob(data, 1.0, prompt_cache=cache)
+    m = rmask.bool()
+    assert float((full.cpu() - cached.cpu())[m].abs().max()) < 2e-3
+    assert torch.all(cached.cpu()[~m] == 0)
+    # a cache built for other prompts (or other weights) is ignored, not misused
+    bad = dict(cache); bad["prompt_ids"] = cache["prompt_ids"].copy(); bad["prompt_ids"][0, -1] += 1
+    assert torch.equal(pe.compute_log_prob(data, 1.0, prompt_cache=bad), full)

@@ -118,10 +118,14 @@ class FSDPWorker:
             gr = [m["image_grid_thw"] for m in mm]
         eos = self.special["eos"]
         self._gen_calls = getattr(self, "_gen_calls", 0) + 1
-        resp = self.generator.generate(ids, mask, pos, n=n, max_new_tokens=r.response_length, temperature=temperature,
-                                       eos_token_id=eos, pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls,
-                                       pixel_values=px, image_grid_thw=gr, ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)),
-                                       forced_lengths=prompts.meta_info.get("synthetic_response_lengths"), top_k=top_k, top_p=top_p).cpu()
+        # the prefill's prompt K/V serves the old-policy log-prob pass that follows on the same weights (PolicyEngine checks that
+        # the cache matches the rows it is handed, else it simply recomputes)
+        resp, self._prompt_cache = self.generator.generate(
+            ids, mask, pos, n=n, max_new_tokens=r.response_length, temperature=temperature, eos_token_id=eos,
+            pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls, pixel_values=px, image_grid_thw=gr,
+            ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)), forced_lengths=prompts.meta_info.get("synthetic_response_lengths"),
+            top_k=top_k, top_p=top_p, return_prompt_cache=True)
+        resp = resp.cpu()
         # post-processing of vllm_rollout_spmd.py:144-188
         if n > 1:
             ids, mask, pos = (t.repeat_interleave(n, dim=0) for t in (ids, mask, pos))
@@ -146,7 +150,8 @@ class FSDPWorker:
         assert self._is_actor
         t = self.config.rollout.temperature
         data.meta_info["temperature"] = t
-        lp = self.actor.compute_log_prob(self._as_dict(data), t).cpu()
+        cache, self._prompt_cache = getattr(self, "_prompt_cache", None), None            # one use, then the K/V memory is released
+        lp = self.actor.compute_log_prob(self._as_dict(data), t, prompt_cache=cache).cpu()
         return DataProto.from_dict(tensors={"old_log_probs": lp}, meta_info={"temperature": t})
 
     @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)

@@ -12,6 +12,7 @@
 // 2.5 PF MFMA peak — above the ~34 TB/s aggregate L2 bandwidth; 256x128 needs 29 TB/s, 256x256 19.5 TB/s.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 __device__ __forceinline__ void glds16t(const void* gsrc, char* lds_dst_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -51,8 +52,11 @@ __device__ __forceinline__ void pin_schedule() {
 // MIDBAR (2 stages only): the per-tile barrier sits BETWEEN the two k-steps of a tile instead of in front of it.  At that point
 // every wave holds both k-steps' fragments of tile t in registers (slot t is free for the DMA of tile t+2) and tile t+1 has
 // landed, so the fragment reads of tile t+1 run under the MFMAs of (t, k-step 1): no LDS read is ever exposed behind a barrier.
+// SW8 (with SWIGLU): gate and up are interleaved at 8-column granularity INSIDE every 16-column MFMA tile (cols 0-7 gate j..j+7,
+// cols 8-15 up j..j+7), so any WTN that is a multiple of 16 works (e.g. 80 = a 256x160 tile, 237 workgroups for the 7B MLP); the
+// up values sit 32 lanes above their gate values and come down with one v_permlane32_swap per accumulator register.
 template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false,
-          bool MIDBAR = false>
+          bool MIDBAR = false, bool SW8 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -68,9 +72,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     constexpr int A_PER = (A_INST + NW - 1) / NW, B_PER = (B_INST + NW - 1) / NW;
     constexpr int PER_WAVE = A_PER + B_PER;                // LDS-DMA instructions a wave issues per K-tile (upper bound if uneven)
     constexpr bool EVEN_DMA = (A_INST % NW == 0) && (B_INST % NW == 0);
-    static_assert(EVEN_DMA || STAGES == 2, "counted vmcnt waits (3-slot ring, mid-tile barrier) need the same DMA count in every wave");
     static_assert(EVEN_DMA || !MIDBAR, "mid-tile barrier prologue counts DMA instructions");
-    static_assert(!SWIGLU || (WTN % 32 == 0 && OUT_BF16 && !HAS_BIAS && !HAS_RES), "SwiGLU epilogue pairs 16-column MFMA tiles");
+    static_assert(!SWIGLU || ((SW8 || WTN % 32 == 0) && OUT_BF16 && !HAS_BIAS && !HAS_RES), "SwiGLU epilogue pairs 16-column MFMA tiles");
+    static_assert(!SW8 || SWIGLU, "SW8 is a flavour of the SwiGLU epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     auto stage = [&](int kt, char* dst) {
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            const int inst = wave * A_PER + j;
+            const int inst = EVEN_DMA ? wave * A_PER + j : j * NW + wave;    // uneven split: round-robin, counts differ by <= 1
             if (!EVEN_DMA && inst >= A_INST) break;
             const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
             int gr = m0 + r; gr = gr < M ? gr : M - 1;
@@ -102,11 +106,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const int inst = wave * B_PER + j;
+            const int inst = EVEN_DMA ? wave * B_PER + j : j * NW + wave;
             if (!EVEN_DMA && inst >= B_INST) break;
             const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
             int gr;
-            if (SWIGLU) {
+            if (SW8) {
+                const int j8 = (r >> 4) * 8 + (r & 7);
+                gr = n0 + j8; gr = gr < N ? gr : N - 1;
+                if (r & 8) gr += N;
+            } else if (SWIGLU) {
                 const int within = r % WTN;
                 const int j = (r / WTN) * (WTN / 2) + (within >> 5) * 16 + (within & 15);
                 gr = n0 + j; gr = gr < N ? gr : N - 1;
@@ -139,7 +147,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         constexpr bool PREFETCH = decltype(prefetch_tag)::value;
         // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
         if (STAGES == 2 || !PREFETCH) wait_vmcnt<0>();          // tail tiles: nothing younger is in flight to count
-        else wait_vmcnt<(STAGES - 2) * PER_WAVE>();
+        else if constexpr (EVEN_DMA) wait_vmcnt<(STAGES - 2) * PER_WAVE>();
+        else {                                               // round-robin split: this wave issued PER_WAVE or PER_WAVE-1 copies
+            static_assert(EVEN_DMA || STAGES == 3, "uneven LDS-DMA split is wired for the 3-slot ring");
+            const int mine = (wave < A_INST % NW || A_INST % NW == 0 ? A_PER : A_PER - 1) + (wave < B_INST % NW || B_INST % NW == 0 ? B_PER : B_PER - 1);
+            if (mine == PER_WAVE) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<PER_WAVE - 1>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                       // keep LDS reads / DMA issue below the barrier
         const char* la = smem + slot * STAGE;
@@ -252,6 +265,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + wm * WTM + mi * 16 + (lane & 15);
         if (m >= M) continue;
+        if constexpr (SW8) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                uint16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {               // lanes 0..31 hold gate, lanes 32..63 the matching up value
+                    const uint32_t mine = __float_as_uint(acc[ni][mi][r]);
+                    auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                    const float g = bfround(acc[ni][mi][r]), u = bfround(__uint_as_float(sw[1]));
+                    o[r] = f2bf(bfround(g * sigmoidf_(g)) * u);
+                }
+                const int n = n0 + (wn * (WTN / 16) + ni) * 8 + (lane >> 4) * 4;
+                if (lane < 32 && n < N) {
+                    uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                    if (n + 3 < N && ((ldc & 3) == 0)) {
+                        uint2 w;
+                        w.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                        w.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                        *reinterpret_cast<uint2*>(cp) = w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = o[r];
+                    }
+                }
+            }
+            continue;
+        }
         if constexpr (SWIGLU) {
 #pragma unroll
             for (int ni = 0; ni < TN; ni += 2) {
@@ -414,11 +454,11 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
 #undef DEC_GO
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool MB = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool MB = false, bool S8 = false>
 static int launch_tile_swiglu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N,
                               int K, hipStream_t s, uint16_t* gu = nullptr, int64_t ldgu = 0) {
     constexpr int smem = STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true, MB>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true, MB, S8>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -456,6 +496,10 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
     // (I = 18944) gives 148 tiles at 128 output columns (0.58 of the CUs) and 198 at 96 (-10 % time).  A 256x160 tile as 8x1
     // waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
     auto cost = [&](int cols) { const int t = st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
+    // 256x160 with the 8-column interleave: 3-slot ring (two K-tiles of weights in flight: the 2-slot variants sit parked on HBM
+    // latency half of the time) and 237 workgroups for I = 18944
+    if (cost(80) <= cost(96) && cost(80) <= cost(128))                                         // 90 us vs 102 us (256x192) on MI355X
+        return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     if (cost(96) <= cost(128)) return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
 }

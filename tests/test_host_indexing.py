@@ -46,3 +46,80 @@ def test_pack_batch_layout(golden_dir):
     assert (pk.ids[pk.image_rows] == tiny.TINY["image_token_id"]).all() and len(pk.image_rows) == 16 + 12
     assert (pk.embed_ids[pk.image_rows] == -1).all() and (pk.embed_ids[pk.T:] == -1).all()
     assert (pk.pos[:, pk.cu_seqlens[:-1]] == 0).all()       # every packed sequence starts at position 0
+
+
+def _random_rollout_batch(rs, n_prompts=3, G=4, Pc=24, R=9):
+    B, S = n_prompts * G, Pc + R
+    ids = rs.randint(20, 500, (B, S)).astype(np.int64)
+    mask = np.ones((B, S), dtype=np.int64)
+    for p in range(n_prompts):
+        lead = rs.randint(0, 6)                                  # left padding of the prompt
+        rows = slice(p * G, (p + 1) * G)
+        ids[rows, :Pc] = ids[p * G, :Pc]
+        mask[rows, :lead] = 0
+        ids[rows, Pc - 5:Pc - 2] = 7                              # three image placeholders inside the prompt
+    for r in range(B):
+        L = rs.randint(0, R + 1)                                  # response length, 0 allowed
+        mask[r, Pc + L:] = 0
+    pos = np.maximum(np.cumsum(mask, 1) - 1, 0)
+    return ids, mask, pos, Pc, R, G
+
+
+def test_grouped_packing_reconstructs_every_sequence_and_its_logit_rows():
+    """pack_batch(groups=...) stores the prompt of a rollout group once; following the segment arrays back must give exactly the
+    tokens, positions and (logit row -> label) pairs of the per-sequence packing."""
+    from spatialthinker_amd import indexing as ix
+    rs = np.random.RandomState(0)
+    for trial in range(5):
+        ids, mask, pos, Pc, R, G = _random_rollout_batch(rs)
+        B = ids.shape[0]
+        a = ix.pack_batch(ids, mask, pos, R, image_token_id=7)
+        g = ix.pack_batch(ids, mask, pos, R, image_token_id=7, groups=[r // G for r in range(B)])
+        assert g.T < a.T and np.array_equal(a.labels, g.labels) and np.array_equal(a.out_index, g.out_index)
+        # the token predicted-from at every logit row is the same token in both layouts
+        assert np.array_equal(a.ids[a.logit_rows], g.ids[g.logit_rows])
+        assert np.array_equal(a.pos[:, a.logit_rows], g.pos[:, g.logit_rows])
+        # segments tile the packed stream; prefixes are prompt segments; dependents end where the group ends
+        cover = np.zeros(g.T, dtype=int)
+        for b_, e_, pb_, pe_, de_ in zip(g.seg_b, g.seg_e, g.pre_b, g.pre_e, g.dep_e):
+            cover[b_:e_] += 1
+            assert de_ >= e_ and (pb_ == pe_ or (pe_ <= b_ and de_ == e_))
+        assert np.all(cover == 1)
+        # every row's full token sequence = its group's prompt rows + its own response rows
+        resp_segs = [(b_, e_, pb_, pe_) for b_, e_, pb_, pe_ in zip(g.seg_b, g.seg_e, g.pre_b, g.pre_e) if pe_ > pb_]
+        it = iter(resp_segs)
+        for r in range(B):
+            want = ids[r][mask[r] == 1]
+            n_resp = int(mask[r, Pc:].sum())
+            n_prompt = int(mask[r, :Pc].sum())
+            if n_resp == 0:
+                continue
+            b_, e_, pb_, pe_ = next(it)
+            got = np.concatenate([g.ids[pb_:pe_], g.ids[b_:e_]])
+            assert pe_ - pb_ == n_prompt and np.array_equal(got, want), (trial, r)
+        # image rows: once per group
+        assert len(g.image_rows) == 3 * (B // G) and len(a.image_rows) == 3 * B
+        # duplicates only at the last prompt row of a group
+        if g.logit_dup is not None:
+            assert (g.logit_dup >= 0).sum() == len(g.logit_rows)
+
+
+def test_pack_responses_layout():
+    from spatialthinker_amd import indexing as ix
+    rs = np.random.RandomState(3)
+    ids, mask, pos, Pc, R, G = _random_rollout_batch(rs)
+    B = ids.shape[0]
+    n_prompts = B // G
+    plens = mask[::G, :Pc].sum(1)
+    p_off = np.concatenate([[0], np.cumsum(plens)])
+    full = ix.pack_batch(ids, mask, pos, R, image_token_id=7)
+    pk = ix.pack_responses(ids, mask, pos, R, [r // G for r in range(B)], p_off)
+    assert pk.T == int(mask[:, Pc:].sum())
+    assert sorted(pk.out_index.tolist()) == sorted(full.out_index.tolist())
+    # same (slot -> label) assignment as the full packing
+    lab_full = dict(zip(full.out_index.tolist(), full.labels.tolist()))
+    assert all(lab_full[i] == l for i, l in zip(pk.out_index.tolist(), pk.labels.tolist()))
+    n_first = len(pk.first_prompt)
+    assert np.all(pk.out_index[:n_first] % R == 0) and np.all(pk.out_index[n_first:] % R > 0)
+    for (b_, e_, pb_, pe_) in zip(pk.seg_b, pk.seg_e, pk.pre_b, pk.pre_e):
+        assert pe_ - pb_ in plens and 0 <= pb_ < pe_ <= p_off[-1]

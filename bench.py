@@ -303,6 +303,7 @@ def main():
             "timing_s": {k: v / a.steps for k, v in phase.items()},
             "perf_throughput_tokens_per_s_per_gpu": tokens_total[0] / elapsed,
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
             "actor_mfu": (flops["old"] + flops["ref"] + flops["update"]) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "actor_mfu_reference_flops": flops.get("reference_formulation", 0.0) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "roofline": {"bound": "mfma", "kernel": "st_gemm_nt family: gemm_tile_kernel<256,256> / gemm_nt_kernel<128,128> (bf16 MFMA 16x16x32, LDS-DMA staged)", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,

@@ -502,7 +502,9 @@ class Qwen25VL:
         gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)      # SwiGLU in the epilogue; gate|up kept only for backward
         x2 = ops.gemm_nt(m, w[p + "down_w"], residual=x1)
         if save is not None:
-            save.append((x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m))
+            # h1, h2 (RMSNorm outputs) and m (SwiGLU output) are cheap row-wise functions of tensors that are kept anyway: the
+            # backward recomputes them (bit-identical kernels) instead of holding 1/3 of the activation memory for them
+            save.append((x0, r1, None, qkv, a, lse, x1, r2, None, gu, None))
         return x2
 
     def _lm_layer_bwd(self, i: int, dx2: torch.Tensor, b: DeviceBatch, saved):
@@ -510,6 +512,10 @@ class Qwen25VL:
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
         x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved
+        if m is None:                                       # recompute the light activations (see _lm_layer_fwd)
+            m = ops.swiglu_fwd(gu)
+            h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
+            h1, _ = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps, want_rstd=False)
         self._dw(g[p + "down_w"], dx2, m, None)
         dm = ops.gemm_nt(dx2, wT[p + "down_w"])
         dgu = ops.swiglu_bwd(gu, dm)

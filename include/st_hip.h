@@ -193,8 +193,13 @@ int st_attn_bwd_seg(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk
 int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
                        const int32_t* o_beg /* output row base per sequence, NULL = q_beg */,
-                       int q_group /* g > 0: query row R = (sample R/g, head h*g + R%g) read in place from (B, n_q*D); 0: plain rows */,
-                       int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo, float* lse /* (n_q, T_out) */, int max_q,
+                       int q_group /* g > 0: query row R = (sample R/g, head h*g + R%g) read in place from (B, n_q*D), 0: plain rows */,
+                       int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out, int64_t ldo,
+                       float* lse /* (n_q, T_out) */, int max_q,
+                       const int32_t* pre_beg, const int32_t* pre_end, const st_bf16* k_pre, int64_t ldk_pre,
+                       const st_bf16* v_pre, int64_t ldv_pre /* optional (D = 128): a second key range per sequence, rows
+                       [pre_beg, pre_end) of k_pre / v_pre, visited before the own range — lets ONE launch cover the shared-prompt
+                       partials (keys in the prompt cache, own range empty) and the per-sample partials (prefix empty) */,
                        st_stream_t stream);
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */

@@ -1174,9 +1174,10 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
 int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
                        const int32_t* o_beg, int q_group, int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out,
-                       int64_t ldo, float* lse, int max_q, st_stream_t stream) {
+                       int64_t ldo, float* lse, int max_q, const int32_t* pre_beg, const int32_t* pre_end, const st_bf16* k_pre,
+                       int64_t ldk_pre, const st_bf16* v_pre, int64_t ldv_pre, st_stream_t stream) {
     return attn_fwd_launch(q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, q_group, n_seq, T_out, n_q, n_kv, D, scale, 0, out, ldo,
-                           lse, max_q, ST_K_DECODE_ATTN, stream);
+                           lse, max_q, ST_K_DECODE_ATTN, stream, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre);
 }
 
 int64_t st_attn_bwd_workspace_bytes(int T, int n_q, int D) {

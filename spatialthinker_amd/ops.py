@@ -444,10 +444,14 @@ def prof_read(klass: int):
 
 
 # ------------------------------------------------------------------ rollout (decode) kernels
-def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, scale, out, lse, o_beg=None, q_group=0):
-    """out: (T_out, n_q*D) bf16 slab buffer, lse: (n_q, T_out) fp32 — both caller-owned (several launches fill disjoint slabs)."""
+def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, scale, out, lse, o_beg=None, q_group=0,
+                    pre_beg=None, pre_end=None, k_pre=None, v_pre=None):
+    """out: (T_out, n_q*D) bf16 slab buffer, lse: (n_q, T_out) fp32 — both caller-owned (several launches fill disjoint slabs).
+    pre_*/k_pre/v_pre: optional second key range per sequence in other tensors (see st_attn_fwd_ranges)."""
     lib().st_attn_fwd_ranges(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(q_beg), _p(q_end), _p(k_beg), _p(k_end),
-                             _p(o_beg), int(q_group), q_beg.numel(), out.shape[0], n_q, n_kv, D, scale, _p(out), out.stride(0), _p(lse), int(max_q), _s())
+                             _p(o_beg), int(q_group), q_beg.numel(), out.shape[0], n_q, n_kv, D, scale, _p(out), out.stride(0), _p(lse), int(max_q),
+                             _p(pre_beg), _p(pre_end), _p(k_pre), k_pre.stride(0) if k_pre is not None else 0,
+                             _p(v_pre), v_pre.stride(0) if v_pre is not None else 0, _s())
     return out, lse
 
 

@@ -152,6 +152,14 @@ class Generator:
             ob2 = ((C + torch.arange(Cg, device=dev, dtype=I32).repeat_interleave(Ba)) * rows_all + (ar * g).repeat(Cg)).contiguous()
             parts = torch.empty(NP * rows_all, width, dtype=BF16, device=dev)
             lse_parts = torch.empty(nkv, NP * rows_all, dtype=F32, device=dev)
+            # ONE attention launch per layer: prompt partials (keys = prefix range in the prompt cache, own range empty) and
+            # generated partials (own range in the sample's cache, prefix empty) are items of the same grid
+            n1, n2 = qb1.numel(), qb2.numel()
+            z1, z2 = torch.zeros(n1, dtype=I32, device=dev), torch.zeros(n2, dtype=I32, device=dev)
+            qb_all, qe_all, ob_all = torch.cat([qb1, qb2]), torch.cat([qe1, qe2]), torch.cat([ob1, ob2])
+            kb_all, ke_all = torch.cat([z1, kb2]), torch.cat([z1, kb2])        # ke_all[n1:] is refreshed every step
+            pb_all, pe_all = torch.cat([kb1, z2]), torch.cat([ke1, z2])
+            max_q_all = max(max_q1, g)
             xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
             abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # attention output, pad rows stay zero
             qbuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # roped queries of the fused path (pad rows stay zero)
@@ -183,6 +191,7 @@ class Generator:
                 x = xbuf
                 glen = gen_len.clamp(max=R - 1)                                     # finished rows at the cap rewrite their last slot
                 ke2 = torch.maximum(torch.minimum(kb2 + CKG, kbase + (glen + 1).repeat(Cg)), kb2).contiguous()
+                ke_all[n1:].copy_(ke2)
                 if fused:
                     # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE +
                     # cache append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue
@@ -193,10 +202,9 @@ class Generator:
                         slabs, sp = ops.gemm_nt_decode_slabs(h1, w[p + "qkv_w"])
                         ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], glen, Ba, nq, nkv, D,
                                               row_map=S_t)
-                        ops.attn_fwd_ranges(qbuf, kp[layer], vp[layer], qb1, qe1, kb1, ke1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
-                                            o_beg=ob1, q_group=g)
-                        ops.attn_fwd_ranges(qbuf, kgv[layer], vgv[layer], qb2, qe2, kb2, ke2, g, nkv, nkv, D, m.scale, parts, lse_parts,
-                                            o_beg=ob2, q_group=g)
+                        ops.attn_fwd_ranges(qbuf, kgv[layer], vgv[layer], qb_all, qe_all, kb_all, ke_all, max_q_all, nkv, nkv, D, m.scale,
+                                            parts, lse_parts, o_beg=ob_all, q_group=g, pre_beg=pb_all, pre_end=pe_all,
+                                            k_pre=kp[layer], v_pre=vp[layer])
                         ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)
                         slabs, sp = ops.gemm_nt_decode_slabs(abuf, w[p + "o_w"])
                         x1 = torch.empty(Bp, H, dtype=BF16, device=dev); h2 = torch.empty(Bp, H, dtype=BF16, device=dev)

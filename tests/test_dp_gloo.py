@@ -46,6 +46,39 @@ def test_bucketed_grad_allreduce_averages_over_ranks(tmp_path):
         assert torch.load(tmp_path / f"m{r}.pt") == [{"rank": 0, "loss": 0.0}, {"rank": 1, "loss": 0.5}]
 
 
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spatialthinker_amd.actor import GradReducer
+    n = 700_001
+    grad = torch.randn(n, generator=torch.Generator().manual_seed(200 + rank))
+    red = GradReducer(grad, world, None, bucket_elems=100_000)
+    # slices announced early, in "backward order" (tail first, then layers from the back), with gaps left for finish()
+    red.ready(650_000, n)
+    for lo in (500_000, 350_000, 200_000):
+        red.ready(lo, lo + 150_000)
+    with pytest.raises(AssertionError):
+        red.ready(300_000, 360_000)                           # overlaps an announced slice
+    assert red.early_elems == 50_001 + 3 * 150_000
+    red.finish()                                              # [0, 200000) goes out here
+    assert red.sent == [] and red.works == []
+    # a second optimizer step on the same reducer, nothing announced: everything goes out in finish()
+    grad2 = grad.clone()
+    red.finish()
+    torch.testing.assert_close(grad, grad2)                   # mean over identical... (each rank holds the same averaged buffer)
+    torch.save(grad, os.path.join(out_dir, f"o{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_early_slices_plus_remainder_equal_one_full_allreduce(tmp_path):
+    """GradReducer: slices sent while backward is still running + the remainder sent by finish() = the plain averaged all-reduce."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = sum(torch.randn(700_001, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)) / world
+    for r in range(world):
+        torch.testing.assert_close(torch.load(tmp_path / f"o{r}.pt"), want, rtol=1e-6, atol=1e-7)
+
+
 def test_trainer_rank_sharding_matches_dataproto_chunk():
     """RayPPOTrainer._shard(rank) must equal DataProto.chunk(world)[rank] (Dispatch.DP_COMPUTE_PROTO, decorator.py:106-108)."""
     from verl.protocol import DataProto

@@ -114,8 +114,15 @@ int st_gelu_bwd(const st_bf16* x, const st_bf16* dy, st_bf16* dx, int64_t n, st_
 int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
                int accumulate, int M, int N, int K, st_stream_t stream);
+/* Optional workspace for st_gemm_nt / st_gemm_nt_variant (device memory, `bytes` long, 256 KiB per tail slice; 128 MiB covers
+ * every split the library picks).  With it, a launch whose 256x256 tiles do not fill whole rounds of the device's CUs cuts its
+ * last partial round into K-slices (fp32 partials in the workspace, summed in a fixed order by a second launch that also runs the
+ * bias/residual/accumulate epilogue) — e.g. 574 tiles on 256 CUs finish in ~2.3 rounds instead of 3.  NULL / 0 switches it off.
+ * The workspace is process-global: GEMMs that may use it must be issued on one stream at a time. */
+int st_gemm_set_workspace(void* workspace, int64_t bytes);
 /* Tuning/inspection entry: the same GEMM with an explicit tile variant (0: 128x128 2-stage, 1: 128x128 3-stage,
- * 2: 256x128 2-stage, 3: 256x128 3-stage, 4: 256x256 2-stage, 5: 128x256 3-stage).  st_gemm_nt picks per shape. */
+ * 2: 256x128 2-stage, 3: 256x128 3-stage, 4: 256x256 2-stage, 5: 128x256 3-stage, 6/7: 256x256 / 128x128 mid-tile barrier,
+ * 8: 256x256 with 4 waves of 128x128 and a hand-written schedule, 9: the same tile, compiler schedule).  st_gemm_nt picks per shape. */
 int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                        const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc, int accumulate,
                        int M, int N, int K, st_stream_t stream);

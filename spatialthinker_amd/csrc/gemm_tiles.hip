@@ -46,6 +46,17 @@ __device__ __forceinline__ void pin_schedule() {
     if constexpr (I + 1 < SLOTS) pin_schedule<I + 1, SLOTS, BASE, EXTRA, NVMEM>();
 }
 
+// Tail split (1 workgroup per CU tiles only): a grid of q * CUs + r tiles spends a whole round on its last r tiles.  The launch
+// keeps the first `full_blocks` tiles as they are and cuts every remaining tile into `split` K-slices ("pieces", dispatched last):
+// a piece leaves its fp32 accumulators in the workspace in fragment order, and a second launch of the same kernel (mode 2, one
+// mode 2, no K loop) sums the slices in a fixed order and runs the regular epilogue; a tail tile is shared by `fin_sub`
+// workgroups there (grid.y, each takes TN / fin_sub of every wave's column tiles) because one CU streams the slices of a whole
+// tile far slower than the pieces produce them.  Deterministic.
+struct TailArgs {
+    float* ws;
+    int full_blocks, split, mode, fin_sub;
+};
+
 // SWIGLU (decode MLP): B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows
 // inside every wave's column slice, so a lane holds gate and up of the same output column in adjacent MFMA tiles and the
 // epilogue writes act(gate) * up for BN/2 output columns — the (M, 2N) intermediate and the SwiGLU launch disappear.
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                                                                 const uint16_t* __restrict__ res, int64_t ldr,
                                                                 uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc,
                                                                 int M, int N, int K, int tiles_m, int tiles_n, int kt_per_split,
-                                                                int64_t slab_stride) {
+                                                                int64_t slab_stride, TailArgs tail) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;            // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;            // MFMA tiles per wave
@@ -83,6 +94,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 
     const int nb = tiles_m * tiles_n;
     int bid = blockIdx.x;
+    int piece = -1;
+    if constexpr (!SWIGLU) {
+        if (tail.mode == 2) bid = tail.full_blocks + blockIdx.x;
+        else if (bid >= tail.full_blocks) { piece = bid - tail.full_blocks; bid = tail.full_blocks + piece / tail.split; }
+    }
     {
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -133,11 +149,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // split-K (decode shapes): grid.y slices of kt_per_split K-tiles, fp32 partial slab per slice (summed by a finish kernel)
-    const int kt_begin = blockIdx.y * kt_per_split;
-    const int nk = min(K / 64 - kt_begin, kt_per_split);
+    int kt_begin = blockIdx.y * kt_per_split;
+    int nk = min(K / 64 - kt_begin, kt_per_split);
+    int ni_lo = 0, ni_hi = TN;                               // column tiles this workgroup finishes (all of them unless mode 2)
+    if constexpr (!SWIGLU) {
+        if (tail.mode == 2) { kt_begin = 0; ni_lo = blockIdx.y * (TN / tail.fin_sub); ni_hi = ni_lo + TN / tail.fin_sub; }
+        if (piece >= 0) {
+            const int per = (K / 64 + tail.split - 1) / tail.split;
+            kt_begin = (piece % tail.split) * per;
+            nk = min(K / 64 - kt_begin, per);
+        }
+        if (tail.mode == 2) nk = 0;
+    }
     A += kt_begin * 64;
     B += kt_begin * 64;
-    if (!OUT_BF16 && !SWIGLU) Cf += blockIdx.y * slab_stride;
+    if (!OUT_BF16 && !SWIGLU && tail.mode != 2) Cf += blockIdx.y * slab_stride;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);
 
@@ -201,10 +227,92 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][ni], af[1][mi], acc[ni][mi], 0, 0, 0);
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     };
+    constexpr bool BIG4 = MIDBAR && NW == 4 && TM == 8 && TN == 8;
     if constexpr (!MIDBAR) {
         int kt = 0;
         for (; kt + STAGES - 1 < nk; ++kt) tile_body(kt, std::true_type{});
         for (; kt < nk; ++kt) tile_body(kt, std::false_type{});
+    } else if constexpr (BIG4) {
+        // One wave per SIMD, 128 x 128 per wave: the 64 accumulator tiles fill the 256 AGPRs, the LDS fragment traffic per MFMA is
+        // half that of the 8-wave layout.  Nothing else runs on the SIMD, so the schedule is written out by hand: the MFMAs are
+        // volatile asm with the accumulator tied in place ("+a": hipcc otherwise rotates the 64 tuples through VGPRs, 280 moves
+        // per K-tile), and the LDS reads / LDS-DMA issues sit between them in source order (volatile asm pins memory operations).
+        static_assert(STAGES == 2 && EVEN_DMA, "two LDS slots, even DMA split");
+        bf16x8 af[2][TM], bfr[2][TN];
+        const int ra0 = wm * WTM + frow, rb0 = wn * WTN + frow;
+        int offA[2], offB[2];                                // rows i*16 further down share the swizzle: + i * 2048 bytes
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kc = s2 * 4 + fk;
+            offA[s2] = ra0 * 128 + ((kc ^ ((ra0 >> 1) & 7)) << 4);
+            offB[s2] = A_BYTES + rb0 * 128 + ((kc ^ ((rb0 >> 1) & 7)) << 4);
+        }
+        // LDS-DMA sources: uniform 64-bit base (advanced per K-tile in SGPRs) + one 32-bit lane offset per copy, relative to the
+        // tile's first row — 16 VGPRs stay live instead of 16 address pairs recomputed or spilled
+        const char* Abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
+        const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+        uint32_t aoff[A_PER], boff[B_PER];
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int inst = wave * A_PER + j, p2 = inst * 64 + lane, r = p2 >> 3, kc = (p2 & 7) ^ ((r >> 1) & 7);
+            const int rr = min(r, M - 1 - m0);
+            aoff[j] = (uint32_t)rr * (uint32_t)(lda * 2) + kc * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int inst = wave * B_PER + j, p2 = inst * 64 + lane, r = p2 >> 3, kc = (p2 & 7) ^ ((r >> 1) & 7);
+            const int rr = min(r, N - 1 - n0);
+            boff[j] = (uint32_t)rr * (uint32_t)(ldb * 2) + kc * 16;
+        }
+        auto dma_one = [&](int kt, char* dst, int j) {       // j < A_PER: A copy j, else B copy j - A_PER
+            if (j < A_PER) glds16t(Abase + (int64_t)kt * 128 + aoff[j], dst + (wave * A_PER + j) * 1024);
+            else glds16t(Bbase + (int64_t)kt * 128 + boff[j - A_PER], dst + A_BYTES + (wave * B_PER + j - A_PER) * 1024);
+        };
+        auto rd = [&](const char* base, int s2, int i) {      // i < TM: A fragment i, else B fragment i - TM
+            if (i < TM) af[s2][i] = *reinterpret_cast<const bf16x8*>(base + offA[s2] + i * 2048);
+            else bfr[s2][i - TM] = *reinterpret_cast<const bf16x8*>(base + offB[s2] + (i - TM) * 2048);
+        };
+        auto mma = [&](int s2, int idx) {
+            const int ni = idx / TM, mi = idx % TM;
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ni][mi]) : "v"(bfr[s2][ni]), "v"(af[s2][mi]));
+        };
+        if (nk > 1) { stage(1, smem + STAGE); wait_vmcnt<PER_WAVE>(); } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (nk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) rd(smem, 0, i);
+        }
+        auto tile = [&](int kt, auto next_tag, auto dma_tag) {
+            constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_DMA = decltype(dma_tag)::value;
+            char* cur = smem + (kt & 1) * STAGE;
+            const char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            // phase A: MFMAs of k-step 0; the 16 fragment reads of k-step 1 go out under the first half
+#pragma unroll
+            for (int idx = 0; idx < TM * TN; ++idx) {
+                mma(0, idx);
+                if ((idx & 1) == 1 && idx / 2 < TM + TN) rd(cur, 1, idx / 2);
+            }
+            if constexpr (HAS_NEXT) {
+                wait_vmcnt<0>();                             // tile kt+1 has landed (issued one tile ago)
+                __builtin_amdgcn_s_barrier();                // ... for every wave, and every wave holds tile kt in registers
+                asm volatile("" ::: "memory");
+            }
+            // phase B: MFMAs of k-step 1; DMA of tile kt+2 into the slot just vacated + fragment reads of (kt+1, k-step 0)
+#pragma unroll
+            for (int idx = 0; idx < TM * TN; ++idx) {
+                mma(1, idx);
+                if constexpr (HAS_NEXT) {
+                    if ((idx & 3) == 1 && idx / 4 < TM + TN) rd(nxt, 0, idx / 4);
+                    if constexpr (HAS_DMA) { if ((idx & 3) == 3 && idx / 4 < PER_WAVE) dma_one(kt + 2, cur, idx / 4); }
+                }
+            }
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { tile(kt, std::true_type{}, std::false_type{}); ++kt; }
+        if (kt < nk) tile(kt, std::false_type{}, std::false_type{});
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results -> epilogue reads: the hazard checker cannot see into asm
     } else {
         static_assert(!MIDBAR || STAGES == 2, "mid-tile barrier schedule uses exactly two LDS slots");
         bf16x8 af[2][TM], bfr[2][TN];
@@ -261,6 +369,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         if (kt < nk) tile(kt, std::false_type{}, std::false_type{});
     }
 
+    if constexpr (!SWIGLU) {
+        if (piece >= 0) {                                    // K-slice of a tail tile: accumulators to the workspace, fragment order
+            float4* wp = reinterpret_cast<float4*>(tail.ws) + ((int64_t)(piece * NW + wave) * (TN * TM)) * 64 + lane;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    wp[(ni * TM + mi) * 64] = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+            return;
+        }
+        if (tail.mode == 2) {                                // sum the slices of this tail tile, then the regular epilogue
+            for (int sp = 0; sp < tail.split; ++sp) {
+                const float4* wp = reinterpret_cast<const float4*>(tail.ws) + ((int64_t)((blockIdx.x * tail.split + sp) * NW + wave) * (TN * TM)) * 64 + lane;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        if (ni < ni_lo || ni >= ni_hi) continue;
+                        const float4 v = wp[(ni * TM + mi) * 64];
+                        acc[ni][mi][0] += v.x; acc[ni][mi][1] += v.y; acc[ni][mi][2] += v.z; acc[ni][mi][3] += v.w;
+                    }
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + wm * WTM + mi * 16 + (lane & 15);
@@ -333,7 +465,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
+            if (n >= N || ni < ni_lo || ni >= ni_hi) continue;
             float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
             const bool full = (n + 3 < N);
             if (HAS_BIAS) {
@@ -371,6 +503,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     }
 }
 
+static float* g_tail_ws = nullptr;          // st_gemm_set_workspace: fp32 slices of split tail tiles (one stream at a time)
+static int64_t g_tail_ws_bytes = 0;
+
+extern "C" int st_gemm_set_workspace(void* ws, int64_t bytes) {
+    g_tail_ws = reinterpret_cast<float*>(ws);
+    g_tail_ws_bytes = ws ? bytes : 0;
+    return 0;
+}
+
+static int st_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
                        int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s, int splits = 1,
@@ -384,8 +535,31 @@ static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     }
     const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN);
     const int kt_per_split = st_cdiv(K / 64, splits);
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, st_cdiv(K / 64, kt_per_split)), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, bias, res,
-                       ldr, Cb, Cf, ldc, M, N, K, tiles_m, tiles_n, kt_per_split, slab_stride);
+    const int nb = tiles_m * tiles_n;
+    TailArgs tail{nullptr, nb, 1, 0, 1};
+    int tail_tiles = 0;
+    if (BM * BN >= 256 * 256 && splits == 1 && g_tail_ws) {  // one workgroup per CU: whole rounds of CUs tiles, then the tail
+        const int ncu = st_num_cus(), nkt = K / 64, r = nb % ncu;
+        const int64_t cap = g_tail_ws_bytes / ((int64_t)BM * BN * 4);
+        // cost in K-tile steps (~1.5 us each at 256x256x64), fitted to kernel traces at 7B shapes: a whole tile pays ~4 steps of
+        // prologue + epilogue, a piece ~14 (cold start, 256 KiB fp32 slice written), the finish launch ~20
+        int best = 1, best_cost = nkt + 4;
+        for (int S = 2; S <= 8 && r > 0; ++S) {
+            if ((int64_t)r * S > cap || S * 4 > nkt) break;
+            const int cost = st_cdiv(r * S, ncu) * (st_cdiv(nkt, S) + 14) + 20;
+            if (cost < best_cost) { best = S; best_cost = cost; }
+        }
+        if (best > 1) { tail = TailArgs{g_tail_ws, nb - r, best, 0, 1}; tail_tiles = r; }
+    }
+    hipLaunchKernelGGL(kern, dim3(tail.full_blocks + tail_tiles * tail.split, st_cdiv(K / 64, kt_per_split)), dim3(64 * WM * WN), smem, s, A,
+                       lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, tiles_m, tiles_n, kt_per_split, slab_stride, tail);
+    if (tail_tiles) {
+        tail.mode = 2;
+        constexpr int TN_ = BN / WN / 16;
+        while (tail.fin_sub * 2 <= TN_ && tail_tiles * tail.fin_sub * 2 <= 4 * st_num_cus()) tail.fin_sub *= 2;
+        hipLaunchKernelGGL(kern, dim3(tail_tiles, tail.fin_sub), dim3(64 * WM * WN), 0 /* no K loop: no LDS */, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K,
+                           tiles_m, tiles_n, kt_per_split, slab_stride, tail);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -415,6 +589,8 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
         case 5: TILE_GO(128, 256, 2, 4, 3, false);
         case 6: TILE_GO(256, 256, 4, 2, 2, true);
         case 7: TILE_GO(128, 128, 2, 2, 2, true);
+        case 8: TILE_GO(256, 256, 2, 2, 2, true);          // 4 waves x (128 x 128): one wave per SIMD, accumulators fill the AGPRs
+        case 9: TILE_GO(256, 256, 2, 2, 2, false);
         default: return ST_EINVAL;
     }
 #undef TILE_GO
@@ -467,7 +643,8 @@ static int launch_tile_swiglu(const uint16_t* A, int64_t lda, const uint16_t* B,
     const int tiles_m = st_cdiv(M, BM), tiles_n = st_cdiv(N, BN / 2);
     // SWIGLU mode: the fp32-output pointer slot carries the optional bf16 gate|up buffer, the residual stride slot its row stride
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1), dim3(64 * WM * WN), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr,
-                       (const uint16_t*)nullptr, ldgu, Cb, reinterpret_cast<float*>(gu), ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0);
+                       (const uint16_t*)nullptr, ldgu, Cb, reinterpret_cast<float*>(gu), ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0,
+                       TailArgs{nullptr, tiles_m * tiles_n, 1, 0, 1});
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -214,6 +214,29 @@ def autotune_decode_gemm(M: int, weights, reps: int = 2):
     return best
 
 
+_gemm_ws = {}
+
+
+def _gemm_workspace(device, nbytes: int = 128 << 20):
+    """Registers (once) the tail-split workspace of st_gemm_nt (st_gemm_set_workspace); ST_GEMM_TAIL_SPLIT=0 leaves it off."""
+    if "ws" not in _gemm_ws:
+        import os
+        ws = None
+        if os.environ.get("ST_GEMM_TAIL_SPLIT", "1") != "0":
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            lib().st_gemm_set_workspace(_p(ws), nbytes)
+        _gemm_ws["ws"] = ws
+    return _gemm_ws["ws"]
+
+
+def gemm_tail_split(enable: bool, device="cuda"):
+    """Switch the tail split of the 256x256-tile GEMMs on/off at run time (tests, A/B timing)."""
+    ws = _gemm_workspace(device)
+    if ws is None and enable:
+        ws = _gemm_ws["ws"] = torch.empty(128 << 20, dtype=torch.uint8, device=device)
+    lib().st_gemm_set_workspace(_p(ws) if enable else None, ws.numel() if (enable and ws is not None) else 0)
+
+
 def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulate=False):
     """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(+residual).  Returns bf16 `out` (allocated if needed) unless `out_f32` given."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
@@ -234,6 +257,7 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
                                             _p(out), out.stride(0), _p(scratch), scratch.numel(), M, N, K, _s())
         return out
     c = out if out_f32 is None else out_f32
+    _gemm_workspace(a.device)
     lib().st_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
                      residual.stride(0) if residual is not None else 0, _p(out) if out_f32 is None else None,
                      _p(out_f32), c.stride(0), int(accumulate), M, N, K, _s())

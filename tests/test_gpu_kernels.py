@@ -283,7 +283,7 @@ def test_gemm_nt(ops, M_, N, K):
     assert np.abs(acc.cpu().numpy() - want.numpy()).max() < scale * 1e-5 + 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("K", [64, 128, 192, 320])
 def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
     """Every tile/pipeline variant (2- and 3-slot rings, the mid-tile-barrier schedule) at 1, 2, 3 and 5 K-tiles — the
@@ -299,6 +299,41 @@ def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
     acc = torch.full((M_, N), 0.25, dtype=torch.float32, device="cuda")
     ops.gemm_nt_variant(variant, a, b, out_f32=acc, accumulate=True)
     assert float((acc - want - 0.25).abs().max()) < scale * 1e-5 + 1e-4
+
+
+@pytest.mark.parametrize("variant", [6, 8])
+@pytest.mark.parametrize("shape", [(4200, 4096, 4096), (3000, 5700, 3200), (70000, 300, 4096)])
+def test_gemm_tail_split_matches_unsplit(ops, variant, shape):
+    """st_gemm_set_workspace: the tiles beyond whole rounds of the CUs are cut into K-slices (fp32 partials + a finish launch
+    that runs the epilogue).  Every epilogue kind, ragged edges, against the unsplit launch and the fp32 product."""
+    M_, N, K = shape
+    rs = np.random.RandomState(M_ % 97)
+    a = torch.from_numpy(rs.standard_normal((M_, K)).astype(np.float32)).cuda().bfloat16()
+    b = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).cuda().bfloat16()
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).cuda().bfloat16()
+    res = torch.from_numpy(rs.standard_normal((M_, N)).astype(np.float32)).cuda().bfloat16()
+    want = a.float() @ b.float().t()
+    scale = float(want.abs().max())
+    outs = {}
+    try:
+        for on in (False, True):
+            ops.gemm_tail_split(on)
+            c = ops.gemm_nt_variant(variant, a, b)
+            c2 = ops.gemm_nt_variant(variant, a, b, bias=bias, residual=res)
+            f = torch.full((M_, N), 0.5, dtype=torch.float32, device="cuda")
+            ops.gemm_nt_variant(variant, a, b, out_f32=f, accumulate=True)
+            outs[on] = (c, c2, f)
+    finally:
+        ops.gemm_tail_split(True)
+    tiles = -(-M_ // 256) * -(-N // 256)
+    assert tiles > 256 and tiles % 256 != 0                  # the shapes do leave a tail on a 256-CU part
+    for on in (False, True):
+        c, c2, f = outs[on]
+        assert float((c.float() - want).abs().max()) < scale * 2 ** -7
+        assert float((c2.float() - (want + bias.float() + res.float())).abs().max()) < scale * 2 ** -6
+        assert float((f - want - 0.5).abs().max()) < scale * 1e-5 + 1e-3
+    assert float((outs[True][2] - outs[False][2]).abs().max()) < scale * 1e-5 + 1e-3
+    assert not torch.equal(outs[True][2], outs[False][2])     # the split really ran (different fp32 summation order somewhere)
 
 
 def test_gemm_identity_layout(ops):

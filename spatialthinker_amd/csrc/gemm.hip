@@ -383,16 +383,17 @@ static int launch_decode_tiles(int variant, int splits, const uint16_t* A, int64
 static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant, int* splits) {
     const int bm = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
     const bool wide = N >= 16384;
-    int v, bn, row_tiles = 1;
+    const int mt = st_cdiv(M, 256);                          // 256-row tiles (2 for the 257..512-row decode batches)
+    int v, bn, row_tiles = mt;
     if (bm == 64) { v = (wide || K >= 8192) ? 11 : 10; bn = v == 11 ? 128 : 64; }
     else if (bm == 128) { v = wide ? 14 : 13; bn = wide ? 128 : 64; }
     else if (wide) {
         // 256x256 tiles are ~10 % faster per flop than 256x128 but quantise worse on 256 CUs: compare the last-round fill
-        const int t18 = st_cdiv(N, 256), t16 = st_cdiv(N, 128);
+        const int t18 = mt * st_cdiv(N, 256), t16 = mt * st_cdiv(N, 128);
         const double e18 = 1.1 * t18 / (double)(st_cdiv(t18, 256) * 256), e16 = t16 / (double)(st_cdiv(t16, 256) * 256);
         v = e18 >= e16 ? 18 : 16; bn = v == 18 ? 256 : 128;
     } else if (K >= 8192) { v = 16; bn = 128; }
-    else { v = 13; bn = 64; row_tiles = 2; }
+    else { v = 13; bn = 64; row_tiles = st_cdiv(M, 128); }
     int sp = 1;
     if (!wide) {
         const int tiles = row_tiles * st_cdiv(N, bn);
@@ -411,7 +412,7 @@ static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant
 extern "C" int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
                                          const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,
                                          float* scratch, int64_t scratch_elems, int M, int N, int K, st_stream_t stream) {
-    if (!A || !B || !out_bf16 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+    if (!A || !B || !out_bf16 || M <= 0 || M > ST_DECODE_MAX_ROWS || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
         ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -428,7 +429,7 @@ extern "C" int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16*
  * (st_decode_finish_norm / st_decode_finish_qkv) sums them.  *splits_out = number of slabs written (>= 1). */
 extern "C" int st_gemm_nt_decode_slabs(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, float* scratch,
                                        int64_t scratch_elems, int M, int N, int K, int* splits_out, st_stream_t stream) {
-    if (!A || !B || !scratch || !splits_out || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K ||
+    if (!A || !B || !scratch || !splits_out || M <= 0 || M > ST_DECODE_MAX_ROWS || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K ||
         ldb < K || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15) || scratch_elems < (int64_t)M * N)
         return ST_EINVAL;
     int variant, splits;
@@ -446,7 +447,7 @@ extern "C" int st_gemm_nt_decode_slabs(const st_bf16* A, int64_t lda, const st_b
 extern "C" int st_gemm_nt_skinny(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                                  const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc, float* scratch,
                                  int64_t scratch_elems, int M, int N, int K, st_stream_t stream) {
-    if (!A || !B || !out_bf16 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+    if (!A || !B || !out_bf16 || M <= 0 || M > ST_DECODE_MAX_ROWS || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
         ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
         return ST_EINVAL;
     int variant, splits;

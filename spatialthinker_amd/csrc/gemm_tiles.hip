@@ -663,7 +663,7 @@ extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate
 
 extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
                                      int M, int I, int K, st_stream_t stream) {
-    if (!A || !gate_up_w || !out || M <= 0 || M > 256 || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+    if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
         ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -672,7 +672,7 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
     // One row tile (M <= 256): the only freedom is the column tile.  Cost ~ rounds over 256 CUs x tile width; the 7B gate/up
     // (I = 18944) gives 148 tiles at 128 output columns (0.58 of the CUs) and 198 at 96 (-10 % time).  A 256x160 tile as 8x1
     // waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
-    auto cost = [&](int cols) { const int t = st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
+    auto cost = [&](int cols) { const int t = st_cdiv(M, 256) * st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
     // 256x160 with the 8-column interleave: 3-slot ring (two K-tiles of weights in flight: the 2-slot variants sit parked on HBM
     // latency half of the time) and 237 workgroups for I = 18944
     if (cost(80) <= cost(96) && cost(80) <= cost(128))                                         // 90 us vs 102 us (256x192) on MI355X

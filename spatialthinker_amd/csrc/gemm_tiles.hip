@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             }
             if constexpr (HAS_NEXT) {
                 wait_vmcnt<0>();                             // tile kt+1 has landed (issued one tile ago)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of slot kt have RETURNED before anyone may refill it
                 __builtin_amdgcn_s_barrier();                // ... for every wave, and every wave holds tile kt in registers
                 asm volatile("" ::: "memory");
             }
@@ -312,7 +313,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{}, std::true_type{});
         if (kt + 1 < nk) { tile(kt, std::true_type{}, std::false_type{}); ++kt; }
         if (kt < nk) tile(kt, std::false_type{}, std::false_type{});
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results -> epilogue reads: the hazard checker cannot see into asm
+        // MFMA results -> epilogue reads: the hazard checker cannot see into asm, and a bare s_nop statement does not stop hipcc from
+        // scheduling the first v_accvgpr_read of the epilogue right behind the last MFMA (seen once in ~6 runs as 4 stale rows of the
+        // last accumulator).  Every accumulator therefore passes THROUGH a wait: row ni of the tiles per statement, oldest first, so
+        // the most recent MFMAs have 64 wait states behind them when their results become readable.
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+            asm volatile("s_nop 7" : "+a"(acc[ni][0]), "+a"(acc[ni][1]), "+a"(acc[ni][2]), "+a"(acc[ni][3]), "+a"(acc[ni][4]), "+a"(acc[ni][5]),
+                         "+a"(acc[ni][6]), "+a"(acc[ni][7]));
     } else {
         static_assert(!MIDBAR || STAGES == 2, "mid-tile barrier schedule uses exactly two LDS slots");
         bf16x8 af[2][TM], bfr[2][TN];
@@ -354,6 +362,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (HAS_NEXT) {
                 wait_vmcnt<0>();                             // tile kt+1 (issued one tile ago) has landed
+                // the fragment reads of slot kt must have RETURNED (not merely been issued) before another wave's LDS-DMA may refill
+                // the slot; the k-step-1 MFMAs behind the barrier need them anyway, so the wait costs nothing here
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                // ... for every wave, and every wave is done reading slot kt
                 asm volatile("" ::: "memory");
                 if constexpr (HAS_DMA) stage(kt + 2, smem + (kt & 1) * STAGE);
@@ -462,6 +473,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             }
             continue;
         }
+        // bias / residual first, as 8-byte vectors and for all column tiles of this row at once: one memory round trip per row of
+        // MFMA tiles instead of four 2-byte loads per tile (59 -> 41 us of fixed cost per round of 256 tiles).  Wider batches
+        // measured slower (all 32 residual vectors of a wave at once: o-proj 305 -> 323 us), and so did batching the fp32
+        // accumulate reads ahead of their stores (36 -> 52 us per round).
+        uint2 rv[TN], bv[TN];
+        if constexpr (HAS_BIAS) {
+            const bool vec = (reinterpret_cast<uintptr_t>(bias) & 7) == 0;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
+                bv[ni] = make_uint2(0u, 0u);
+                if (n >= N || ni < ni_lo || ni >= ni_hi) continue;
+                if (n + 3 < N && vec) bv[ni] = *reinterpret_cast<const uint2*>(bias + n);
+                else {
+                    uint32_t e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) e[r] = bias[n + r];
+                    bv[ni] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                }
+            }
+        }
+        if constexpr (HAS_RES) {
+            const bool vec = ((ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(res) & 7) == 0);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
+                rv[ni] = make_uint2(0u, 0u);
+                if (n >= N || ni < ni_lo || ni >= ni_hi) continue;
+                const uint16_t* rp = res + (int64_t)m * ldr + n;
+                if (n + 3 < N && vec) rv[ni] = *reinterpret_cast<const uint2*>(rp);
+                else {
+                    uint32_t e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) e[r] = rp[r];
+                    rv[ni] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                }
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int n = n0 + wn * WTN + ni * 16 + (lane >> 4) * 4;
@@ -469,13 +518,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
             const bool full = (n + 3 < N);
             if (HAS_BIAS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (full || n + r < N) v[r] += bf2f(bias[n + r]);
+                v[0] += bf2f((uint16_t)(bv[ni].x & 0xffffu)); v[1] += bf2f((uint16_t)(bv[ni].x >> 16));
+                v[2] += bf2f((uint16_t)(bv[ni].y & 0xffffu)); v[3] += bf2f((uint16_t)(bv[ni].y >> 16));
             }
             if (HAS_RES) {
-                const uint16_t* rp = res + (int64_t)m * ldr + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (full || n + r < N) v[r] += bf2f(rp[r]);
+                v[0] += bf2f((uint16_t)(rv[ni].x & 0xffffu)); v[1] += bf2f((uint16_t)(rv[ni].x >> 16));
+                v[2] += bf2f((uint16_t)(rv[ni].y & 0xffffu)); v[3] += bf2f((uint16_t)(rv[ni].y >> 16));
             }
             if (OUT_BF16) {
                 uint16_t* cp = Cb + (int64_t)m * ldc + n;
@@ -490,7 +538,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                 }
             } else {
                 float* cp = Cf + (int64_t)m * ldc + n;
-                if (full && ((ldc & 3) == 0)) {
+                if (full && ((ldc & 3) == 0)) {                 // (batching these reads ahead of the stores measured slower)
                     float4 o = ACCUM ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
                     o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
                     *reinterpret_cast<float4*>(cp) = o;

@@ -329,9 +329,9 @@ def test_gemm_tail_split_matches_unsplit(ops, variant, shape):
     assert tiles > 256 and tiles % 256 != 0                  # the shapes do leave a tail on a 256-CU part
     for on in (False, True):
         c, c2, f = outs[on]
-        assert float((c.float() - want).abs().max()) < scale * 2 ** -7
-        assert float((c2.float() - (want + bias.float() + res.float())).abs().max()) < scale * 2 ** -6
-        assert float((f - want - 0.5).abs().max()) < scale * 1e-5 + 1e-3
+        assert float((c.float() - want).abs().max()) < scale * 2 ** -7, on
+        assert float((c2.float() - (want + bias.float() + res.float())).abs().max()) < scale * 2 ** -6, on
+        assert float((f - want - 0.5).abs().max()) < scale * 1e-5 + 1e-3, on
     assert float((outs[True][2] - outs[False][2]).abs().max()) < scale * 1e-5 + 1e-3
     assert not torch.equal(outs[True][2], outs[False][2])     # the split really ran (different fp32 summation order somewhere)
 

@@ -358,7 +358,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             // phase A: MFMAs of k-step 0 with the reads of k-step 1 in their shadow
             load_frags(cur, 1, af[1], bfr[1]);
             mfmas(af[0], bfr[0]);
-            pin_schedule<0, SLOTS, BASE, EXTRA, 0>();
+            // the reads are spread over the first 5/8 of the phase's MFMAs so that the last of them has time to return before the
+            // lgkmcnt wait in front of the barrier (all reads up front measured 3-8 % slower: LDS port contention with the DMA)
+            constexpr int FRONT = (TM * TN * 5) / 8;          // reads spread over the first 5/8 of the MFMAs
+            constexpr int FBASE = FRONT / SLOTS, FEXTRA = FRONT - FBASE * SLOTS;
+            pin_schedule<0, SLOTS, FBASE, FEXTRA, 0>();
+            if constexpr (TM * TN > FRONT) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - FRONT, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (HAS_NEXT) {
                 wait_vmcnt<0>();                             // tile kt+1 (issued one tile ago) has landed

@@ -105,7 +105,7 @@ class Generator:
         forced_len_g = None if forced_lengths is None else torch.as_tensor(forced_lengths, device=dev, dtype=I32)
         # split-KV chunk sizes of the decode attention (keys per workgroup): prompt keys / generated keys
         CK = int(os.environ.get("ST_DECODE_CKP", "256"))
-        CKG = int(os.environ.get("ST_DECODE_CKG", "256"))
+        CKG = int(os.environ.get("ST_DECODE_CKG", "512"))   # same-box A/B at the bench workload: gen 12.04 s (256) -> 11.74 s (512), 11.79 s (1024)
         C = max(1, int(-(-int(lens.max()) // CK)))
         Cg = max(1, -(-R // CKG))
         NP = C + Cg

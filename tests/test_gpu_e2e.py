@@ -34,3 +34,29 @@ def test_main_runs_two_grpo_steps(tmp_path):
     assert last in ("2", "3")
     assert os.path.exists(tmp_path / "ckpt" / f"global_step_{last}" / "actor" / "huggingface" / "model.safetensors")
     assert os.path.exists(tmp_path / "ckpt" / f"global_step_{last}" / "actor" / "optim_world_size_1_rank_0.pt")
+
+
+def test_config1_3b_vanilla_grpo_r1v_2x4_224px(tmp_path):
+    """BASELINE config #1's shape on the GPU engine: Qwen2.5-VL-3B dimensions (tied embeddings), vanilla GRPO with the `r1v` reward,
+    2 prompts x G=4, one 224x224 image (256 patches -> 64 image tokens) + 700 text tokens per prompt
+    (scripts/qwen_2_5_3b_stvqa_vanilla_grpo.sh; responses capped at 24 tokens to keep the test short)."""
+    cmd = [sys.executable, "-m", "verl.trainer.main", "data.train_files=synthetic:stvqa:224x224@train", "data.val_files=", "data.rollout_batch_size=2",
+           "data.max_prompt_length=1024", "data.max_response_length=24", "worker.actor.model.model_path=random:3b",
+           "worker.actor.global_batch_size=2", "worker.actor.micro_batch_size_per_device_for_update=4",
+           "worker.actor.micro_batch_size_per_device_for_experience=8", "worker.actor.optim.strategy=adamw_bf16",
+           "worker.actor.fsdp.torch_dtype=bf16", "worker.rollout.n=4", "worker.reward.score_function=r1v",
+           "algorithm.use_kl_loss=true", "algorithm.kl_penalty=low_var_kl", "algorithm.kl_coef=1.0e-2", "trainer.max_steps=2",
+           "trainer.total_episodes=1", "trainer.n_gpus_per_node=1", "trainer.val_before_train=false", "trainer.logger=['console']",
+           "trainer.save_freq=-1", f"trainer.save_checkpoint_path={tmp_path}/ckpt"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, ST_SKIP_FINAL_SAVE="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("step ")]
+    assert len(lines) == 2, p.stdout[-2000:]
+    for key in ("actor/pg_loss", "actor/kl_loss", "actor/grad_norm", "reward/overall", "reward/format", "reward/accuracy", "timing_s/gen",
+                "timing_s/old", "timing_s/ref", "timing_s/update_actor", "prompt_length/mean"):
+        assert key in lines[-1], key
+    import re
+    gn = float(re.search(r"actor/grad_norm:([-+0-9.eE]+|nan|inf)", lines[-1]).group(1))
+    assert gn == gn and gn > 0.0 and gn < 1e4, lines[-1]                       # finite, non-zero gradient through the tied embedding
+    pl = float(re.search(r"prompt_length/mean:([0-9.eE+]+)", lines[-1]).group(1))
+    assert abs(pl - (700 + 2 + 64)) < 1, lines[-1]                              # 200 + 500 text, vision start/end, 64 image tokens

@@ -20,11 +20,14 @@ FULL = dict(hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=2
 VISION_END, EOS = 151653, 151645
 
 
-def _params(seed=3):
+FULL_3B = dict(FULL, hidden_size=2048, intermediate_size=11008, num_heads=16, num_kv_heads=2, vocab_size=151936, tie_word_embeddings=True)
+
+
+def _params(seed=3, dims=None):
     """Cheap deterministic bf16-exact weights (the big tables from a ramp: value quality is irrelevant, cost is not)."""
     rs = np.random.RandomState(seed)
     out = {}
-    for name, shape in tiny.param_shapes(FULL).items():
+    for name, shape in tiny.param_shapes(dims or FULL).items():
         n = int(np.prod(shape))
         if "norm" in name or "ln_q" in name:
             w = 1.0 + 0.1 * rs.standard_normal(shape)
@@ -39,7 +42,7 @@ def _params(seed=3):
 
 
 def _group_batch(rs, n_roll=3, text=(40, 60), grid=(1, 16, 20), R=48, Pc=256):
-    """One prompt (text + 16x20-patch image = 80 image tokens) with n_roll rollouts of different lengths."""
+    """One prompt (text + one image of `grid` patches) with n_roll rollouts of different lengths."""
     n_img = grid[0] * grid[1] * grid[2] // 4
     prompt = (rs.randint(0, 150000, text[0]).tolist() + [FULL["vision_start_token_id"]] + [FULL["image_token_id"]] * n_img + [VISION_END]
               + rs.randint(0, 150000, text[1]).tolist())
@@ -97,3 +100,63 @@ def test_7b_dimension_layer_shared_prompt_vs_oracle_fwd_bwd():
         rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-20)
         print(f"  grad {n_}: rel err {rel:.4f}")
         assert rel < 8e-2, (n_, rel)
+
+
+def _run_group_case(dims, rs, batch, grad_suffixes, tol_lp, tol_grad):
+    """Shared body: fp32 oracle per sequence vs the engine on ONE shared-prompt group; returns (max |dlogp|, {name: rel grad err})."""
+    from spatialthinker_amd import model as mdl
+    params = _params(dims=dims)
+    cfg = mdl.VLConfig(**dims)
+    store = mdl.ParamStore(cfg, trainable=True)
+    store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = mdl.Qwen25VL(cfg, store)
+    ids, mask, pos, px, g, R = batch
+    k = ids.shape[0]
+    rmask = mask[:, -R:]
+    p32 = {n_: torch.from_numpy(v).clone().requires_grad_(n_.endswith(grad_suffixes)) for n_, v in params.items()}
+    lp = Q.response_log_probs(p32, Q.VLConfig(**dims), torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), R, 1.0,
+                              torch.from_numpy(np.concatenate([px] * k, 0)), np.concatenate([g] * k, 0))
+    old = (lp.detach().numpy() + 0.2 * rs.standard_normal((k, R))).astype(np.float32)
+    adv = rs.standard_normal((k, 1)).astype(np.float32).repeat(R, 1) * rmask
+    _, gl = M.actor_micro_batch_loss(lp.detach().numpy(), old, old, adv, rmask, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1)
+    lp.backward(torch.from_numpy(gl))
+    b = eng.stage(ids, mask, pos, R, px, g, groups=[0] * k)
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    store.grad.zero_()
+    lp_e, _ = eng.forward_backward(b, dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64)),
+                                   1.0, clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
+    m = rmask.astype(bool)
+    err = float(np.abs(lp_e.cpu().numpy()[m] - lp.detach().numpy()[m]).max())
+    print(f"max |dlogp| vs fp32 oracle = {err:.4f}")
+    assert err < tol_lp, err
+    grads = store.export_hf(store.g)
+    rels = {}
+    for n_, t in p32.items():
+        if t.grad is None:
+            continue
+        want, got = t.grad.numpy(), grads[n_].float().cpu().numpy()
+        rels[n_] = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-20))
+        print(f"  grad {n_}: rel err {rels[n_]:.4f}")
+        assert rels[n_] < tol_grad, (n_, rels[n_])
+    return err, rels
+
+
+def test_3b_dimension_layer_tied_embeddings_vs_oracle_fwd_bwd():
+    """BASELINE config #2's shapes (Qwen2.5-VL-3B: hidden 2048, 16/2 heads, MLP 11008, vocab 151936, TIED embeddings, one 448x448
+    image = 32x32 patches = 256 image tokens; reference: verl/workers/fsdp_workers.py:193-215 loading
+    scripts/spatialthinker_3b_grpo.sh's model).  The embedding gradient receives BOTH the input-gather and the lm_head
+    contributions — checked against fp32 autograd through the oracle, together with the log-probs."""
+    rs = np.random.RandomState(23)
+    batch = _group_batch(rs, n_roll=3, text=(30, 50), grid=(1, 32, 32), R=48, Pc=384)
+    err, rels = _run_group_case(FULL_3B, rs, batch, ("embed_tokens.weight", "q_proj.weight", "gate_proj.weight", "merger.mlp.2.weight",
+                                                     "input_layernorm.weight"), tol_lp=3e-2, tol_grad=5e-2)
+    assert "model.language_model.embed_tokens.weight" in rels
+
+
+def test_7b_dimension_64x64_grid_full_attention_vit_vs_oracle_fwd_bwd():
+    """BASELINE config #5's image shape: 896x896 -> 64x64 patches = 4096 ViT tokens (the full-attention ViT block attends over all
+    4096 of them, windows of 64) -> 1024 image tokens; packed LM sequence ~1.2k tokens per rollout."""
+    rs = np.random.RandomState(29)
+    batch = _group_batch(rs, n_roll=2, text=(24, 40), grid=(1, 64, 64), R=32, Pc=1152)
+    _run_group_case(FULL, rs, batch, ("q_proj.weight", "blocks.1.attn.qkv.weight", "blocks.0.attn.proj.weight", "merger.mlp.0.weight",
+                                      "patch_embed.proj.weight"), tol_lp=3e-2, tol_grad=5e-2)

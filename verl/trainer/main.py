@@ -51,8 +51,15 @@ def main():
             from spatialthinker_amd.pretrained import synthetic_config
             mcfg, _ = synthetic_config(mc.model_path if is_synthetic(mc.model_path) else "random:7b")
             tiny = mcfg.hidden_size <= 512
+            grid, text = ((1, 8, 8), (8, 12)) if tiny else ((1, 32, 42), (200, 564))
+            # "synthetic:stvqa:224x224@train": square/rect images of that pixel size (SURVEY 8d': 224/448/896 -> 256/1024/4096
+            # patches) with 700 text tokens, instead of the STVQA-shaped 588x448 default
+            name = spec.split("@")[0].split(":")
+            if len(name) >= 3 and "x" in name[2]:
+                w_px, h_px = (int(v) for v in name[2].lower().split("x"))
+                grid, text = (1, h_px // mcfg.v_patch, w_px // mcfg.v_patch), ((8, 12) if tiny else (200, 500))
             return SyntheticSTVQADataset(mcfg, tokenizer, size=max(4 * cfg.data.rollout_batch_size, 64), max_prompt_length=cfg.data.max_prompt_length,
-                                         seed=cfg.data.seed, grid=(1, 8, 8) if tiny else (1, 32, 42), text_tokens=(8, 12) if tiny else (200, 564))
+                                         seed=cfg.data.seed + (1 if spec.endswith("@val") else 0), grid=grid, text_tokens=text)
         return RLHFDataset(spec, tokenizer, processor, prompt_key=cfg.data.prompt_key, answer_key=cfg.data.answer_key, image_key=cfg.data.image_key,
                            max_prompt_length=cfg.data.max_prompt_length, truncation="right", format_prompt=cfg.data.format_prompt,
                            min_pixels=cfg.data.min_pixels, max_pixels=cfg.data.max_pixels, text_only=cfg.data.text_only)

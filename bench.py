@@ -14,6 +14,7 @@ gradient all-reduce (RCCL).  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -42,7 +43,48 @@ def parse():
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher/contract check without a GPU: ranks rendezvous over gloo, time K trivial steps, rank 0 prints the JSON line")
     return ap.parse_args()
+
+
+def maybe_spawn(a):
+    """`python bench.py --gpus N` started as ONE process: launch N ranks as a CHILD torch.distributed.run (nothing has touched the
+    GPU yet — a process that has initialised HIP must never exec) and exit with its return code.  Under torchrun (RANK set) this is
+    a no-op.  Counterpart of the reference's worker-group launch (verl/single_controller/ray/base.py:75-405)."""
+    if "RANK" in os.environ or a.gpus <= 1:
+        return
+    port = os.environ.get("MASTER_PORT", "29541")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
+
+def dry_run(a):
+    """The bench contract without the engine (CPU, gloo): same barrier / max-over-ranks timing / one JSON line from rank 0."""
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        dist.init_process_group("gloo")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    for _ in range(a.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.002 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher check)", "value": a.steps * world / float(el), "unit": "steps/s", "n_gpus": world,
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": float(el) / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "none", "config": {"workload": "dry-run"}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------ synthetic STVQA-shaped data
@@ -159,8 +201,12 @@ def cpu_baseline(cfg, S_text, grid, R_mean):
 # ------------------------------------------------------------------ main
 def main():
     a = parse()
+    maybe_spawn(a)
+    if a.dry_run:
+        return dry_run(a)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))

@@ -389,8 +389,115 @@ def gen_model():
          hidden_last_token=np.stack(hid), **taps)
 
 
+# ------------------------------------------------------------------ 6. trainer-side RL math outside the GRPO kernel + rollout post-processing
+def gen_rl_extra():
+    """apply_kl_penalty's pieces + KL controllers, the non-GRPO estimators, the value loss, FlopsCounter and the rollout
+    post-processing, all evaluated by the reference's own importable functions (verl.trainer.core_algos,
+    verl.utils.torch_functional, verl.utils.flops_counter).  verl.trainer.ray_trainer / verl.workers.rollout.vllm_rollout_spmd
+    themselves need ray / vllm / tensordict: the few torch lines that glue those functions together there
+    (ray_trainer.py:125-145, vllm_rollout_spmd.py:149-176) are re-executed here on the reference functions' outputs."""
+    from types import SimpleNamespace
+
+    from verl.trainer import core_algos
+    from verl.utils import torch_functional as VF
+    from verl.utils.flops_counter import FlopsCounter
+
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    # ---- apply_kl_penalty (ray_trainer.py:125-145) for every estimator kind, one AdaptiveKLController step each
+    B, R = 7, 24
+    old = -torch.rand(B, R, generator=g) * 3
+    ref = old + torch.randn(B, R, generator=g) * 0.3
+    ref[2, :3] = old[2, :3] + torch.tensor([4.0, -12.0, 0.0])
+    lens = torch.randint(1, R + 1, (B,), generator=g)
+    mask = (torch.arange(R)[None, :] < lens[:, None]).long()
+    scores = torch.zeros(B, R)
+    scores[torch.arange(B), lens - 1] = torch.rand(B, generator=g)
+    out.update(klp_old=old.numpy(), klp_ref=ref.numpy(), klp_mask=mask.numpy(), klp_scores=scores.numpy())
+    for kind in ("kl", "abs", "mse", "low_var_kl", "chi2"):
+        ctrl = core_algos.AdaptiveKLController(init_kl_coef=0.05, target_kl=0.02, horizon=100.0)
+        kld = core_algos.compute_kl(old, ref, kl_penalty=kind) * mask
+        rewards = scores - ctrl.kl_coef * kld
+        cur = torch.mean(VF.masked_mean(kld, mask=mask, dim=-1), dim=0).item()
+        ctrl.update(current_kl=cur, n_steps=B)
+        out[f"klp_{kind}_rewards"] = rewards.numpy()
+        out[f"klp_{kind}_stats"] = np.array([cur, ctrl.kl_coef], dtype=np.float64)
+    # controller trajectories
+    ctrl = core_algos.AdaptiveKLController(init_kl_coef=0.01, target_kl=0.05, horizon=64.0)
+    kls = [0.001, 0.2, 0.05, 0.049, 0.0, 1.0, 0.06]
+    traj = []
+    for i, k in enumerate(kls):
+        ctrl.update(current_kl=k, n_steps=8 + i)
+        traj.append(ctrl.kl_coef)
+    fixed = core_algos.get_kl_controller(SimpleNamespace(kl_type="fixed", kl_coef=0.3, kl_horizon=0, kl_target=0))
+    fixed.update(current_kl=5.0, n_steps=10)
+    adaptive = core_algos.get_kl_controller(SimpleNamespace(kl_type="adaptive", kl_coef=0.3, kl_horizon=10, kl_target=0.1))
+    out.update(klc_kls=np.array(kls), klc_traj=np.array(traj, dtype=np.float64), klc_fixed=np.array([fixed.kl_coef]),
+               klc_adaptive_cls=np.array([type(adaptive).__name__ == "AdaptiveKLController"]))
+    # ---- other estimators (core_algos.py:92-133,178-278) and the value loss (:356-391)
+    N, R = 12, 10
+    uid = np.repeat(np.arange(3), 4)[torch.randperm(12, generator=g).numpy()]
+    lens = torch.randint(1, R + 1, (N,), generator=g)
+    mask = (torch.arange(R)[None, :] < lens[:, None]).long()
+    rew = torch.zeros(N, R)
+    rew[torch.arange(N), lens - 1] = torch.rand(N, generator=g)
+    dense_rew = torch.randn(N, R, generator=g) * mask
+    values = torch.randn(N, R, generator=g)
+    base = torch.rand(N, generator=g)
+    adv, ret = core_algos.compute_gae_advantage_return(dense_rew, values, mask, torch.tensor(0.99), torch.tensor(0.95))
+    out.update(est_uid=uid, est_mask=mask.numpy(), est_rew=rew.numpy(), est_dense_rew=dense_rew.numpy(), est_values=values.numpy(),
+               est_base=base.numpy(), gae_adv=adv.numpy(), gae_ret=ret.numpy())
+    adv, _ = core_algos.compute_rloo_outcome_advantage(rew.clone(), mask, uid.astype(object))
+    out["rloo_adv"] = adv.numpy()
+    adv, ret = core_algos.compute_reinforce_plus_plus_outcome_advantage(dense_rew, mask, torch.tensor(0.97))
+    out.update(rpp_adv=adv.numpy(), rpp_ret=ret.numpy())
+    adv, _ = core_algos.compute_remax_outcome_advantage(rew, base, mask)
+    out["remax_adv"] = adv.numpy()
+    vpred = values + torch.randn(N, R, generator=g) * 0.5
+    vl, vc = core_algos.compute_value_loss(vpred, ret, values, mask, 0.3)
+    out.update(vl_vpred=vpred.numpy(), vl_out=np.array([vl.item(), vc.item()], dtype=np.float32))
+    out["whiten"] = VF.masked_whiten(dense_rew, mask).numpy()
+    # ---- FlopsCounter._estimate_llama_flops (flops_counter.py:82-115) at the 7B and 3B text shapes
+    seqlens = [1612, 1480, 1750, 1333, 1612, 1900, 1211, 1499]
+    rows = []
+    for (H, V, L, nkv, nq, I) in ((3584, 152064, 28, 4, 28, 18944), (2048, 151936, 36, 2, 16, 11008)):
+        cfg = SimpleNamespace(model_type="qwen2_5_vl", hidden_size=H, vocab_size=V, num_hidden_layers=L, num_key_value_heads=nkv,
+                              num_attention_heads=nq, intermediate_size=I)
+        rows.append(FlopsCounter(cfg)._estimate_llama_flops(sum(seqlens), seqlens, 2.5))
+    out.update(flops_seqlens=np.array(seqlens), flops_dt=np.array([2.5]), flops_achieved=np.array(rows, dtype=np.float64))
+    # ---- rollout post-processing (vllm_rollout_spmd.py:144-188): n = 3 completions per prompt, ragged, EOS in the middle / absent
+    b, P, R, n, pad, eos = 3, 9, 8, 3, 99, [7, 5]
+    ids = torch.randint(10, 90, (b, P), generator=g)
+    am = torch.ones(b, P, dtype=torch.long)
+    for i, k in enumerate((0, 3, 5)):
+        ids[i, :k] = pad
+        am[i, :k] = 0
+    pos = torch.clip(am.cumsum(-1) - 1, min=0)[:, None, :].repeat(1, 3, 1)
+    pos[:, 1] += torch.randint(0, 3, (b, 1), generator=g) * am                       # distinct h/w rows as get_rope_index produces
+    pos[:, 2] += torch.randint(0, 4, (b, 1), generator=g) * am
+    comp = []
+    for i in range(b * n):
+        L_ = int(torch.randint(1, R + 1, (1,), generator=g))
+        toks = torch.randint(10, 90, (L_,), generator=g).tolist()
+        if i % 3 == 0 and L_ > 2:
+            toks[L_ // 2] = 7                                                         # EOS in the middle: everything after is masked
+        if i % 3 == 1:
+            toks[-1] = 5                                                              # ends with the second EOS id
+        comp.append(toks)
+    resp = VF.pad_2d_list_to_length(comp, pad, max_length=R)
+    ids_r, am_r, pos_r = (t.repeat_interleave(n, dim=0) for t in (ids, am, pos))
+    delta = torch.arange(1, R + 1).view(1, -1).expand(b * n, -1).view(b * n, 1, -1).expand(b * n, 3, -1)
+    pos_full = torch.cat([pos_r, pos_r[..., -1:] + delta], dim=-1)
+    rmask = VF.get_response_mask(response_ids=resp, eos_token_id=eos, dtype=am.dtype)
+    out.update(ro_ids=ids.numpy(), ro_mask=am.numpy(), ro_pos=pos.numpy(), ro_n=np.array([n]), ro_pad=np.array([pad]), ro_eos=np.array(eos),
+               ro_completions=np.array([len(c) for c in comp]), ro_completion_tokens=np.concatenate([np.asarray(c) for c in comp]),
+               ro_prompts=ids_r.numpy(), ro_responses=resp.numpy(), ro_input_ids=torch.cat([ids_r, resp], -1).numpy(),
+               ro_attention_mask=torch.cat([am_r, rmask], -1).numpy(), ro_response_mask=rmask.numpy(), ro_position_ids=pos_full.numpy())
+    save("rl_extra", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -401,3 +508,5 @@ if __name__ == "__main__":
         gen_rewards()
     if "model" in which:
         gen_model()
+    if "extra" in which:
+        gen_rl_extra()

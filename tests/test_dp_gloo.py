@@ -77,16 +77,3 @@ def test_early_slices_plus_remainder_equal_one_full_allreduce(tmp_path):
     want = sum(torch.randn(700_001, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)) / world
     for r in range(world):
         torch.testing.assert_close(torch.load(tmp_path / f"o{r}.pt"), want, rtol=1e-6, atol=1e-7)
-
-
-def test_trainer_rank_sharding_matches_dataproto_chunk():
-    """RayPPOTrainer._shard(rank) must equal DataProto.chunk(world)[rank] (Dispatch.DP_COMPUTE_PROTO, decorator.py:106-108)."""
-    from verl.protocol import DataProto
-    from verl.trainer.ray_trainer import RayPPOTrainer
-    full = {"input_ids": torch.arange(24).view(8, 3), "s": np.array([f"s{i}" for i in range(8)], dtype=object)}
-    chunks = DataProto.from_single_dict(full).chunk(4)
-    for rank in range(4):
-        t = RayPPOTrainer.__new__(RayPPOTrainer)
-        t.rank, t.local_prompts = rank, 2
-        sh = t._shard(full)
-        assert torch.equal(sh["input_ids"], chunks[rank].batch["input_ids"]) and sh["s"].tolist() == chunks[rank].non_tensor_batch["s"].tolist()

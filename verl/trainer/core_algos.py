@@ -4,7 +4,11 @@
   compute_policy_loss / compute_kl (:291-353, :394-436) live inside st_grpo_loss, fused with the masked means and the
   gradient w.r.t. the log-probs (see spatialthinker_amd/model.py forward_backward); exposed here for inspection.
   FixedKLController / AdaptiveKLController (:36-89) are plain host objects.
-GAE / RLOO / ReMax / REINFORCE++ / value loss are outside the GRPO path (SURVEY.md §2.1 #4) and raise."""
+The other estimators of the reference — GAE (:92-133), RLOO (:178-215), REINFORCE++ (:218-246), ReMax (:249-278) — and the
+clipped value loss (:356-391) are a few elementwise passes over (bs, R) host tensors that the reference also runs on the driver
+CPU: plain torch here, pinned by tests/golden/rl_extra.npz.  Batch-wide statistics (masked_whiten) take an optional
+`all_reduce` callable so that several SPMD ranks whiten with the statistics of the GLOBAL batch, as the reference's single
+driver does."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -69,9 +73,97 @@ def compute_policy_loss_and_kl(old_log_probs, log_probs, advantages, response_ma
     return m[0], m[1], m[2], m[3], m[5], g.view_as(log_probs)
 
 
-def _outside_scope(*_a, **_k):
-    raise NotImplementedError("only the GRPO estimator is on the SpatialThinker path (algorithm.adv_estimator=grpo)")
+# ------------------------------------------------------------------ other estimators (host math)
+def masked_mean(values: torch.Tensor, mask: torch.Tensor, dim=None, eps: float = 1e-8) -> torch.Tensor:
+    """VF.masked_mean (verl/utils/torch_functional.py:69-71)."""
+    return (values * mask).sum(dim=dim) / (mask.sum(dim=dim) + eps)
 
 
-compute_gae_advantage_return = compute_rloo_outcome_advantage = compute_remax_outcome_advantage = _outside_scope
-compute_reinforce_plus_plus_outcome_advantage = compute_value_loss = _outside_scope
+def masked_whiten(values: torch.Tensor, mask: torch.Tensor, eps: float = 1e-8, all_reduce=None) -> torch.Tensor:
+    """VF.masked_whiten (torch_functional.py:74-97): (v - mean) * rsqrt(var_unbiased + eps) over the masked entries.
+    all_reduce(t) -> t summed over the ranks (in place or not): the statistics then cover every rank's rows."""
+    red = (lambda t: t) if all_reduce is None else all_reduce
+    n = red(mask.sum().to(torch.float32).reshape(1).clone())[0]
+    mean = red((values * mask).sum().reshape(1).clone())[0] / (n + 1e-8)
+    var = red((((values - mean) ** 2) * mask).sum().reshape(1).clone())[0] / (n + 1e-8)
+    if n > 1:
+        var = var * (n / (n - 1))
+    else:
+        print("The sum of the mask is less than one, which can cause a division by zero.")
+    return (values - mean) * torch.rsqrt(var + eps)
+
+
+@torch.no_grad()
+def compute_gae_advantage_return(token_level_rewards, values, response_mask, gamma, lam, all_reduce=None):
+    """A_t = delta_t + gamma*lam*A_{t+1}, delta_t = r_t + gamma*V_{t+1} - V_t (V past the end = 0); returns = A + V; A whitened."""
+    R = token_level_rewards.shape[-1]
+    adv = torch.zeros_like(token_level_rewards)
+    carry = torch.zeros_like(token_level_rewards[:, 0])
+    for t in range(R - 1, -1, -1):
+        nxt = values[:, t + 1] if t + 1 < R else 0.0
+        carry = token_level_rewards[:, t] + gamma * nxt - values[:, t] + gamma * lam * carry
+        adv[:, t] = carry
+    returns = adv + values
+    return masked_whiten(adv, response_mask, all_reduce=all_reduce), returns
+
+
+@torch.no_grad()
+def compute_rloo_outcome_advantage(token_level_rewards, response_mask, index):
+    """Leave-one-out baseline inside each uid group: A_i = s_i - (sum_g - s_i) / (n_g - 1)."""
+    scores = token_level_rewards.sum(-1)
+    _, dense = np.unique(np.asarray(index), return_inverse=True)
+    g = torch.from_numpy(dense.astype(np.int64))
+    n_groups = int(dense.max()) + 1
+    cnt = torch.zeros(n_groups, dtype=scores.dtype).index_add_(0, g, torch.ones_like(scores))
+    if bool((cnt < 2).any()):
+        raise AssertionError("RLOO needs rollout.n > 1.")
+    tot = torch.zeros(n_groups, dtype=scores.dtype).index_add_(0, g, scores)
+    out = scores - (tot[g] - scores) / (cnt[g] - 1)
+    ret = out.unsqueeze(-1) * response_mask
+    return ret, ret
+
+
+@torch.no_grad()
+def compute_reinforce_plus_plus_outcome_advantage(token_level_rewards, response_mask, gamma, all_reduce=None):
+    """Discounted return-to-go, restarted behind the EOS, whitened over the batch."""
+    returns = torch.zeros_like(token_level_rewards)
+    run = torch.zeros_like(token_level_rewards[:, 0])
+    for t in range(token_level_rewards.shape[1] - 1, -1, -1):
+        run = token_level_rewards[:, t] + gamma * run
+        returns[:, t] = run
+        run = run * response_mask[:, t]
+    return masked_whiten(returns, response_mask, all_reduce=all_reduce), returns
+
+
+@torch.no_grad()
+def compute_remax_outcome_advantage(token_level_rewards, reward_baselines, response_mask):
+    """Outcome score minus the score of the greedy rollout of the same prompt."""
+    ret = (token_level_rewards.sum(-1) - reward_baselines).unsqueeze(-1) * response_mask
+    return ret, ret
+
+
+def compute_value_loss(vpreds, returns, values, action_mask, cliprange_value: float):
+    """0.5 * masked_mean(max((v - R)^2, (clip(v, V_old +- c) - R)^2)) and the fraction of clipped entries."""
+    clipped = torch.clamp(vpreds, values - cliprange_value, values + cliprange_value)
+    l1, l2 = (vpreds - returns) ** 2, (clipped - returns) ** 2
+    return 0.5 * masked_mean(torch.max(l1, l2), action_mask), masked_mean((l1 < l2).float(), action_mask)
+
+
+def compute_kl(log_probs: torch.Tensor, ref_log_probs: torch.Tensor, kl_penalty: str) -> torch.Tensor:
+    """Per-token KL estimators on host tensors (core_algos.py:394-436) — the reward-side penalty branch and inspection; the
+    training loss evaluates the same formulas inside st_grpo_loss."""
+    lp, ref = log_probs.float(), ref_log_probs.float()
+    if kl_penalty == "kl":
+        return lp - ref
+    if kl_penalty == "abs":
+        return (lp - ref).abs()
+    if kl_penalty == "mse":
+        return 0.5 * (lp - ref).square()
+    if kl_penalty == "low_var_kl":
+        d = ref - lp
+        return torch.clamp(d.exp() - d - 1, min=-10, max=10)
+    if kl_penalty == "chi2":
+        return torch.clamp(((ref - lp).exp() - 1) ** 2, min=0, max=20)
+    if kl_penalty == "full":
+        return torch.nn.functional.kl_div(ref, lp, log_target=True, reduction="none").sum(-1)
+    raise NotImplementedError(f"Unknown KL penalty: {kl_penalty}.")

@@ -16,17 +16,20 @@ def _stats(prefix: str, t: torch.Tensor) -> Dict[str, float]:
     return {f"{prefix}/mean": t.mean().item(), f"{prefix}/max": t.max().item(), f"{prefix}/min": t.min().item()}
 
 
-def compute_data_metrics(batch: DataProto, use_critic: bool = False) -> Dict[str, Any]:
+def compute_data_metrics(batch: DataProto, use_critic: bool = False, gather=None) -> Dict[str, Any]:
+    """metrics.py:27-94.  gather(list) -> the list concatenated over the data-parallel ranks: the statistics then cover the
+    global batch, as the reference's driver computes them (per-sample / per-valid-token scalars only are exchanged)."""
     b = batch.batch
     R = b["responses"].size(-1)
     mask = b["attention_mask"]
     prompt_mask, resp_mask = mask[:, :-R].bool(), mask[:, -R:].bool()
-    plen, rlen = prompt_mask.sum(-1).float(), resp_mask.sum(-1).float()
+    g = (lambda t: t) if gather is None else (lambda t: torch.tensor(gather(t.tolist()), dtype=t.dtype))
+    plen, rlen = g(prompt_mask.sum(-1).float()), g(resp_mask.sum(-1).float())
     out: Dict[str, Any] = {}
-    out.update(_stats("critic/score", b["token_level_scores"].sum(-1)))
-    out.update(_stats("critic/rewards", b["token_level_rewards"].sum(-1)))
-    out.update(_stats("critic/advantages", torch.masked_select(b["advantages"], resp_mask)))
-    out.update(_stats("critic/returns", torch.masked_select(b["returns"], resp_mask)))
+    out.update(_stats("critic/score", g(b["token_level_scores"].sum(-1))))
+    out.update(_stats("critic/rewards", g(b["token_level_rewards"].sum(-1))))
+    out.update(_stats("critic/advantages", g(torch.masked_select(b["advantages"], resp_mask))))
+    out.update(_stats("critic/returns", g(torch.masked_select(b["returns"], resp_mask))))
     out.update(_stats("response_length", rlen))
     out["response_length/clip_ratio"] = (rlen == R).float().mean().item()
     out.update(_stats("prompt_length", plen))
@@ -34,8 +37,8 @@ def compute_data_metrics(batch: DataProto, use_critic: bool = False) -> Dict[str
     return out
 
 
-def compute_timing_metrics(batch: DataProto, timing_raw: Dict[str, float]) -> Dict[str, Any]:
-    n_resp = int(batch.batch["response_mask"].sum().item())
+def compute_timing_metrics(batch: DataProto, timing_raw: Dict[str, float], n_response_tokens=None) -> Dict[str, Any]:
+    n_resp = int(batch.batch["response_mask"].sum().item()) if n_response_tokens is None else int(n_response_tokens)
     n_all = sum(batch.meta_info["global_token_num"])
     per = {**dict.fromkeys(["gen", "reward"], n_resp), **dict.fromkeys(["ref", "old", "values", "adv", "update_critic", "update_actor"], n_all)}
     out = {f"timing_s/{k}": v for k, v in timing_raw.items()}

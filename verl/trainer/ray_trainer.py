@@ -1,27 +1,35 @@
 """GRPO trainer: the step loop of the reference's RayPPOTrainer.fit (verl/trainer/ray_trainer.py:543-721) without Ray.
 
 One process per GPU (torchrun); every rank runs this loop on its own share of the rollout batch (SPMD).  Phases, timers
-and metric names follow the reference: gen -> reward -> (balance) -> old -> ref -> adv -> update_actor.  Group-relative
+and metric names follow the reference: gen -> reward -> balance -> old -> ref -> adv -> update_actor.  Group-relative
 advantages need all G rollouts of a prompt, which stay on the rank that generated them, so no activation or score ever
-crosses the fabric; the only collective is the gradient all-reduce inside update_actor."""
+crosses the fabric; the only data-path collective is the gradient all-reduce inside update_actor.  What the reference's single
+driver sees of the whole batch — reward / actor / data metrics, the balance statistics, validation scores — is rebuilt from
+small per-rank python objects gathered over the process group (`SPMDWorkerGroup.gather_objects`), so rank 0 logs the same
+numbers a one-controller run would."""
 from __future__ import annotations
 
 import os
+import shutil
 import time
 import uuid
+from collections import defaultdict
 from contextlib import contextmanager
+from copy import deepcopy
 from enum import Enum
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional
 
 import numpy as np
 import torch
 import torch.distributed as dist
-from torch.utils.data import DataLoader, RandomSampler, SequentialSampler
 
 from ..protocol import DataProto
+from ..utils.dataloader import ResumableDataLoader
 from ..utils.seqlen_balancing import get_seqlen_balanced_partitions, log_seqlen_unbalance
 from . import core_algos
 from .metrics import compute_data_metrics, compute_throughout_metrics, compute_timing_metrics, reduce_metrics
+
+CHECKPOINT_TRACKER = "latest_global_step.txt"
 
 
 class AdvantageEstimator(str, Enum):
@@ -32,51 +40,65 @@ class AdvantageEstimator(str, Enum):
     RLOO = "rloo"
 
 
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 @contextmanager
 def _timer(name: str, timing_raw: Dict[str, float]):
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     yield
-    torch.cuda.synchronize()
+    _sync()
     timing_raw[name] = time.perf_counter() - t0
 
 
-def compute_advantage(data: DataProto, adv_estimator: str):
-    if adv_estimator != AdvantageEstimator.GRPO.value:
-        raise NotImplementedError("only algorithm.adv_estimator=grpo is on the SpatialThinker path")
-    adv, ret = core_algos.compute_grpo_outcome_advantage(data.batch["token_level_rewards"], data.batch["response_mask"],
-                                                         data.non_tensor_batch["uid"])
+def _dist_sum(t: torch.Tensor) -> torch.Tensor:
+    """Sum a small host tensor over the ranks (identity on one rank): the batch-wide statistics of masked_whiten."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            d = t.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(d)
+            return d.to(t.device)
+        dist.all_reduce(t)
+    return t
+
+
+def compute_advantage(data: DataProto, adv_estimator: str, gamma: float = 1.0, lam: float = 1.0):
+    """ray_trainer.py:148-175.  GRPO runs the HIP kernel; the other estimators are host math (core_algos)."""
+    rew, mask, index = data.batch["token_level_rewards"], data.batch["response_mask"], data.non_tensor_batch["uid"]
+    est = AdvantageEstimator(adv_estimator).value
+    if est == "grpo":
+        adv, ret = core_algos.compute_grpo_outcome_advantage(rew, mask, index)
+    elif est == "gae":
+        adv, ret = core_algos.compute_gae_advantage_return(rew, data.batch["values"], mask, gamma, lam, all_reduce=_dist_sum)
+    elif est == "reinforce_plus_plus":
+        adv, ret = core_algos.compute_reinforce_plus_plus_outcome_advantage(rew, mask, gamma, all_reduce=_dist_sum)
+    elif est == "remax":
+        adv, ret = core_algos.compute_remax_outcome_advantage(rew, data.batch["reward_baselines"], mask)
+    else:
+        adv, ret = core_algos.compute_rloo_outcome_advantage(rew, mask, index)
     data.batch["advantages"], data.batch["returns"] = adv, ret
     return data
 
 
-def _kl_tokens(old: torch.Tensor, ref: torch.Tensor, kind: str) -> torch.Tensor:
-    """compute_kl (core_algos.py:394-436) on host tensors — used only by the reward-side KL penalty branch."""
-    if kind == "kl":
-        return old - ref
-    if kind == "abs":
-        return (old - ref).abs()
-    if kind == "mse":
-        return 0.5 * (old - ref).square()
-    if kind == "low_var_kl":
-        d = ref - old
-        return torch.clamp(d.exp() - d - 1, min=-10, max=10)
-    if kind == "chi2":
-        return torch.clamp(((ref - old).exp() - 1) ** 2, min=0, max=20)
-    raise NotImplementedError(kind)
-
-
-def apply_kl_penalty(data: DataProto, kl_ctrl, kl_penalty="kl"):
-    """token_level_rewards = scores - kl_coef * kl(old, ref)  (ray_trainer.py:125-145; only when use_kl_loss is off)."""
+def apply_kl_penalty(data: DataProto, kl_ctrl, kl_penalty="kl", gather=None):
+    """token_level_rewards = scores - kl_coef * kl(old, ref)  (ray_trainer.py:125-145; only when use_kl_loss is off).
+    gather: callable(list) -> the list concatenated over the ranks, so the controller sees the GLOBAL batch's mean KL and size."""
     scores, mask = data.batch["token_level_scores"], data.batch["response_mask"]
     if "ref_log_probs" in data.batch.keys():
-        kld = _kl_tokens(data.batch["old_log_probs"].float(), data.batch["ref_log_probs"].float(), kl_penalty) * mask
+        kld = core_algos.compute_kl(data.batch["old_log_probs"], data.batch["ref_log_probs"], kl_penalty) * mask
     else:
         kld = torch.zeros_like(mask, dtype=torch.float32)
     data.batch["token_level_rewards"] = scores - kl_ctrl.kl_coef * kld
-    cur = ((kld * mask).sum(-1) / (mask.sum(-1) + 1e-8)).mean().item()
-    kl_ctrl.update(current_kl=cur, n_steps=len(data))
-    return data, {"critic/kl": cur, "critic/kl_coef": kl_ctrl.kl_coef}
+    per_seq = core_algos.masked_mean(kld, mask, dim=-1)
+    if gather is not None:
+        per_seq = torch.tensor(gather(per_seq.tolist()), dtype=per_seq.dtype)
+    cur = torch.mean(per_seq, dim=0).item()
+    metrics = {"critic/kl": cur, "critic/kl_coef": kl_ctrl.kl_coef}
+    kl_ctrl.update(current_kl=cur, n_steps=int(per_seq.numel()))
+    return data, metrics
 
 
 class ConsoleTracker:
@@ -90,6 +112,25 @@ class ConsoleTracker:
         if self.rank == 0:
             print(f"step {step}: " + " - ".join(f"{k}:{v:.4g}" if isinstance(v, (int, float)) else f"{k}:{v}" for k, v in sorted(data.items())), flush=True)
 
+    def log_generation(self, samples: List[tuple], step: int):
+        """utils/logger/gen_logger.py's console flavour: (input, output, label, score) rows."""
+        if self.rank == 0:
+            for inp, out, lab, score in samples:
+                print(f"[val generation @ step {step}] score={score:.4g}\n  prompt: {inp[:200]!r}\n  output: {out[:400]!r}\n  label : {str(lab)[:200]!r}", flush=True)
+
+
+def remove_obsolete_ckpt(path: str, global_step: int, save_limit: int = -1, directory_format: str = "global_step_{}"):
+    """Keep the newest save_limit - 1 step directories older than `global_step` (utils/checkpoint/checkpoint_manager.py:138-160)."""
+    if save_limit <= 0 or not os.path.exists(path):
+        return
+    pat = directory_format.format("")
+    steps = []
+    for name in os.listdir(path):
+        if name.startswith(pat) and name[len(pat):].isdigit() and int(name[len(pat):]) < global_step:
+            steps.append(int(name[len(pat):]))
+    for s in sorted(steps, reverse=True)[save_limit - 1:]:
+        shutil.rmtree(os.path.join(path, directory_format.format(s)), ignore_errors=True)
+
 
 class RayPPOTrainer:
     """Name kept for drop-in use by verl.trainer.main; there is no Ray underneath."""
@@ -101,8 +142,10 @@ class RayPPOTrainer:
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
         a = config.algorithm
-        if a.adv_estimator != "grpo":
-            raise NotImplementedError("only algorithm.adv_estimator=grpo is built")
+        if a.adv_estimator == "gae":
+            raise NotImplementedError("adv_estimator=gae needs the critic worker, which is outside the GRPO path (SURVEY 8f-4); "
+                                      "grpo, rloo, remax and reinforce_plus_plus are built")
+        AdvantageEstimator(a.adv_estimator)
         self.use_reference_policy = not a.disable_kl
         self.kl_ctrl = core_algos.get_kl_controller(a) if self.use_reference_policy else core_algos.FixedKLController(0.0)
         d, act = config.data, config.worker.actor
@@ -111,24 +154,29 @@ class RayPPOTrainer:
             raise ValueError("Rollout batch size must be divisible by global batch size.")
         if (d.rollout_batch_size * config.worker.rollout.n) % act.micro_batch_size_per_device_for_experience != 0:
             raise ValueError("Rollout batch size * rollout.n must be divisible by actor micro batch size for experience.")
-        if config.worker.rollout.n == 1:
+        if a.adv_estimator in ("grpo", "rloo") and config.worker.rollout.n == 1:
             raise ValueError("GRPO and RLOO algorithm need `config.worker.rollout.n > 1`.")
         if d.rollout_batch_size % self.world != 0:
             raise ValueError("rollout_batch_size must be divisible by the number of GPUs")
         self.local_prompts = d.rollout_batch_size // self.world
-        gen = torch.Generator().manual_seed(d.seed)
-        sampler = RandomSampler(train_dataset, generator=gen) if d.shuffle else SequentialSampler(train_dataset)
         from ..utils.dataset import collate_fn
-        self.train_dataloader = DataLoader(train_dataset, batch_size=d.rollout_batch_size, sampler=sampler, num_workers=0,
-                                           collate_fn=collate_fn, drop_last=True)
+        workers = int(os.environ.get("ST_DATALOADER_WORKERS", "0"))
+        self.train_dataloader = ResumableDataLoader(train_dataset, batch_size=d.rollout_batch_size, shuffle=d.shuffle, seed=d.seed,
+                                                    collate_fn=collate_fn, drop_last=True, num_workers=workers, rank=self.rank,
+                                                    world_size=self.world)
         self.val_dataloader = None
+        self._val_rows = 0
         if val_dataset is not None:
             vb = len(val_dataset) if d.val_batch_size == -1 else d.val_batch_size
-            self.val_dataloader = DataLoader(val_dataset, batch_size=vb, shuffle=False, collate_fn=collate_fn, drop_last=False)
+            vb = -(-vb // self.world) * self.world             # pad_dataproto_to_divisor(world) of the reference (:384)
+            self.val_dataloader = ResumableDataLoader(val_dataset, batch_size=vb, shuffle=False, collate_fn=collate_fn, drop_last=False,
+                                                      num_workers=workers, rank=self.rank, world_size=self.world)
+            self._val_rows = len(val_dataset)
         t = config.trainer
         self.training_steps = t.max_steps if t.max_steps is not None else len(self.train_dataloader) * t.total_episodes
         act.optim.training_steps = self.training_steps
         self.global_step = 0
+        self.logger = ConsoleTracker(t.logger)
 
     def set_worker_groups(self, actor_rollout_wg, ref_policy_wg):
         self.actor_rollout_wg, self.ref_policy_wg = actor_rollout_wg, ref_policy_wg
@@ -138,41 +186,116 @@ class RayPPOTrainer:
             self.ref_policy_wg.init_model()
         self.actor_rollout_wg.init_model()
 
-    # ------------------------------------------------------------------------------------------------
-    def _shard(self, batch_dict: Dict[str, Any]) -> Dict[str, Any]:
-        """This rank's contiguous share of the global rollout batch (Dispatch.DP_COMPUTE_PROTO's chunk(world)[rank])."""
-        lo, hi = self.rank * self.local_prompts, (self.rank + 1) * self.local_prompts
-        return {k: v[lo:hi] for k, v in batch_dict.items()}
+    # ------------------------------------------------------------------------------------------------ cross-rank helpers
+    def _gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] (DP_COMPUTE_PROTO's collect side, decorator.py:118-123, for small objects)."""
+        wg = self.actor_rollout_wg
+        if wg is not None and hasattr(wg, "gather_objects"):
+            return wg.gather_objects(obj)
+        return [obj]
 
+    def _gather_list(self, xs: list) -> list:
+        return [x for part in self._gather(list(xs)) for x in part]
+
+    def _gather_metric_lists(self, m: Dict[str, Any]) -> Dict[str, list]:
+        out: Dict[str, list] = defaultdict(list)
+        local = {k: ([v] if np.isscalar(v) else [float(x) for x in np.asarray(v).reshape(-1)]) for k, v in m.items()}
+        for part in self._gather(local):
+            for k, v in part.items():
+                out[k].extend(v)
+        return out
+
+    # ------------------------------------------------------------------------------------------------
     def _balance_batch(self, batch: DataProto, metrics: Dict[str, Any], logging_prefix: str = "global_seqlen") -> None:
-        """ray_trainer.py:526-541.  The partitioner is the reference's; rows stay on the rank that generated them (they never
-        leave HBM-side locality), so with one rank per GPU the reorder is the identity and only the statistics are logged."""
+        """ray_trainer.py:526-541 in two parts.
+        (1) Statistics: the reference partitions the GLOBAL list of sequence lengths into world_size sets with Karmarkar-Karp and
+            logs min/max/minmax_diff (contiguous chunks) vs balanced_min/max (its partition): same list, same partitioner, same keys.
+        (2) Reorder: the reference then permutes rows so DP rank r receives partition r.  Here the G rollouts of a prompt stay on
+            the GPU that generated them (one prompt copy per group in every pass, prompt K/V re-used for the old log-probs), so
+            the partitioner is applied where this design has a choice: each rank's rollout GROUPS are spread over its optimizer
+            steps (mini-batches of global_batch_size_per_device rows) with equal group counts and balanced token sums, and the
+            batch is reordered accordingly — ranks then reach each gradient all-reduce after similar amounts of work."""
         lens = batch.batch["attention_mask"].sum(-1).tolist()
-        parts = get_seqlen_balanced_partitions(lens, k_partitions=1, equal_size=True)
-        metrics.update(log_seqlen_unbalance(lens, parts, logging_prefix))
+        glob = self._gather_list(lens)
+        world = max(1, len(glob) // max(1, len(lens)))
+        parts = get_seqlen_balanced_partitions(glob, k_partitions=world, equal_size=True)
+        metrics.update(log_seqlen_unbalance(glob, parts, logging_prefix))
+        n = self.config.worker.rollout.n
+        mini = getattr(self.config.worker.actor, "global_batch_size_per_device", 0) or len(batch)
+        n_mini = len(batch) // mini if (mini and len(batch) % mini == 0) else 1
+        n_groups = len(batch) // n if n else 0
+        uid = batch.non_tensor_batch.get("uid")
+        grouped = uid is not None and n > 0 and len(batch) % n == 0 and all(uid[i] == uid[i - i % n] for i in range(len(batch)))
+        if n_mini > 1 and grouped and mini % n == 0 and n_groups % n_mini == 0:
+            gl = [sum(lens[g * n:(g + 1) * n]) for g in range(n_groups)]
+            gparts = get_seqlen_balanced_partitions(gl, k_partitions=n_mini, equal_size=True)
+            idx = torch.tensor([g * n + j for p in gparts for g in p for j in range(n)])
+            batch.reorder(idx)
+            sums = [sum(gl[g] for g in p) for p in gparts]
+            metrics.update({"minibatch_seqlen/balanced_min": min(sums), "minibatch_seqlen/balanced_max": max(sums)})
 
     def _validate(self) -> Dict[str, Any]:
+        """ray_trainer.py:358-411, data-parallel: every rank generates and scores ITS rows of each validation batch (in chunks
+        that bound the generator's KV allocation), the per-sample scores and reward components are gathered, rank-padding rows are
+        dropped, and the reference's metric names are returned: val/reward_score + val/{k}_reward."""
         if self.val_dataloader is None:
             return {}
-        scores = []
+        chunk = int(os.environ.get("ST_VAL_CHUNK", "256"))
+        over = dict(self.config.worker.rollout.val_override_config)
+        n = int(over.get("n", 1))
+        scores_all: List[float] = []
+        comp_all: Dict[str, list] = defaultdict(list)
+        samples: List[tuple] = []
+        seen = 0
         for batch_dict in self.val_dataloader:
             test = DataProto.from_single_dict(batch_dict)
-            keys = ["raw_prompt_ids", "multi_modal_data", "multi_modal_inputs"] if "multi_modal_inputs" in test.non_tensor_batch else ["raw_prompt_ids"]
-            gen = test.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=[k for k in keys if k in test.non_tensor_batch])
-            gen.meta_info = dict(self.config.worker.rollout.val_override_config)
-            out = self.actor_rollout_wg.generate_sequences(gen)
-            n = int(gen.meta_info.get("n", 1))
-            test = test.repeat(n, interleave=True).union(out) if n > 1 else test.union(out)
-            reward, _ = self.val_reward_fn(test)
-            scores.append(reward.sum(-1))
-        return {"val/test_score": torch.cat(scores).mean().item()}
+            local_scores, local_comp = [], defaultdict(list)
+            for lo in range(0, len(test), chunk):
+                part = test[lo:lo + chunk]
+                nt_keys = [k for k in ("raw_prompt_ids", "multi_modal_data", "multi_modal_inputs") if k in part.non_tensor_batch]
+                gen = part.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=nt_keys)
+                gen.meta_info = dict(over)
+                in_texts = [self.tokenizer.decode(ids, skip_special_tokens=True) for ids in gen.batch["input_ids"]]
+                out = self.actor_rollout_wg.generate_sequences(gen)
+                part = part.repeat(n, interleave=True).union(out) if n > 1 else part.union(out)
+                reward, rmet = self.val_reward_fn(part)
+                sc = reward.sum(-1).tolist()
+                local_scores.extend(sc)
+                for k, v in rmet.items():
+                    local_comp[k].extend(v)
+                if self.config.trainer.val_generations_to_log > 0:
+                    outs = [self.tokenizer.decode(ids, skip_special_tokens=True) for ids in out.batch["responses"]]
+                    samples.extend(zip(np.repeat(np.array(in_texts, dtype=object), n).tolist(), outs,
+                                       part.non_tensor_batch["ground_truth"].tolist(), sc))
+            # global row order = rank-major shards of the batch; the tail of the LAST batch may be cyclic rank padding
+            per_rank = self._gather((local_scores, dict(local_comp)))
+            n_glob = sum(len(p[0]) for p in per_rank)
+            n_keep = min(n_glob, max(0, self._val_rows * n - seen))
+            scores_all.extend([s for p in per_rank for s in p[0]][:n_keep])
+            for k in per_rank[0][1]:
+                comp_all[k].extend([v for p in per_rank for v in p[1][k]][:n_keep])
+            seen += n_keep
+        if self.config.trainer.val_generations_to_log > 0:
+            samples = [s for part in self._gather(samples) for s in part]
+            samples.sort(key=lambda x: x[0])
+            np.random.RandomState(42).shuffle(samples)
+            self.logger.log_generation(samples[: self.config.trainer.val_generations_to_log], self.global_step)
+        out = {"val/reward_score": float(np.mean(scores_all)) if scores_all else 0.0}
+        out.update({f"val/{k}_reward": v for k, v in reduce_metrics(comp_all).items()})
+        return out
 
+    # ------------------------------------------------------------------------------------------------ checkpoints
     def _save_checkpoint(self):
-        path = os.path.join(self.config.trainer.save_checkpoint_path, f"global_step_{self.global_step}")
+        """global_step_N/{actor/, dataloader.pt} + latest_global_step.txt, older steps pruned to save_limit (ray_trainer.py:483-506)."""
+        root = self.config.trainer.save_checkpoint_path
+        if self.rank == 0:
+            remove_obsolete_ckpt(root, self.global_step, self.config.trainer.save_limit)
+        path = os.path.join(root, f"global_step_{self.global_step}")
         os.makedirs(os.path.join(path, "actor"), exist_ok=True)
         self.actor_rollout_wg.save_checkpoint(os.path.join(path, "actor"))
         if self.rank == 0:
-            with open(os.path.join(self.config.trainer.save_checkpoint_path, "latest_global_step.txt"), "w") as f:
+            torch.save({"dataloader": self.train_dataloader.state_dict(), "kl_coef": self.kl_ctrl.kl_coef}, os.path.join(path, "dataloader.pt"))
+            with open(os.path.join(root, CHECKPOINT_TRACKER), "w") as f:
                 f.write(str(self.global_step))
 
     def _load_checkpoint(self):
@@ -181,13 +304,20 @@ class RayPPOTrainer:
             return
         if "global_step_" not in p.strip(os.path.sep).split(os.path.sep)[-1]:
             raise ValueError("`load_checkpoint_path` should end with `global_step_*`.")
+        print(f"Load from checkpoint: {p}.")
         self.global_step = int(p.strip(os.path.sep).split("global_step_")[-1])
         self.actor_rollout_wg.load_checkpoint(os.path.join(p, "actor"))
+        dl = os.path.join(p, "dataloader.pt")
+        if os.path.exists(dl):
+            st = torch.load(dl, weights_only=False)
+            self.train_dataloader.load_state_dict(st["dataloader"])
+            self.kl_ctrl.kl_coef = st.get("kl_coef", self.kl_ctrl.kl_coef)
+        else:
+            print(f"No dataloader state found at {dl}, will start from scratch.")
 
     # ------------------------------------------------------------------------------------------------
     def fit(self):
         cfg = self.config
-        self.logger = ConsoleTracker(cfg.trainer.logger, cfg.to_dict())
         self._load_checkpoint()
         val_metrics: Optional[Dict[str, Any]] = None
         if self.val_reward_fn is not None and cfg.trainer.val_before_train and self.val_dataloader is not None:
@@ -196,13 +326,16 @@ class RayPPOTrainer:
             if cfg.trainer.val_only:
                 return
         n = cfg.worker.rollout.n
+        est = cfg.algorithm.adv_estimator
+        done = False
         for _ in range(cfg.trainer.total_episodes):
             for batch_dict in self.train_dataloader:
                 self.global_step += 1
                 if self.global_step > self.training_steps:
+                    done = True
                     break
                 metrics, timing_raw = {}, {}
-                batch = DataProto.from_single_dict(self._shard(batch_dict))
+                batch = DataProto.from_single_dict(batch_dict)                 # this rank's rows of the global rollout batch
                 nt_keys = [k for k in ("raw_prompt_ids", "multi_modal_data", "multi_modal_inputs") if k in batch.non_tensor_batch]
                 gen_batch = batch.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=nt_keys)
                 if "synthetic_response_lengths" in batch.meta_info:
@@ -210,13 +343,22 @@ class RayPPOTrainer:
                 with _timer("step", timing_raw):
                     with _timer("gen", timing_raw):
                         gen_out = self.actor_rollout_wg.generate_sequences(gen_batch)
+                    if est == "remax":                                        # greedy baseline rollout (ray_trainer.py:590-604)
+                        with _timer("gen_max", timing_raw):
+                            base_in = deepcopy(gen_batch)
+                            base_in.meta_info.update({"temperature": 0, "n": 1})
+                            base_out = self.actor_rollout_wg.generate_sequences(base_in)
+                            batch = batch.union(base_out)
+                            base_reward, _ = self.reward_fn(batch)
+                            batch.pop(batch_keys=list(base_out.batch.keys()))
+                            batch.batch["reward_baselines"] = base_reward.sum(-1)
                     batch.non_tensor_batch["uid"] = np.array([str(uuid.uuid4()) for _ in range(len(batch))], dtype=object)
                     batch = batch.repeat(repeat_times=n, interleave=True)
                     batch = batch.union(gen_out)
                     with _timer("reward", timing_raw):
                         reward_tensor, reward_metrics = self.reward_fn(batch)
                         batch.batch["token_level_scores"] = reward_tensor
-                        metrics.update({f"reward/{k}": v for k, v in reduce_metrics(reward_metrics).items()})
+                        metrics.update({f"reward/{k}": v for k, v in reduce_metrics(self._gather_metric_lists(reward_metrics)).items()})
                     self._balance_batch(batch, metrics)
                     batch.meta_info["global_token_num"] = torch.sum(batch.batch["attention_mask"], dim=-1).tolist()
                     with _timer("old", timing_raw):
@@ -226,15 +368,15 @@ class RayPPOTrainer:
                             batch = batch.union(self.ref_policy_wg.compute_ref_log_probs(batch))
                     with _timer("adv", timing_raw):
                         if not cfg.algorithm.use_kl_loss and self.use_reference_policy:
-                            batch, kl_metrics = apply_kl_penalty(batch, self.kl_ctrl, cfg.algorithm.kl_penalty)
+                            batch, kl_metrics = apply_kl_penalty(batch, self.kl_ctrl, cfg.algorithm.kl_penalty, gather=self._gather_list)
                             metrics.update(kl_metrics)
                         else:
                             batch.batch["token_level_rewards"] = batch.batch["token_level_scores"]
-                        batch = compute_advantage(batch, cfg.algorithm.adv_estimator)
+                        batch = compute_advantage(batch, est, cfg.algorithm.gamma, cfg.algorithm.lam)
                     if cfg.trainer.critic_warmup <= self.global_step:
                         with _timer("update_actor", timing_raw):
                             actor_out = self.actor_rollout_wg.update_actor(batch)
-                        metrics.update(reduce_metrics(actor_out.non_tensor_batch))
+                        metrics.update(reduce_metrics(self._gather_metric_lists(actor_out.non_tensor_batch)))
                     if self.val_reward_fn is not None and cfg.trainer.val_freq > 0 and self.global_step % cfg.trainer.val_freq == 0:
                         with _timer("validation", timing_raw):
                             val_metrics = self._validate()
@@ -242,13 +384,25 @@ class RayPPOTrainer:
                     if cfg.trainer.save_freq > 0 and self.global_step % cfg.trainer.save_freq == 0:
                         with _timer("save_checkpoint", timing_raw):
                             self._save_checkpoint()
-                metrics.update(compute_data_metrics(batch))
-                metrics.update(compute_timing_metrics(batch, timing_raw))
-                metrics.update(compute_throughout_metrics(batch, timing_raw, n_gpus=1))      # per-rank tokens / per-rank time = per-GPU rate
-                metrics["perf/samples_per_s_per_gpu"] = len(batch) / timing_raw["step"]
+                # the driver's view (ray_trainer.py:697-703): data metrics over every rank's rows, the slowest rank's phase times,
+                # the token count over all GPUs
+                metrics.update(compute_data_metrics(batch, gather=self._gather_list))
+                timing_all = self._gather(timing_raw)
+                timing_max = {k: max(t[k] for t in timing_all if k in t) for k in timing_raw}
+                batch.meta_info["global_token_num"] = self._gather_list(batch.meta_info["global_token_num"])
+                n_resp = sum(self._gather_list([int(batch.batch["response_mask"].sum().item())]))
+                metrics.update(compute_timing_metrics(batch, timing_max, n_response_tokens=n_resp))
+                metrics.update(compute_throughout_metrics(batch, timing_max, n_gpus=self.world))
+                metrics["perf/samples_per_s"] = len(batch) * self.world / timing_max["step"]
                 self.logger.log(metrics, self.global_step)
-            if self.global_step > self.training_steps:
+            if done:
                 break
+        if self.val_reward_fn is not None and self.val_dataloader is not None:
+            if val_metrics is None or cfg.trainer.val_freq <= 0 or self.global_step % cfg.trainer.val_freq != 0:
+                val_metrics = self._validate()
+                self.logger.log(val_metrics, self.global_step)
+            if self.rank == 0:
+                print("Final validation metrics: " + ", ".join(f"{k}: {v}" for k, v in val_metrics.items()), flush=True)
         # the reference always writes a final checkpoint (ray_trainer.py:718-719); ST_SKIP_FINAL_SAVE=1 is a test/bench knob for
         # multi-GB synthetic models whose final state nobody will read
         if (cfg.trainer.save_freq <= 0 or self.global_step % cfg.trainer.save_freq != 0) and os.environ.get("ST_SKIP_FINAL_SAVE") != "1":

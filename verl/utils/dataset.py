@@ -17,6 +17,8 @@ from torch.utils.data import Dataset
 
 from spatialthinker_amd import indexing as ix
 
+from .torch_functional import postprocess_data
+
 
 def collate_fn(features: List[Dict[str, Any]]) -> Dict[str, Any]:
     tensors, others = defaultdict(list), defaultdict(list)
@@ -30,26 +32,6 @@ def collate_fn(features: List[Dict[str, Any]]) -> Dict[str, Any]:
             arr[i] = x
         out[k] = arr
     return out
-
-
-def postprocess_data(input_ids, attention_mask, position_ids, max_length: int, pad_token_id: int, left_pad: bool = True,
-                     truncation: str = "error"):
-    """Left-pad with pad/0/0 or truncate (reference verl/utils/torch_functional.py:150-184)."""
-    n = input_ids.shape[-1]
-    if n < max_length:
-        def pad(t, value):
-            p = torch.full(t.shape[:-1] + (max_length - n,), value, dtype=t.dtype)
-            return torch.cat((p, t), -1) if left_pad else torch.cat((t, p), -1)
-        return pad(input_ids, pad_token_id), pad(attention_mask, 0), pad(position_ids, 0)
-    if n > max_length:
-        if truncation == "left":
-            sl = slice(n - max_length, None)
-        elif truncation == "right":
-            sl = slice(0, max_length)
-        else:
-            raise NotImplementedError(f"{n} is larger than {max_length}.")
-        return input_ids[..., sl], attention_mask[..., sl], position_ids[..., sl]
-    return input_ids, attention_mask, position_ids
 
 
 class SyntheticSTVQADataset(Dataset):

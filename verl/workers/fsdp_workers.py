@@ -26,6 +26,7 @@ from ..protocol import DataProto
 from ..single_controller.decorator import Dispatch, register
 from ..utils.flops_counter import FlopsCounter
 from ..utils.tokenizer import get_processor, get_tokenizer
+from .rollout import assemble_rollout_batch
 
 
 class FSDPWorker:
@@ -125,21 +126,7 @@ class FSDPWorker:
             pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls, pixel_values=px, image_grid_thw=gr,
             ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)), forced_lengths=prompts.meta_info.get("synthetic_response_lengths"),
             top_k=top_k, top_p=top_p, return_prompt_cache=True)
-        resp = resp.cpu()
-        # post-processing of vllm_rollout_spmd.py:144-188
-        if n > 1:
-            ids, mask, pos = (t.repeat_interleave(n, dim=0) for t in (ids, mask, pos))
-        eos_list = [eos] if isinstance(eos, int) else list(eos)
-        is_eos = torch.zeros_like(resp, dtype=torch.bool)
-        for e in eos_list:
-            is_eos |= resp.eq(e)
-        resp_mask = ((torch.cumsum(is_eos.long(), 1) - is_eos.long()) == 0).to(mask.dtype)
-        R = resp.shape[1]
-        delta = torch.arange(1, R + 1)
-        resp_pos = pos[..., -1:] + (delta.view(1, 1, -1) if pos.dim() == 3 else delta.view(1, -1))
-        batch = {"prompts": ids, "responses": resp, "input_ids": torch.cat([ids, resp], -1),
-                 "attention_mask": torch.cat([mask, resp_mask], -1), "response_mask": resp_mask,
-                 "position_ids": torch.cat([pos, resp_pos], -1)}
+        batch = assemble_rollout_batch(ids, mask, pos, resp.cpu(), n, eos)          # vllm_rollout_spmd.py:144-188
         non_tensor = {}
         if mm is not None:
             non_tensor["multi_modal_inputs"] = np.repeat(mm, n, axis=0) if n > 1 else mm
@@ -170,7 +157,9 @@ class FSDPWorker:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         est, promised = self.flops_counter.estimate_flops(data.meta_info["global_token_num"], dt)
-        metrics["perf/mfu_actor"] = est * self.config.actor.ppo_epochs / (promised * self.world_size)
+        # meta_info["global_token_num"] holds THIS rank's sequences (each rank drives its own shard), so the estimate is already
+        # per GPU: no division by the world size (the reference divides a global count, fsdp_workers.py:447-449)
+        metrics["perf/mfu_actor"] = est * self.config.actor.ppo_epochs / promised
         metrics["perf/max_memory_allocated_gb"] = torch.cuda.max_memory_allocated() / (1024 ** 3)
         metrics["perf/max_memory_reserved_gb"] = torch.cuda.max_memory_reserved() / (1024 ** 3)
         metrics["perf/cpu_memory_used_gb"] = psutil.virtual_memory().used / (1024 ** 3)

@@ -242,6 +242,13 @@ int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width
 int st_adamw_kahan_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, st_bf16* c, int64_t n,
                         double lr, double beta1, double beta2, double eps, double weight_decay, float step_size,
                         float denom_corr, const float* grad_scale, st_stream_t stream);
+/* torch.optim.AdamW(fused=True) semantics on bf16 p / exp_avg m / exp_avg_sq v, no compensation buffer: the optimizer the
+ * reference builds for worker.actor.optim.strategy=adamw (verl/workers/fsdp_workers.py:284-291).  grad fp32, rounded to bf16
+ * (the parameter dtype torch's fused kernel requires of a gradient) after scaling by grad_scale.  bias_correction1 = 1-b1^t,
+ * bias_correction2_sqrt = sqrt(1-b2^t), host-computed. */
+int st_adamw_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, float bias_correction1, float bias_correction2_sqrt,
+                  const float* grad_scale, st_stream_t stream);
 /* sum of squares of an fp32 buffer into out[0] (+= if accumulate) — global grad-norm for clipping
  * (verl/workers/actor/dp_actor.py:155-167). Deterministic two-stage reduction, scratch >= 1024 floats. */
 int st_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, int accumulate, st_stream_t stream);

@@ -45,6 +45,8 @@ class ActorHyper:
     weight_decay: float = 1e-2
     lr_warmup_steps: int = 0
     allreduce_bucket_mb: int = 512
+    optim_strategy: str = "adamw_bf16"      # adamw_bf16 = AnyPrecisionAdamW (bf16 states + Kahan); adamw = torch.optim.AdamW(fused) semantics
+    freeze_vision_tower: bool = False       # fsdp_workers.py:226-232: the ViT gets no gradient and no optimizer update
 
 
 class GradReducer:
@@ -220,8 +222,17 @@ class PolicyEngine:
             return norm
         self._coef.fill_(min(1.0, h.max_grad_norm / (norm + 1e-6)))   # clip_grad_norm_: coef = max_norm/(norm+1e-6), clamped to 1
         self.opt_steps += 1
-        ops.adamw_kahan_step_(st.flat, st.grad, st.m, st.v, st.c, t=self.opt_steps, lr=self.current_lr(), betas=h.betas, eps=h.eps,
-                              weight_decay=h.weight_decay, grad_scale=self._coef)
+        # frozen parameters have grad None in the reference, so its optimizers skip them entirely (no decay either): the ViT
+        # slice leads the flat buffer (model.param_layout), the update starts behind it
+        lo = st.offsets["embed"] if h.freeze_vision_tower else 0
+        if h.optim_strategy == "adamw_bf16":
+            ops.adamw_kahan_step_(st.flat[lo:], st.grad[lo:], st.m[lo:], st.v[lo:], st.c[lo:], t=self.opt_steps, lr=self.current_lr(),
+                                  betas=h.betas, eps=h.eps, weight_decay=h.weight_decay, grad_scale=self._coef)
+        elif h.optim_strategy == "adamw":
+            ops.adamw_step_(st.flat[lo:], st.grad[lo:], st.m[lo:], st.v[lo:], t=self.opt_steps, lr=self.current_lr(), betas=h.betas,
+                            eps=h.eps, weight_decay=h.weight_decay, grad_scale=self._coef)
+        else:
+            raise NotImplementedError(f"Optimizer {h.optim_strategy} not supported.")
         st.refresh_transposes()
         st.version = getattr(st, "version", 0) + 1          # invalidates prompt caches built from the previous weights
         self.zero_grad()
@@ -261,7 +272,8 @@ class PolicyEngine:
                     _, met = self.model.forward_backward(b, loss_in, temperature, clip_low=h.clip_ratio_low, clip_high=h.clip_ratio_high,
                                                          clip_dual=h.clip_ratio_dual, kl_kind=h.kl_penalty, kl_coef=h.kl_coef,
                                                          grad_accum=float(accum), loss_rows=micro,
-                                                         on_final=red.ready if red is not None else None)
+                                                         on_final=red.ready if red is not None else None,
+                                                         train_vision=not h.freeze_vision_tower)
                     pending.extend(met if met.dim() == 2 else [met])
                 norm = self.optimizer_step()
                 metrics["actor/grad_norm"].append(norm)

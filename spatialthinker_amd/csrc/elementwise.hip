@@ -156,6 +156,50 @@ __global__ __launch_bounds__(256) void adamw_kahan_kernel(uint16_t* __restrict__
     }
 }
 
+// torch.optim.AdamW(fused=True) on bf16 parameters with bf16 exp_avg / exp_avg_sq — what the reference builds for
+// worker.actor.optim.strategy=adamw (verl/workers/fsdp_workers.py:284-291).  One pass, no compensation buffer: every quantity is
+// widened to fp32 ("opmath"), the python-double hyper-parameters enter the arithmetic as doubles exactly where torch's
+// fused kernel mixes them in, and each tensor is rounded to bf16 once when stored.  Algorithmic bytes per parameter:
+// read p,m,v (bf16) + grad (fp32) = 10, write p,m,v = 6.
+__device__ __forceinline__ void adamw_plain_math(float& p, float g, float& m, float& v, double lr, double b1, double b2, double wd,
+                                                double eps, float bc1, float bc2_sqrt) {
+    if (wd != 0.0) p = (float)((double)p - lr * wd * (double)p);
+    const float w = (float)(1.0 - b1);                                     // lerp(exp_avg, grad, 1 - beta1), weight < 0.5 branch
+    m = w < 0.5f ? __fmaf_rn(w, g - m, m) : g - (g - m) * (1.f - w);
+    v = (float)(b2 * (double)v + (1.0 - b2) * (double)g * (double)g);
+    const float step_size = (float)(lr / (double)bc1);
+    const float denom = (float)((double)(__fsqrt_rn(v) / bc2_sqrt) + eps);
+    p -= step_size * m / denom;
+}
+
+__global__ __launch_bounds__(256) void adamw_plain_kernel(uint16_t* __restrict__ p, const float* __restrict__ grad,
+                                                         uint16_t* __restrict__ m, uint16_t* __restrict__ v, int64_t n, double lr,
+                                                         double b1, double b2, double wd, double eps, float bc1, float bc2_sqrt,
+                                                         const float* __restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    const int64_t n8 = n >> 3;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * blockDim.x) {
+        float pf[8], mf[8], vf[8], gf[8];
+        unpack8(reinterpret_cast<const uint4*>(p)[idx], pf);
+        unpack8(reinterpret_cast<const uint4*>(m)[idx], mf);
+        unpack8(reinterpret_cast<const uint4*>(v)[idx], vf);
+        const float4 g0 = reinterpret_cast<const float4*>(grad)[idx * 2], g1 = reinterpret_cast<const float4*>(grad)[idx * 2 + 1];
+        gf[0] = g0.x; gf[1] = g0.y; gf[2] = g0.z; gf[3] = g0.w; gf[4] = g1.x; gf[5] = g1.y; gf[6] = g1.z; gf[7] = g1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) adamw_plain_math(pf[j], bfround(gf[j] * gs), mf[j], vf[j], lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        reinterpret_cast<uint4*>(p)[idx] = pack8(pf);
+        reinterpret_cast<uint4*>(m)[idx] = pack8(mf);
+        reinterpret_cast<uint4*>(v)[idx] = pack8(vf);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) {
+            float pf = bf2f(p[i]), mf = bf2f(m[i]), vf = bf2f(v[i]);
+            adamw_plain_math(pf, bfround(grad[i] * gs), mf, vf, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+            p[i] = f2bf(pf); m[i] = f2bf(mf); v[i] = f2bf(vf);
+        }
+    }
+}
+
 // deterministic sum of squares: stage 1 -> scratch[blocks], stage 2 (one block) -> out
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ scratch) {
     double acc = 0.0;
@@ -509,6 +553,20 @@ int st_adamw_kahan_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, s
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(adamw_kahan_kernel, dim3(blocks), dim3(256), 0, s, p, grad, m, v, c, n, wd_mul, (float)beta1, one_m_b1,
                        (float)beta2, one_m_b2, (float)eps, -step_size, denom_corr, grad_scale);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_adamw_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, float bias_correction1, float bias_correction2_sqrt, const float* grad_scale, st_stream_t stream) {
+    if (!p || !grad || !m || !v || n < 0) return ST_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_ADAMW, s, 16.0 * (double)n);
+    int blocks = st_cdiv(n / 8 + 1, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(adamw_plain_kernel, dim3(blocks), dim3(256), 0, s, p, grad, m, v, n, lr, beta1, beta2, weight_decay, eps,
+                       bias_correction1, bias_correction2_sqrt, grad_scale);
     ST_CHECK_LAUNCH();
     return 0;
 }

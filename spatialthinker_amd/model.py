@@ -611,9 +611,10 @@ class Qwen25VL:
         that slice's all-reduce there when the pass is the last one of an optimizer step (actor.GradReducer)."""
         c, g, wT = self.cfg, self.p.g, self.p.wT
         on_final = loss_kw.pop("on_final", None)
+        train_vision = loss_kw.pop("train_vision", True)     # False: frozen vision tower — no ViT activations kept, no ViT backward
         off = self.p.offsets
         layer_lo = lambda i: off[f"l.{i}.in_norm"] if i < c.num_layers else off["final_norm"]
-        vit_saved: list = []
+        vit_saved: Optional[list] = [] if train_vision else None
         x = self._embed(b, vit_saved)
         saved = []
         for i in range(c.num_layers):
@@ -658,7 +659,7 @@ class Qwen25VL:
             if on_final is not None:
                 on_final(layer_lo(i), layer_lo(i + 1))
         ops.embed_grad_(g["embed"], b.embed_ids, dx)
-        if b.vis is not None:
+        if b.vis is not None and train_vision:
             d_img = ops.rows_gather(dx, b.image_rows)
             if b.vis["dup_idx"] is not None:                                          # gradient of the shared features = sum over their users
                 d_img = ops.rows_gather_sum(d_img, b.vis["dup_idx"])

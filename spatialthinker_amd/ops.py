@@ -402,6 +402,16 @@ def adamw_kahan_step_(p, grad_f32, m, v, c, *, t: int, lr, betas=(0.9, 0.999), e
                               step_size, dc, _p(grad_scale), _s())
 
 
+def adamw_step_(p, grad_f32, m, v, *, t: int, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=None):
+    """torch.optim.AdamW(fused=True) semantics on bf16 p / m / v (optim.strategy=adamw): bias corrections as torch's
+    _fused_adamw forms them (python doubles, cast once to the fp32 opmath type)."""
+    _chk(p, BF16, "p"); _chk(grad_f32, F32, "grad")
+    bc1 = 1.0 - betas[0] ** t
+    bc2_sqrt = (1.0 - betas[1] ** t) ** 0.5
+    lib().st_adamw_step(_p(p), _p(grad_f32), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, bc1, bc2_sqrt,
+                        _p(grad_scale), _s())
+
+
 def sumsq(x_f32, out=None, accumulate=False):
     scratch = torch.empty(1024, dtype=F32, device=x_f32.device)
     o = torch.zeros(1, dtype=F32, device=x_f32.device) if out is None else out

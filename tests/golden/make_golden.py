@@ -496,8 +496,80 @@ def gen_rl_extra():
     save("rl_extra", **out)
 
 
+# ------------------------------------------------------------------ 7. dataset row pipeline (verl/utils/dataset.py:34-265)
+def gen_dataset():
+    """Writes tests/golden/stvqa_tiny/{train,val}-00000.parquet (6 + 2 synthetic rows: STVQA-7K's columns, 3 random PNG images)
+    and dataset.npz = the reference RLHFDataset's output rows for several configurations, produced with the stub tokenizer /
+    processor of stub_mm.py (no real tokenizer files exist offline)."""
+    import io
+
+    import pandas as pd
+    from PIL import Image
+
+    from stub_mm import StubProcessor, StubTokenizer
+    from verl.utils.dataset import RLHFDataset, collate_fn
+
+    rs = np.random.RandomState(3)
+    root = os.path.join(HERE, "stvqa_tiny")
+    os.makedirs(root, exist_ok=True)
+
+    def png(w, h):
+        buf = io.BytesIO()
+        Image.fromarray(rs.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(buf, format="PNG")
+        return {"bytes": buf.getvalue(), "path": None}
+
+    def rows(n, tag):
+        out = []
+        for i in range(n):
+            w, h = [(64, 48), (30, 20), (200, 120)][i % 3]                      # 30x20 is below min_pixels (up-scaled), 200x120 above max_pixels
+            q = f"Image size: ({w} x {h})\nQ{tag}{i}. what is left of the {'dog' if i % 2 else 'cat'}?"
+            out.append({"images": [png(w, h)], "problem": ("<image>" if i % 4 != 3 else "") + q if i % 2 == 0 else q + " <image> tail ",
+                        "question_with_options": f"<image>{q}\nOptions: (A) a (B) b", "answer_option_text": f"<scene>{{}}</scene>\n<answer>(A) a{i}</answer>",
+                        "answer_option_text_only": f"(A) a{i}", "extra": i})
+        return out
+    pd.DataFrame(rows(6, "t")).to_parquet(os.path.join(root, "train-00000-of-00001.parquet"))
+    pd.DataFrame(rows(2, "v")).to_parquet(os.path.join(root, "val-00000-of-00001.parquet"))
+
+    out = {}
+    cases = {
+        "spatial": dict(split="train", prompt_key="problem", answer_key="answer_option_text", image_key="images", max_prompt_length=96,
+                        truncation="right", format_prompt=None, shuffle=False, mixed_data=False, text_only=False),
+        "vanilla": dict(split="val", prompt_key="question_with_options", answer_key="answer_option_text_only", image_key="images",
+                        max_prompt_length=160, truncation="right", format_prompt="  You FIRST think. \n", shuffle=True, mixed_data=False,
+                        text_only=False),
+        "mixed": dict(split="train", prompt_key="problem", answer_key="answer_option_text", image_key="images", max_prompt_length=128,
+                      truncation="left", format_prompt=None, shuffle=True, mixed_data=True, text_only=False),
+        "textonly": dict(split="train", prompt_key="problem", answer_key="answer_option_text", image_key="images", max_prompt_length=64,
+                         truncation="right", format_prompt=None, shuffle=False, mixed_data=False, text_only=True),
+    }
+    for name, c in cases.items():
+        ds = RLHFDataset(f"{root}@{c['split']}", StubTokenizer(), StubProcessor(), prompt_key=c["prompt_key"], answer_key=c["answer_key"],
+                         image_key=c["image_key"], mixed_data=c["mixed_data"], text_only=c["text_only"], max_prompt_length=c["max_prompt_length"],
+                         truncation=c["truncation"], format_prompt=c["format_prompt"], max_pixels=64 * 28 * 28 // 4, min_pixels=28 * 28 * 4,
+                         shuffle=c["shuffle"], seed=5)
+        out[f"{name}_len"] = np.array([len(ds)])
+        for i in range(len(ds)):
+            r = ds[i]
+            out[f"{name}_{i}_input_ids"] = r["input_ids"].numpy()
+            out[f"{name}_{i}_attention_mask"] = r["attention_mask"].numpy()
+            out[f"{name}_{i}_position_ids"] = r["position_ids"].numpy()
+            out[f"{name}_{i}_raw_prompt_ids"] = np.asarray(r["raw_prompt_ids"])
+            out[f"{name}_{i}_ground_truth"] = np.array([r["ground_truth"]])
+            out[f"{name}_{i}_extra"] = np.array([r["extra"]])
+            if "multi_modal_inputs" in r:
+                out[f"{name}_{i}_grid"] = r["multi_modal_inputs"]["image_grid_thw"].numpy()
+                pv = r["multi_modal_inputs"]["pixel_values"].numpy()
+                out[f"{name}_{i}_pix_stats"] = np.array([pv.shape[0], pv.shape[1], float(pv.sum()), float(np.abs(pv).sum()), float(pv[0, :8].sum())])
+                out[f"{name}_{i}_image_size"] = np.array(r["multi_modal_data"]["image"][0].size)
+        if name == "spatial":
+            b = collate_fn([ds[0], ds[1]])
+            out["collate_keys"] = np.array(sorted(b.keys()))
+            out["collate_input_ids"] = b["input_ids"].numpy()
+    save("dataset", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -510,3 +582,5 @@ if __name__ == "__main__":
         gen_model()
     if "extra" in which:
         gen_rl_extra()
+    if "dataset" in which:
+        gen_dataset()

@@ -62,7 +62,8 @@ def main():
                                          seed=cfg.data.seed + (1 if spec.endswith("@val") else 0), grid=grid, text_tokens=text)
         return RLHFDataset(spec, tokenizer, processor, prompt_key=cfg.data.prompt_key, answer_key=cfg.data.answer_key, image_key=cfg.data.image_key,
                            max_prompt_length=cfg.data.max_prompt_length, truncation="right", format_prompt=cfg.data.format_prompt,
-                           min_pixels=cfg.data.min_pixels, max_pixels=cfg.data.max_pixels, text_only=cfg.data.text_only)
+                           min_pixels=cfg.data.min_pixels, max_pixels=cfg.data.max_pixels, text_only=cfg.data.text_only,
+                           mixed_data=cfg.data.mixed_data, shuffle=cfg.data.shuffle, seed=cfg.data.seed)
 
     # the trainer validates the batch-size relations on the user's numbers BEFORE the worker scales global_batch_size by
     # rollout.n (ray_trainer.py:238-263 runs before fsdp_workers.py:130-136 in the reference too)

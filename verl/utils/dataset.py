@@ -2,7 +2,7 @@
 
 RLHFDataset mirrors the reference row pipeline (verl/utils/dataset.py:34-265): chat template ->
 processor -> pixel_values / image_grid_thw -> M-RoPE ids -> left-pad / truncate to max_prompt_length; it needs the real
-tokenizer + processor files and a parquet/HF dataset, none of which exist offline.  SyntheticSTVQADataset emits
+tokenizer + processor files and a parquet/HF dataset (a tiny parquet + stub processor pin it in tests).  SyntheticSTVQADataset emits
 STVQA-7K-shaped rows without any of them (`data.train_files=synthetic:stvqa@train`)."""
 from __future__ import annotations
 
@@ -72,32 +72,56 @@ class SyntheticSTVQADataset(Dataset):
 
 
 class RLHFDataset(Dataset):
-    """Real-data path (needs tokenizer/processor files + a dataset on disk or the hub; see module docstring)."""
+    """Real-data row pipeline of the reference (verl/utils/dataset.py:79-265), pinned against the reference
+    class itself by tests/golden/dataset.npz (tests/test_dataset.py).  data_path = "<dir | parquet file | hub id>[@split]"."""
 
     def __init__(self, data_path: str, tokenizer, processor, prompt_key="prompt", answer_key="answer", image_key="images",
-                 max_prompt_length=1024, truncation="error", format_prompt: Optional[str] = None, max_pixels=None, min_pixels=None,
-                 text_only: bool = False, **_unused):
+                 mixed_data: bool = False, text_only: bool = False, max_prompt_length=1024, truncation="error",
+                 format_prompt: Optional[str] = None, max_pixels=None, min_pixels=None, shuffle: bool = True, seed: int = 42):
+        import glob
+        import os
+
         from datasets import load_dataset
         self.tokenizer, self.processor = tokenizer, processor
         self.prompt_key, self.answer_key, self.image_key = prompt_key, answer_key, image_key
+        self.mixed_data, self.text_only = mixed_data, text_only
         self.max_prompt_length, self.truncation, self.format_prompt = max_prompt_length, truncation, format_prompt
-        self.max_pixels, self.min_pixels, self.text_only = max_pixels, min_pixels, text_only
+        self.max_pixels, self.min_pixels = max_pixels, min_pixels
         split = "train"
         if "@" in data_path:
             data_path, split = data_path.split("@")
-        import os
         if os.path.isdir(data_path):
-            self.dataset = load_dataset("parquet", data_dir=data_path, split="train")
+            # a local parquet directory holds "<split>-*.parquet" shards (dataset.py:121-148); the train split also registers the
+            # val files, exactly as the reference does
+            files = sorted(glob.glob(os.path.join(data_path, f"{split}-*.parquet")))
+            if not files:
+                raise ValueError(f"No files found for split '{split}' at path '{data_path}'")
+            data_files = {split: files}
+            if split == "train":
+                val = sorted(glob.glob(os.path.join(data_path, "val-*.parquet")))
+                if val:
+                    data_files["val"] = val
+            self.dataset = load_dataset("parquet", data_files=data_files, split=split)
         elif os.path.isfile(data_path):
-            self.dataset = load_dataset("parquet", data_files=data_path, split="train")
-        else:
+            self.dataset = load_dataset("parquet", data_files={split: [data_path]}, split=split)
+        else:                                                   # hub dataset id, e.g. hunarbatra/STVQA-7K@train
             self.dataset = load_dataset(data_path, split=split)
+        if mixed_data:                                          # :159-170 every even row loses its <image> marker (text-only half)
+            def drop_image(example, idx):
+                if idx % 2 == 0 and self.image_key in example and "<image>" in example[self.prompt_key]:
+                    example[self.prompt_key] = example[self.prompt_key].replace("<image>", "").strip()
+                return example
+            self.dataset = self.dataset.map(drop_image, with_indices=True, desc="Removing <image> from prompt_key")
+        if shuffle:
+            self.dataset = self.dataset.shuffle(seed=seed)
 
     def __len__(self):
         return len(self.dataset)
 
     def process_image(self, image):
+        """:56-75 — bytes/dict -> PIL, down-scale above max_pixels, up-scale below min_pixels, RGB."""
         from io import BytesIO
+
         from PIL import Image
         if isinstance(image, dict):
             image = Image.open(BytesIO(image["bytes"]))
@@ -115,19 +139,29 @@ class RLHFDataset(Dataset):
         row = dict(self.dataset[index])
         prompt = row[self.prompt_key]
         if self.format_prompt:
-            prompt = self.format_prompt.strip() + " " + prompt
+            prompt = self.format_prompt.strip() + " " + prompt          # prefix (:189-191)
         if self.text_only:
-            prompt = prompt.replace("<image>", "")
-        has_image = "<image>" in prompt and row.get(self.image_key) is not None
-        if has_image:
-            prompt = "<image> " + prompt.replace("<image>", "")
-            content = [{"type": "image"}, {"type": "text", "text": prompt.replace("<image> ", "", 1)}]
+            prompt = prompt.replace("<image>", "").strip()
+        if "<image>" in prompt and self.image_key in row and row[self.image_key] is not None:
+            # exactly one image marker, moved to the front (:205-206); text pieces are passed on verbatim (with their spaces)
+            prompt = "<image> " + prompt.replace("<image>", "").strip()
+            content = []
+            for i, piece in enumerate(prompt.split("<image>")):
+                if i != 0:
+                    content.append({"type": "image"})
+                if piece:
+                    content.append({"type": "text", "text": piece})
             text = self.processor.apply_chat_template([{"role": "user", "content": content}], add_generation_prompt=True, tokenize=False)
-            images = [self.process_image(im) for im in row.pop(self.image_key)]
-            enc = self.processor(images, [text], add_special_tokens=False, return_tensors="pt")
+            images = row.pop(self.image_key)
+            if not isinstance(images, list):
+                images = [images]
+            if any(im is None for im in images):
+                raise ValueError(f"Image is None at index {index} despite <image> token present. Check data logic.")
+            images = [self.process_image(im) for im in images]
+            enc = dict(self.processor(images, [text], return_tensors="pt"))
             input_ids, attention_mask = enc.pop("input_ids")[0], enc.pop("attention_mask")[0]
             row["multi_modal_data"] = {"image": images}
-            row["multi_modal_inputs"] = dict(enc)
+            row["multi_modal_inputs"] = enc
             tok = self.processor.tokenizer
             position_ids = torch.from_numpy(ix.get_rope_index(
                 input_ids.numpy(), enc["image_grid_thw"].numpy(), attention_mask.numpy(), image_token_id=tok.convert_tokens_to_ids("<|image_pad|>"),

@@ -69,16 +69,23 @@ class FSDPWorker:
             a = self.config.actor
             if a.optim.strategy not in ("adamw_bf16", "adamw"):
                 raise NotImplementedError(f"Optimizer {a.optim.strategy} not supported.")
-            if a.optim.strategy == "adamw":
-                self.print_rank0("note: optim.strategy=adamw runs the bf16-state Kahan AdamW kernel (the shipped scripts use adamw_bf16)")
+            dt = (a.fsdp.torch_dtype or "fp32").lower()
+            if dt not in ("bf16", "bfloat16"):
+                raise NotImplementedError(
+                    f"worker.actor.fsdp.torch_dtype={a.fsdp.torch_dtype!r}: this engine trains bf16 weights (pass worker.actor.fsdp.torch_dtype=bf16 "
+                    "as every shipped STVQA script does, scripts/spatialthinker_7b_grpo.sh:25); fp32 master weights (the reference's "
+                    "default when torch_dtype is unset, fsdp_workers.py:186-189) are not built")
             cfg, store, special = load_model(mc.model_path, trainable=True)
+            if mc.freeze_vision_tower:
+                self.print_rank0("Vision tower is set to not trainable.")
             hyper = ActorHyper(micro_batch_size_per_device_for_update=a.micro_batch_size_per_device_for_update,
                                micro_batch_size_per_device_for_experience=a.micro_batch_size_per_device_for_experience,
                                global_batch_size_per_device=a.global_batch_size_per_device, max_grad_norm=a.max_grad_norm,
                                clip_ratio_low=a.clip_ratio_low, clip_ratio_high=a.clip_ratio_high, clip_ratio_dual=a.clip_ratio_dual,
                                ppo_epochs=a.ppo_epochs, use_kl_loss=a.use_kl_loss, disable_kl=a.disable_kl, kl_penalty=a.kl_penalty,
                                kl_coef=a.kl_coef, lr=a.optim.lr, betas=tuple(a.optim.betas), weight_decay=a.optim.weight_decay,
-                               lr_warmup_steps=int(a.optim.lr_warmup_ratio * max(a.optim.training_steps, 0)))
+                               lr_warmup_steps=int(a.optim.lr_warmup_ratio * max(a.optim.training_steps, 0)),
+                               optim_strategy=a.optim.strategy, freeze_vision_tower=bool(mc.freeze_vision_tower))
             self.model_config, self.special = cfg, special
             self.actor = PolicyEngine(cfg, store, hyper)
             self.flops_counter = FlopsCounter(cfg)
@@ -168,13 +175,18 @@ class FSDPWorker:
     # ------------------------------------------------------------------------------------------------
     @register(dispatch_mode=Dispatch.ONE_TO_ALL)
     def save_checkpoint(self, path: str):
-        """Replicas are identical, so rank 0 writes ONE HF-format model + the optimizer state."""
+        """Replicas are identical, so rank 0 writes ONE HF-loadable directory (weights + config + generation config + tokenizer /
+        processor files, as fsdp_checkpoint_manager.py:96-131 puts under actor/huggingface) and ONE optimizer / scheduler / RNG-
+        position file (the reference writes a shard per rank: model_world_size_W_rank_r.pt etc., :52-95)."""
         assert self._is_actor
         if self.rank == 0:
-            save_hf(self.actor.store, os.path.join(path, "huggingface"))
             st = self.actor.store
-            torch.save({"m": st.m.cpu(), "v": st.v.cpu(), "c": st.c.cpu(), "opt_steps": self.actor.opt_steps,
-                        "sched_steps": self.actor.sched_steps}, os.path.join(path, "optim_world_size_1_rank_0.pt"))
+            save_hf(st, os.path.join(path, "huggingface"), tokenizer=getattr(self, "tokenizer", None), processor=getattr(self, "processor", None))
+            opt = {"m": st.m.cpu(), "v": st.v.cpu(), "opt_steps": self.actor.opt_steps, "sched_steps": self.actor.sched_steps,
+                   "gen_calls": getattr(self, "_gen_calls", 0), "strategy": self.actor.h.optim_strategy}
+            if self.actor.h.optim_strategy == "adamw_bf16":
+                opt["c"] = st.c.cpu()
+            torch.save(opt, os.path.join(path, "optim_world_size_1_rank_0.pt"))
         if self.world_size > 1:
             dist.barrier()
 
@@ -183,11 +195,18 @@ class FSDPWorker:
         if path is None:
             return
         from safetensors.torch import load_file
-        sd = load_file(os.path.join(path, "huggingface", "model.safetensors"))
-        self.actor.store.load_hf_state_dict(sd)
-        opt = torch.load(os.path.join(path, "optim_world_size_1_rank_0.pt"), map_location="cpu")
+        import glob
+        sd = {}
+        for shard in sorted(glob.glob(os.path.join(path, "huggingface", "*.safetensors"))):
+            sd.update(load_file(shard))
         st = self.actor.store
-        st.m.copy_(opt["m"]); st.v.copy_(opt["v"]); st.c.copy_(opt["c"])
+        st.load_hf_state_dict(sd)
+        st.version = getattr(st, "version", 0) + 1
+        opt = torch.load(os.path.join(path, "optim_world_size_1_rank_0.pt"), map_location="cpu")
+        st.m.copy_(opt["m"]); st.v.copy_(opt["v"])
+        if "c" in opt:
+            st.c.copy_(opt["c"])
         self.actor.opt_steps, self.actor.sched_steps = opt["opt_steps"], opt["sched_steps"]
+        self._gen_calls = opt.get("gen_calls", 0)                     # the rollout seed stream continues where it stopped
         if self.world_size > 1:
             dist.barrier()

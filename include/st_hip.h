@@ -35,6 +35,13 @@ enum { ST_K_GEMM = 0, ST_K_ATTN_FWD = 1, ST_K_ATTN_BWD = 2, ST_K_LOGPROB = 3, ST
 int st_prof_enable(int klass, int max_events);
 int st_prof_read(int klass, int* launches, double* total_ms, double* total_units);
 int st_prof_disable(int klass);
+/* sample every stride-th launch of the class (default 1): max_events then spans stride * max_events launches of a long run */
+int st_prof_set_stride(int klass, int stride);
+/* algorithmic units (flops / bytes) of the NEXT launch of the class, for launchers whose work depends on device-side ranges
+ * (attention: the host-side packing knows the (query, key) pair count); ignored while the class is disabled */
+int st_prof_hint_units(int klass, double units);
+/* launches of the class seen since st_prof_enable / the last st_prof_read (sampled or not; graph-captured ones excluded) */
+int64_t st_prof_seen(int klass);
 
 /* ---- fused log-prob (replaces flash_attn.ops.triton.cross_entropy, called from
  *      verl/utils/torch_functional.py:34-42 via verl/workers/actor/dp_actor.py:125-128) --------

@@ -89,9 +89,11 @@ __device__ __forceinline__ float st_half_sum(float v) {
 // ---- launch / profiling plumbing (host side) -------------------------------------------------
 struct StProf {
     bool on = false;
-    int cap = 0, n = 0;
+    int cap = 0, n = 0, stride = 1;
+    long long seen = 0;            // eligible (non-captured) launches since st_prof_enable, sampled or not
     hipEvent_t* ev = nullptr;      // 2*cap events
-    double units = 0.0;
+    double units = 0.0;            // algorithmic flops / bytes of the SAMPLED launches
+    double pending = 0.0;          // st_prof_hint_units: units of the next launch when the launcher cannot know them (attention)
 };
 extern StProf g_prof[ST_K_COUNT];
 
@@ -99,10 +101,15 @@ struct StProfScope {
     int k; hipStream_t s; bool live;
     StProfScope(int klass, hipStream_t st, double units) : k(klass), s(st), live(false) {
         StProf& p = g_prof[k];
-        if (p.on && p.n < p.cap) {
+        if (p.on) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             hipStreamIsCapturing(s, &cs);                       // launches captured into a hipGraph are not timed
-            if (cs == hipStreamCaptureStatusNone) { live = true; hipEventRecord(p.ev[2 * p.n], s); p.units += units; }
+            if (cs == hipStreamCaptureStatusNone) {
+                const bool pick = (p.seen % p.stride) == 0 && p.n < p.cap;      // every stride-th launch: the cap spans the whole run
+                p.seen++;
+                if (pick) { live = true; hipEventRecord(p.ev[2 * p.n], s); p.units += units > 0.0 ? units : p.pending; }
+            }
+            p.pending = 0.0;
         }
     }
     ~StProfScope() {

@@ -328,6 +328,7 @@ class DeviceBatch:
     logit_dup: Optional[torch.Tensor] = None
     logit_distinct: Optional[torch.Tensor] = None
     first_prompt: Optional[torch.Tensor] = None
+    pairs: float = 0.0                   # (query, key) pairs of one LM attention launch over this batch (profiling hooks only)
 
 
 class Qwen25VL:
@@ -381,7 +382,8 @@ class Qwen25VL:
             vcos = np.zeros((N_pad, c.v_head_dim // 2), np.float32); vcos[:plan.n_patches] = plan.cos
             vsin = np.zeros_like(vcos); vsin[:plan.n_patches] = plan.sin
             px = pixel_values if torch.is_tensor(pixel_values) else torch.from_numpy(np.asarray(pixel_values))
-            vis = dict(N=plan.n_patches, N_pad=N_pad, px=px.to(device=dev, dtype=F32, non_blocking=True), gather=t(gather, I32),
+            sq = lambda cu: float((np.diff(np.asarray(cu, dtype=np.float64)) ** 2).sum())
+            vis = dict(pairs_win=sq(plan.cu_window), pairs_img=sq(plan.cu_image), N=plan.n_patches, N_pad=N_pad, px=px.to(device=dev, dtype=F32, non_blocking=True), gather=t(gather, I32),
                        inverse=t(plan.merged_inverse, I32), cu_win=t(plan.cu_window, I32), cu_img=t(plan.cu_image, I32),
                        max_win=plan.max_window, max_img=plan.max_image, cos=t(vcos, F32), sin=t(vsin, F32),
                        img_src=None if img_src is None else t(img_src, I32), dup_idx=None if dup_idx is None else t(dup_idx, I32))
@@ -389,7 +391,7 @@ class Qwen25VL:
         return DeviceBatch(pk, t(pk.ids, I32), t(pk.embed_ids, I32), t(pk.cu_seqlens, I32), cos, sin, t(pk.image_rows, I32),
                            t(rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, vis, seg,
                            None if pk.logit_dup is None else t(pk.logit_dup, I32),
-                           None if pk.logit_distinct is None else t(pk.logit_distinct, I32))
+                           None if pk.logit_distinct is None else t(pk.logit_distinct, I32), pairs=_seg_pairs(pk))
 
     # ---------------------------------------------------------------- vision tower
     def _vit_forward(self, b: DeviceBatch, save: Optional[list]):
@@ -410,7 +412,8 @@ class Qwen25VL:
             full = i in c.v_fullatt
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             a = torch.zeros(Np, vh, dtype=BF16, device=x.device)
-            _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a)
+            _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a,
+                                  pairs=v["pairs_img"] if full else v["pairs_win"])
             x1 = ops.gemm_nt(a, w[p + "proj_w"], bias=w[p + "proj_b"], residual=x)
             h2, r2 = ops.rmsnorm_fwd(x1, w[p + "norm2"], 1e-6)
             gu = ops.gemm_nt(h2, w[p + "gu_w"], bias=w[p + "gu_b"])
@@ -457,7 +460,7 @@ class Qwen25VL:
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             dqkv = torch.zeros_like(qkv)
             ops.attn_bwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], a, da, lse, cu, mx, heads, heads, hd, self.v_scale, False,
-                         dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:])
+                         dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:], pairs=v["pairs_img"] if full else v["pairs_win"])
             ops.rope_apply_(dqkv, v["cos"], v["sin"], 2 * heads, hd, inverse=True)
             self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
             dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
@@ -497,7 +500,7 @@ class Qwen25VL:
         a = torch.zeros(x0.shape[0], nq * D, dtype=BF16, device=x0.device)
         kpre, vpre = prefix_kv if prefix_kv is not None else (None, None)     # prompt K/V cached by the rollout prefill
         _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a,
-                                  k_pre=kpre, v_pre=vpre)
+                                  k_pre=kpre, v_pre=vpre, pairs=b.pairs)
         x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x0)
         h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
         gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)      # SwiGLU in the epilogue; gate|up kept only for backward
@@ -532,7 +535,7 @@ class Qwen25VL:
         dqkv = torch.zeros_like(qkv)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
-                         self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:])
+                         self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
         ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
         self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
         dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
@@ -558,7 +561,7 @@ class Qwen25VL:
         labels = np.full(Tr_pad, -1, dtype=np.int64); labels[:Tr] = pk.labels
         seg = tuple(t(a, I32) for a in (pk.seg_b, pk.seg_e, pk.pre_b, pk.pre_e, pk.dep_e))
         b = DeviceBatch(pk, t(pk.ids, I32), t(pk.embed_ids, I32), t(pk.cu_seqlens, I32), cos, sin, t(pk.image_rows, I32),
-                        t(pk.logit_rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, None, seg)
+                        t(pk.logit_rows, I32), t(labels, I64), t(pk.out_index, I64), Tr_pad, None, seg, pairs=_seg_pairs(pk))
         b.first_prompt = t(pk.first_prompt, I32)
         return b
 
@@ -665,6 +668,12 @@ class Qwen25VL:
                 d_img = ops.rows_gather_sum(d_img, b.vis["dup_idx"])
             self._vit_backward(b, vit_saved, d_img)
         return lp_full.view(b.pk.B, b.pk.R), metrics
+
+
+def _seg_pairs(pk) -> float:
+    """(query, key) pairs of the shared-prefix causal attention over the packed segments: own rows causally + the whole prefix."""
+    L = (pk.seg_e - pk.seg_b).astype(np.float64)
+    return float((L * (L + 1) / 2 + L * (pk.pre_e - pk.pre_b)).sum())
 
 
 def _np(x):

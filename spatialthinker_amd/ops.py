@@ -334,9 +334,12 @@ def colsum(x, out_f32=None, accumulate=False):
 
 
 # ------------------------------------------------------------------ attention
-def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=None):
-    """q (T, >=n_q*D) view, k/v (T, >=n_kv*D) views (row strides may exceed the width: qkv buffer slices)."""
+def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=None, pairs=None):
+    """q (T, >=n_q*D) view, k/v (T, >=n_kv*D) views (row strides may exceed the width: qkv buffer slices).
+    pairs: number of (query, key) pairs the launch evaluates (host-side knowledge, only used for the profiling hooks)."""
     T = q.shape[0]
+    if pairs is not None:
+        prof_hint(K_ATTN_FWD if D == 128 else K_VIT_ATTN, 4.0 * D * n_q * pairs)
     o = torch.empty(T, n_q * D, dtype=BF16, device=q.device) if out is None else out
     lse = torch.empty(n_q, T, dtype=F32, device=q.device)
     lib().st_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(cu_seqlens), cu_seqlens.numel() - 1,
@@ -347,8 +350,10 @@ def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=N
 _attn_ws = {}
 
 
-def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, dq, dk, dv):
+def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, dq, dk, dv, pairs=None):
     T = q.shape[0]
+    if pairs is not None:
+        prof_hint(K_ATTN_BWD if D == 128 else K_VIT_ATTN, 10.0 * D * n_q * pairs)
     delta = torch.empty(n_q, T, dtype=F32, device=q.device)
     need = int(lib().st_attn_bwd_workspace_bytes(T, n_q, D))
     ws = _attn_ws.get(q.device)
@@ -361,9 +366,11 @@ def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, c
     return dq, dk, dv
 
 
-def attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, scale, out=None, k_pre=None, v_pre=None):
+def attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, scale, out=None, k_pre=None, v_pre=None, pairs=None):
     """Shared-prefix causal attention over packed segments (st_attn_fwd_seg); k_pre / v_pre: external prefix K/V tensors."""
     T = q.shape[0]
+    if pairs is not None:
+        prof_hint(K_ATTN_FWD, 4.0 * D * n_q * pairs)
     o = torch.empty(T, n_q * D, dtype=BF16, device=q.device) if out is None else out
     lse = torch.empty(n_q, T, dtype=F32, device=q.device)
     lib().st_attn_fwd_seg(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(seg_b), _p(seg_e), _p(pre_b), _p(pre_e),
@@ -372,8 +379,10 @@ def attn_fwd_seg(q, k, v, seg_b, seg_e, pre_b, pre_e, max_seg, n_q, n_kv, D, sca
     return o, lse
 
 
-def attn_bwd_seg(q, k, v, o, do, lse, seg_b, seg_e, pre_b, pre_e, dep_e, T_valid, max_seg, n_q, n_kv, D, scale, dq, dk, dv):
+def attn_bwd_seg(q, k, v, o, do, lse, seg_b, seg_e, pre_b, pre_e, dep_e, T_valid, max_seg, n_q, n_kv, D, scale, dq, dk, dv, pairs=None):
     T = q.shape[0]
+    if pairs is not None:
+        prof_hint(K_ATTN_BWD, 10.0 * D * n_q * pairs)
     delta = torch.empty(n_q, T, dtype=F32, device=q.device)
     need = int(lib().st_attn_bwd_workspace_bytes(T, n_q, D))
     ws = _attn_ws.get(q.device)
@@ -466,15 +475,31 @@ def add_(a, b, out=None):
 
 
 # ------------------------------------------------------------------ profiling hooks
-def prof_enable(klass: int, max_events: int = 200000):
+_prof_on = [False] * 8
+
+
+def prof_enable(klass: int, max_events: int = 200000, stride: int = 1):
+    """Event-time every `stride`-th launch of the class on its launch stream (hipGraph-captured launches are never timed)."""
     lib().st_prof_enable(klass, max_events)
+    lib().st_prof_set_stride(klass, stride)
+    _prof_on[klass] = True
 
 
 def prof_read(klass: int):
+    """(sampled launches, their summed ms, their summed algorithmic units)"""
     import ctypes
     n, ms, units = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
     lib().st_prof_read(klass, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(units))
     return n.value, ms.value, units.value
+
+
+def prof_seen(klass: int) -> int:
+    return int(lib().st_prof_seen(klass))
+
+
+def prof_hint(klass: int, units: float):
+    if _prof_on[klass]:
+        lib().st_prof_hint_units(klass, float(units))
 
 
 # ------------------------------------------------------------------ rollout (decode) kernels
@@ -513,3 +538,4 @@ def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, 
 
 def prof_disable(klass: int):
     lib().st_prof_disable(klass)
+    _prof_on[klass] = False

@@ -91,7 +91,7 @@ def test_7b_dimension_layer_shared_prompt_vs_oracle_fwd_bwd():
     m = rmask.astype(bool)
     err = np.abs(lp_e.cpu().numpy()[m] - lp.detach().numpy()[m]).max()
     print(f"7B-dimension layer: max |dlogp| vs fp32 oracle = {err:.4f}")
-    assert err < 6e-2
+    assert err < 2.2e-2                                   # measured 0.0169
     grads = store.export_hf(store.g)
     for n_, t in p32.items():
         if t.grad is None:
@@ -99,7 +99,7 @@ def test_7b_dimension_layer_shared_prompt_vs_oracle_fwd_bwd():
         want, got = t.grad.numpy(), grads[n_].float().cpu().numpy()
         rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-20)
         print(f"  grad {n_}: rel err {rel:.4f}")
-        assert rel < 8e-2, (n_, rel)
+        assert rel < 4.9e-2, (n_, rel)                    # measured 0.008 - 0.038
 
 
 def _run_group_case(dims, rs, batch, grad_suffixes, tol_lp, tol_grad):
@@ -149,7 +149,7 @@ def test_3b_dimension_layer_tied_embeddings_vs_oracle_fwd_bwd():
     rs = np.random.RandomState(23)
     batch = _group_batch(rs, n_roll=3, text=(30, 50), grid=(1, 32, 32), R=48, Pc=384)
     err, rels = _run_group_case(FULL_3B, rs, batch, ("embed_tokens.weight", "q_proj.weight", "gate_proj.weight", "merger.mlp.2.weight",
-                                                     "input_layernorm.weight"), tol_lp=3e-2, tol_grad=5e-2)
+                                                     "input_layernorm.weight"), tol_lp=7.5e-3, tol_grad=2.2e-2)      # measured 0.0057 / <= 0.0167
     assert "model.language_model.embed_tokens.weight" in rels
 
 
@@ -159,4 +159,4 @@ def test_7b_dimension_64x64_grid_full_attention_vit_vs_oracle_fwd_bwd():
     rs = np.random.RandomState(29)
     batch = _group_batch(rs, n_roll=2, text=(24, 40), grid=(1, 64, 64), R=32, Pc=1152)
     _run_group_case(FULL, rs, batch, ("q_proj.weight", "blocks.1.attn.qkv.weight", "blocks.0.attn.proj.weight", "merger.mlp.0.weight",
-                                      "patch_embed.proj.weight"), tol_lp=3e-2, tol_grad=5e-2)
+                                      "patch_embed.proj.weight"), tol_lp=1.5e-2, tol_grad=4.2e-2)      # measured 0.0113 / <= 0.0321

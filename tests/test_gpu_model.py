@@ -49,7 +49,7 @@ def test_log_probs_vs_fp32_oracle_and_hf_golden(env):
     # HF itself in bf16 on this GPU: the size of a bf16 evaluation's own error
     err_hf = _hf_bf16_error(z, cfg, params, batch)
     print(f"engine max|dlogp| vs HF-fp32 golden: {err_golden:.4f}; HF-bf16 vs HF-fp32: {err_hf:.4f}")
-    assert err_golden <= max(1.5 * err_hf, 2e-2)
+    assert err_golden <= 1.5 * err_hf              # measured 0.0158 vs 0.0137: the side-by-side ratio decides, no absolute floor
     assert np.all(lp[~mask] == 0)
     # temperature is applied to the logits (dp_actor.py:126)
     lp2 = eng.log_probs(b, temperature=0.5).cpu().numpy()
@@ -57,7 +57,9 @@ def test_log_probs_vs_fp32_oracle_and_hf_golden(env):
                                torch.from_numpy(batch["input_ids"]), torch.from_numpy(batch["attention_mask"]),
                                torch.from_numpy(z["position_ids"]), batch["R"], 0.5, torch.from_numpy(batch["pixel_values"]),
                                batch["image_grid_thw"]).numpy()
-    assert np.abs(lp2[mask] - orc[mask]).max() <= max(3 * err_hf, 4e-2)
+    err_t = np.abs(lp2[mask] - orc[mask]).max()
+    print(f"temperature 0.5: max|dlogp| vs fp32 oracle {err_t:.4f}")
+    assert err_t <= 3 * err_hf                      # logits are doubled before the softmax: ~2x the temperature-1 error
 
 
 def _hf_bf16_error(z, cfg, params, batch):
@@ -122,7 +124,7 @@ def test_grpo_micro_batch_gradients_vs_oracle_autograd(env):
                                                    response_mask=dv(rmask, torch.int64)), 1.0,
                                            clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=2.0)
     mask = rmask.astype(bool)
-    assert np.abs(lp_eng.cpu().numpy()[mask] - lp.detach().numpy()[mask]).max() < 5e-2
+    assert np.abs(lp_eng.cpu().numpy()[mask] - lp.detach().numpy()[mask]).max() < 2.1e-2         # measured 0.0158
     grads = store.export_hf(store.g)
     worst = []
     for k, t in p32.items():
@@ -132,7 +134,7 @@ def test_grpo_micro_batch_gradients_vs_oracle_autograd(env):
         worst.append((rel, k))
     worst.sort(reverse=True)
     print("worst gradient relative errors:", worst[:6])
-    assert worst[0][0] < 6e-2, worst[:5]
+    assert worst[0][0] < 3.9e-2 and worst[1][0] < 2.5e-2, worst[:5]      # measured 0.0296 (a 256-element bias), then 0.0189
     # padded parameter regions must receive exactly zero gradient
     vi, vip = cfg.v_intermediate, cfg.v_inter_pad
     assert float(store.g["v.0.gu_w"][vi:vip].abs().max()) == 0 and float(store.g["v.0.down_w"][:, vi:].abs().max()) == 0
@@ -271,3 +273,31 @@ def test_recompute_light_activations_is_bit_identical(env):
     eng.recompute_light = False
     store.grad.zero_()
     assert torch.equal(grads[0], grads[1])
+
+
+def test_vision_tower_taps_vs_hf_golden(env):
+    """Direct check of the ViT path (patch embed, window reorder, 2-D RoPE, windowed + full attention, SwiGLU MLP, merger, inverse
+    reorder) against the HF-fp32 taps of model_tiny.npz: `vit_last*` = output of the last block (window order), `image_embeds*` =
+    merged features in image order.  The ViT only contributes a fifth of the LM tokens, so log-prob tolerances alone would dilute
+    an error here.  Bound: bf16 evaluation error, normalised by the tap's RMS."""
+    z, cfg, params, store, eng, batch = env
+    off = 0
+    for bi, n in enumerate(batch["patch_counts"]):
+        n = int(n)
+        sel = batch["attention_mask"][bi] == 1
+        b = eng.stage(batch["input_ids"][bi:bi + 1], batch["attention_mask"][bi:bi + 1], z["position_ids"][bi:bi + 1], batch["R"],
+                      batch["pixel_values"][off:off + n], batch["image_grid_thw"][bi:bi + 1])
+        off += n
+        saved = []
+        img = eng._vit_forward(b, saved).float().cpu().numpy()
+        last = saved[-1][0][:n].float().cpu().numpy()
+        for name, got, want in (("image_embeds", img[:n // 4], z[f"image_embeds{bi}"]), ("vit_last", last, z[f"vit_last{bi}"])):
+            rms = float(np.sqrt((want ** 2).mean()))
+            err = float(np.abs(got - want).max()) / rms
+            rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            print(f"ViT tap {name}{bi}: max|err|/rms = {err:.4f}, relative L2 = {rel:.5f}")
+            assert got.shape == want.shape
+            assert rel < VIT_TAP_REL_L2 and err < VIT_TAP_MAX_OVER_RMS, (name, bi, rel, err)
+
+
+VIT_TAP_REL_L2, VIT_TAP_MAX_OVER_RMS = 9.1e-3, 5.0e-2        # 1.3x the measured 0.0070 / 0.0386

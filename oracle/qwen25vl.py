@@ -134,19 +134,7 @@ def vision_tower(p: Dict[str, torch.Tensor], cfg: VLConfig, pixel_values: torch.
     cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]
     cu_full = P.vision_cu_seqlens(grid_thw)
     for i in range(cfg.v_depth):
-        b = f"{pre}blocks.{i}."
-        h = rms_norm(x, p[b + "norm1.weight"], 1e-6)
-        qkv = h @ p[b + "attn.qkv.weight"].t() + p[b + "attn.qkv.bias"]
-        q, k, v = qkv.reshape(N, 3, cfg.v_heads, hd).unbind(1)
-        q = q * cos + rotate_half(q) * sin                                          # :160-171
-        k = k * cos + rotate_half(k) * sin
-        cu = cu_full if i in cfg.v_fullatt else cu_win
-        a = dense_attention(q, k, v, cu, causal=False).reshape(N, -1)
-        x = x + a @ p[b + "attn.proj.weight"].t() + p[b + "attn.proj.bias"]
-        h = rms_norm(x, p[b + "norm2.weight"], 1e-6)
-        g = h @ p[b + "mlp.gate_proj.weight"].t() + p[b + "mlp.gate_proj.bias"]
-        u = h @ p[b + "mlp.up_proj.weight"].t() + p[b + "mlp.up_proj.bias"]
-        x = x + (F.silu(g) * u) @ p[b + "mlp.down_proj.weight"].t() + p[b + "mlp.down_proj.bias"]
+        x = vit_block(p, cfg, i, x, cos, sin, cu_full if i in cfg.v_fullatt else cu_win)
         if taps is not None:
             taps[f"vit_block{i}"] = x.detach().clone()
     m = pre + "merger."
@@ -157,6 +145,23 @@ def vision_tower(p: Dict[str, torch.Tensor], cfg: VLConfig, pixel_values: torch.
     if taps is not None:
         taps["image_embeds"] = out.detach().clone()
     return out
+
+
+def vit_block(p, cfg: VLConfig, i: int, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cu) -> torch.Tensor:
+    """One vision block (HF Qwen2_5_VLVisionBlock :286-322) on window-ordered patches x (N, v_hidden); cos/sin (N, 1, head_dim)."""
+    b = f"model.visual.blocks.{i}."
+    N, hd = x.shape[0], cfg.v_head_dim
+    h = rms_norm(x, p[b + "norm1.weight"], 1e-6)
+    qkv = h @ p[b + "attn.qkv.weight"].t() + p[b + "attn.qkv.bias"]
+    q, k, v = qkv.reshape(N, 3, cfg.v_heads, hd).unbind(1)
+    q = q * cos + rotate_half(q) * sin                                              # :160-171
+    k = k * cos + rotate_half(k) * sin
+    a = dense_attention(q, k, v, cu, causal=False).reshape(N, -1)
+    x = x + a @ p[b + "attn.proj.weight"].t() + p[b + "attn.proj.bias"]
+    h = rms_norm(x, p[b + "norm2.weight"], 1e-6)
+    g = h @ p[b + "mlp.gate_proj.weight"].t() + p[b + "mlp.gate_proj.bias"]
+    u = h @ p[b + "mlp.up_proj.weight"].t() + p[b + "mlp.up_proj.bias"]
+    return x + (F.silu(g) * u) @ p[b + "mlp.down_proj.weight"].t() + p[b + "mlp.down_proj.bias"]
 
 
 def forward_logits(p: Dict[str, torch.Tensor], cfg: VLConfig, input_ids: torch.Tensor,
@@ -175,29 +180,109 @@ def forward_logits(p: Dict[str, torch.Tensor], cfg: VLConfig, input_ids: torch.T
         x = x.clone()
         x[mask] = img.to(x.dtype)                                                   # masked_scatter :1209-1215
     cos, sin = mrope_cos_sin(position_ids, cfg.head_dim, cfg.rope_theta, cfg.mrope_section)
-    cos, sin = cos[:, None, :], sin[:, None, :]
-    T, D = x.shape[0], cfg.head_dim
     for i in range(cfg.num_layers):
-        b = f"{lm}layers.{i}."
-        h = rms_norm(x, p[b + "input_layernorm.weight"], cfg.rms_eps)
-        q = (h @ p[b + "self_attn.q_proj.weight"].t() + p[b + "self_attn.q_proj.bias"]).reshape(T, cfg.num_heads, D)
-        k = (h @ p[b + "self_attn.k_proj.weight"].t() + p[b + "self_attn.k_proj.bias"]).reshape(T, cfg.num_kv_heads, D)
-        v = (h @ p[b + "self_attn.v_proj.weight"].t() + p[b + "self_attn.v_proj.bias"]).reshape(T, cfg.num_kv_heads, D)
-        q = q * cos + rotate_half(q) * sin
-        k = k * cos + rotate_half(k) * sin
-        a = dense_attention(q, k, v, cu_seqlens, causal=True).reshape(T, -1)
-        x = x + a @ p[b + "self_attn.o_proj.weight"].t()
-        h = rms_norm(x, p[b + "post_attention_layernorm.weight"], cfg.rms_eps)
-        g = h @ p[b + "mlp.gate_proj.weight"].t()
-        u = h @ p[b + "mlp.up_proj.weight"].t()
-        x = x + (F.silu(g) * u) @ p[b + "mlp.down_proj.weight"].t()
+        x = lm_layer(p, cfg, i, x, cos, sin, cu_seqlens)
         if taps is not None:
             taps[f"lm_layer{i}"] = x.detach().clone()
     if rows is not None:
         x = x[rows]
+    return lm_head(p, cfg, x)
+
+
+def lm_layer(p, cfg: VLConfig, i: int, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cu_seqlens, kv_out: Optional[list] = None):
+    """One decoder layer (HF Qwen2_5_VLDecoderLayer :692-758) on packed rows x (T, H); cos/sin (T, head_dim).
+    kv_out: if a list, the layer's roped K and V (T, Hkv, D) are appended (prefill of the KV-cache decode below)."""
+    b = f"model.language_model.layers.{i}."
+    T, D = x.shape[0], cfg.head_dim
+    c, s_ = cos[:, None, :], sin[:, None, :]
+    h = rms_norm(x, p[b + "input_layernorm.weight"], cfg.rms_eps)
+    q = (h @ p[b + "self_attn.q_proj.weight"].t() + p[b + "self_attn.q_proj.bias"]).reshape(T, cfg.num_heads, D)
+    k = (h @ p[b + "self_attn.k_proj.weight"].t() + p[b + "self_attn.k_proj.bias"]).reshape(T, cfg.num_kv_heads, D)
+    v = (h @ p[b + "self_attn.v_proj.weight"].t() + p[b + "self_attn.v_proj.bias"]).reshape(T, cfg.num_kv_heads, D)
+    q = q * c + rotate_half(q) * s_
+    k = k * c + rotate_half(k) * s_
+    if kv_out is not None:
+        kv_out.append((k, v))
+    a = dense_attention(q, k, v, cu_seqlens, causal=True).reshape(T, -1)
+    x = x + a @ p[b + "self_attn.o_proj.weight"].t()
+    h = rms_norm(x, p[b + "post_attention_layernorm.weight"], cfg.rms_eps)
+    g = h @ p[b + "mlp.gate_proj.weight"].t()
+    u = h @ p[b + "mlp.up_proj.weight"].t()
+    return x + (F.silu(g) * u) @ p[b + "mlp.down_proj.weight"].t()
+
+
+def lm_head(p, cfg: VLConfig, x: torch.Tensor) -> torch.Tensor:
+    """final RMSNorm + lm_head (tied to the embedding table for the 3B model) on rows x (n, H) -> logits (n, V)."""
+    lm = "model.language_model."
     x = rms_norm(x, p[lm + "norm.weight"], cfg.rms_eps)
     head = p[lm + "embed_tokens.weight"] if cfg.tie_word_embeddings else p["lm_head.weight"]
     return x @ head.t()
+
+
+def lm_layer_decode(p, cfg: VLConfig, i: int, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, k_cache: torch.Tensor,
+                    v_cache: torch.Tensor, lens: torch.Tensor):
+    """One decoder layer for ONE new token per sequence with a KV cache: x (B, H), cos/sin (B, head_dim), k_cache / v_cache
+    (B, S_max, Hkv, D) holding lens[b] valid positions; the new K/V are written at position lens[b] (in place) and the token attends
+    to positions [0, lens[b]].  The plain-PyTorch decode loop the CPU baseline times."""
+    b_ = f"model.language_model.layers.{i}."
+    B, D = x.shape[0], cfg.head_dim
+    c, s_ = cos[:, None, :], sin[:, None, :]
+    h = rms_norm(x, p[b_ + "input_layernorm.weight"], cfg.rms_eps)
+    q = (h @ p[b_ + "self_attn.q_proj.weight"].t() + p[b_ + "self_attn.q_proj.bias"]).reshape(B, cfg.num_heads, D)
+    k = (h @ p[b_ + "self_attn.k_proj.weight"].t() + p[b_ + "self_attn.k_proj.bias"]).reshape(B, cfg.num_kv_heads, D)
+    v = (h @ p[b_ + "self_attn.v_proj.weight"].t() + p[b_ + "self_attn.v_proj.bias"]).reshape(B, cfg.num_kv_heads, D)
+    q = q * c + rotate_half(q) * s_
+    k = k * c + rotate_half(k) * s_
+    ar = torch.arange(B)
+    k_cache[ar, lens] = k
+    v_cache[ar, lens] = v
+    rep = cfg.num_heads // cfg.num_kv_heads
+    S = int(lens.max()) + 1
+    ks = k_cache[:, :S].repeat_interleave(rep, dim=2)                       # (B, S, Hq, D)
+    vs = v_cache[:, :S].repeat_interleave(rep, dim=2)
+    sc = torch.einsum("bhd,bshd->bhs", q, ks) / math.sqrt(D)
+    sc = sc.masked_fill(torch.arange(S)[None, None, :] > lens[:, None, None], float("-inf"))
+    a = torch.einsum("bhs,bshd->bhd", torch.softmax(sc, dim=-1), vs).reshape(B, -1)
+    x = x + a @ p[b_ + "self_attn.o_proj.weight"].t()
+    h = rms_norm(x, p[b_ + "post_attention_layernorm.weight"], cfg.rms_eps)
+    g = h @ p[b_ + "mlp.gate_proj.weight"].t()
+    u = h @ p[b_ + "mlp.up_proj.weight"].t()
+    return x + (F.silu(g) * u) @ p[b_ + "mlp.down_proj.weight"].t()
+
+
+@torch.no_grad()
+def generate_greedy(p, cfg: VLConfig, input_ids: torch.Tensor, position_ids: torch.Tensor, max_new_tokens: int,
+                    pixel_values: Optional[torch.Tensor] = None, grid_thw=None) -> torch.Tensor:
+    """Greedy continuation of ONE un-padded prompt with a KV cache: prefill -> argmax -> lm_layer_decode loop.  position ids of
+    the new tokens continue last+1.. on all three M-RoPE rows (vllm_rollout_spmd.py:159-170).  Returns (max_new_tokens,) ids."""
+    lm = "model.language_model."
+    T = input_ids.shape[0]
+    x = p[lm + "embed_tokens.weight"][input_ids]
+    if pixel_values is not None:
+        img = vision_tower(p, cfg, pixel_values, grid_thw)
+        x = x.clone()
+        x[input_ids == cfg.image_token_id] = img.to(x.dtype)
+    cos, sin = mrope_cos_sin(position_ids, cfg.head_dim, cfg.rope_theta, cfg.mrope_section)
+    S_max = T + max_new_tokens
+    kc = [torch.zeros(1, S_max, cfg.num_kv_heads, cfg.head_dim) for _ in range(cfg.num_layers)]
+    vc = [torch.zeros(1, S_max, cfg.num_kv_heads, cfg.head_dim) for _ in range(cfg.num_layers)]
+    for i in range(cfg.num_layers):
+        kv: list = []
+        x = lm_layer(p, cfg, i, x, cos, sin, [0, T], kv_out=kv)
+        kc[i][0, :T], vc[i][0, :T] = kv[0]
+    tok = int(lm_head(p, cfg, x[-1:]).argmax(-1))
+    out = [tok]
+    pos = position_ids[:, -1:] + 1
+    lens = torch.tensor([T])
+    for _ in range(max_new_tokens - 1):
+        h = p[lm + "embed_tokens.weight"][torch.tensor([tok])]
+        c1, s1 = mrope_cos_sin(pos, cfg.head_dim, cfg.rope_theta, cfg.mrope_section)
+        for i in range(cfg.num_layers):
+            h = lm_layer_decode(p, cfg, i, h, c1, s1, kc[i], vc[i], lens)
+        tok = int(lm_head(p, cfg, h).argmax(-1))
+        out.append(tok)
+        pos, lens = pos + 1, lens + 1
+    return torch.tensor(out)
 
 
 def response_log_probs(p, cfg: VLConfig, input_ids_2d, attention_mask_2d, position_ids_3d, response_length: int,

@@ -32,6 +32,11 @@ class Generator:
         self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
         self.autotune = autotune          # time the decode GEMM tile/split-K candidates once per (batch, weight shape)
+        # decode-loop accounting for the HBM roofline of the rollout (bench.py `roofline_decode`): seconds inside the replayed
+        # decode iterations (device events), iterations, and the ALGORITHMIC bytes one iteration must read — every LM weight once
+        # + the K/V of the live context (prompt K/V once per prompt and kv-head group, generated K/V per row)
+        self.stats = {"decode_s": 0.0, "decode_steps": 0, "decode_bytes": 0.0, "decode_row_steps": 0}
+        self._timers: list = []
 
     def _tune_decode(self, B: int):
         w = self.m.p.w
@@ -113,6 +118,7 @@ class Generator:
         ti = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev, I32)
         logits_g = torch.empty(B, c.vocab_size, dtype=BF16, device=dev)        # pending logits of every sample
         ops.gemm_nt(hn, head, out=logits_g)
+        w_bytes = 2.0 * (sum(w[f"l.{i}.{nm}"].numel() for i in range(L) for nm in ("qkv_w", "o_w", "gu_w", "down_w")) + head.numel())
         can_fuse = self.fused_decode and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
         wave = max(1, self.max_decode_batch)
         if self.autotune and wave <= 256:
@@ -245,6 +251,10 @@ class Generator:
                     iteration()
                 done = 1                                           # capture itself does not execute
             n_live = Ba
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            len0 = gen_len.sum()
+            ev0.record()
+            done0 = done
             while True:
                 if done % sync_every == 0 or done >= R:
                     n_live = int(active.sum().item())
@@ -255,6 +265,13 @@ class Generator:
                 else:
                     iteration()
                 done += 1
+            ev1.record()
+            steps = done - done0
+            if steps > 0:
+                kv_row = 2 * width * 2 * L                                   # K and V bytes of one cached position over all layers
+                prompt_ctx = float(sum(int(pe[p_] - pb[p_]) for p_ in pids))
+                gen_ctx = float(len0.item() + gen_len.sum().item()) / 2.0    # mean generated context per iteration, summed over the rows
+                self._timers.append((ev0, ev1, steps, steps * (w_bytes + (prompt_ctx + gen_ctx) * kv_row), steps * Ba))
             out[S_l] = out_l
             gen_len_g[S_l] = gen_len
             pos_g[:, S_l] = pos
@@ -286,6 +303,13 @@ class Generator:
         while len(pool):
             S, pool = np.sort(pool[:wave]), pool[wave:]
             pool = np.concatenate([pool, run(S, len(S) > 32)])
+        torch.cuda.synchronize()
+        for ev0, ev1, steps, nbytes, rows in self._timers:
+            self.stats["decode_s"] += ev0.elapsed_time(ev1) * 1e-3
+            self.stats["decode_steps"] += steps
+            self.stats["decode_bytes"] += nbytes
+            self.stats["decode_row_steps"] += rows
+        self._timers = []
         if return_prompt_cache:
             return out, dict(kp=kp, vp=vp, last_h=last_h, p_off=p_off.astype(np.int64), prompt_ids=ids_np, prompt_mask=mask_np, n=n,
                              weights_version=getattr(self.m.p, "version", 0))

@@ -320,9 +320,8 @@ def gen_rewards():
 
 
 # ------------------------------------------------------------------ 5. HF tiny model
-def gen_model():
+def _hf_tiny_model():
     from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
-    from verl.models.transformers.qwen2_vl import get_rope_index
 
     c = tiny.TINY
     cfg = Qwen2_5_VLConfig(
@@ -345,7 +344,37 @@ def gen_model():
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all("inv_freq" in m for m in missing), (missing, unexpected)
+    return model
 
+
+def gen_generate():
+    """Greedy continuation by HF itself (`model.generate(do_sample=False)`, its own KV cache and rope-index bookkeeping) for the two
+    tiny image+text prompts: pins the oracle's KV-cache decode (oracle.qwen25vl.generate_greedy) and, through it, the GPU rollout."""
+    model = _hf_tiny_model()
+    batch = tiny.make_batch(tiny.TINY)
+    ids, mask, P = batch["input_ids"], batch["attention_mask"], batch["P"]
+    out, off = {}, 0
+    for b in range(ids.shape[0]):
+        sel = mask[b, :P] == 1
+        n_patch = int(batch["patch_counts"][b])
+        px = torch.from_numpy(batch["pixel_values"][off:off + n_patch])
+        off += n_patch
+        prompt = torch.from_numpy(ids[b, :P][sel])[None]
+        with torch.no_grad():
+            # transformers 5.x derives the M-RoPE ids inside generate() from mm_token_type_ids (1 = image placeholder)
+            seq = model.generate(input_ids=prompt, attention_mask=torch.ones_like(prompt), pixel_values=px,
+                                 mm_token_type_ids=(prompt == tiny.TINY["image_token_id"]).int(),
+                                 image_grid_thw=torch.from_numpy(batch["image_grid_thw"][b:b + 1]), max_new_tokens=10, do_sample=False,
+                                 eos_token_id=None, pad_token_id=tiny.PAD_ID)
+        out[f"greedy{b}"] = seq[0, prompt.shape[1]:].numpy()
+    save("generate_tiny", **out)
+
+
+def gen_model():
+    from verl.models.transformers.qwen2_vl import get_rope_index
+
+    c = tiny.TINY
+    model = _hf_tiny_model()
     proc = types.SimpleNamespace(
         tokenizer=_FakeTok({"<|image_pad|>": c["image_token_id"], "<|video_pad|>": 1009, "<|vision_start|>": c["vision_start_token_id"]}),
         image_processor=types.SimpleNamespace(merge_size=2))
@@ -569,7 +598,7 @@ def gen_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset", "generate"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -584,3 +613,5 @@ if __name__ == "__main__":
         gen_rl_extra()
     if "dataset" in which:
         gen_dataset()
+    if "generate" in which:
+        gen_generate()

@@ -61,6 +61,38 @@ def test_greedy_decode_matches_teacher_forced_oracle(env, use_graph):
             assert chosen >= float(row.max()) - 0.08, (b, j, chosen, float(row.max()))    # argmax up to bf16 noise
 
 
+def test_greedy_decode_vs_hf_generate_golden(env, golden_dir):
+    """Greedy rollout vs transformers' own `generate(do_sample=False)` on the same tiny model (tests/golden/generate_tiny.npz, made by
+    make_golden.py gen_generate; the oracle's KV-cache decode reproduces it exactly on CPU).  bf16 evaluation may flip an argmax whose
+    fp32 margin is below the bf16 noise (0.08 on these logits): tokens must agree up to the first such near-tie, which the fp32
+    oracle's teacher-forced logits identify."""
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    gold = np.load(os.path.join(golden_dir, "generate_tiny.npz"))
+    R = 10
+    out = gen.generate(ids, mask, pos, n=1, max_new_tokens=R, temperature=0.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                       pixel_values=pix, image_grid_thw=grids, ignore_eos=True).cpu().numpy()
+    p32 = {k: torch.from_numpy(v) for k, v in params.items()}
+    ocfg = Q.VLConfig(**tiny.TINY)
+    agreed = 0
+    for b in range(2):
+        want = gold[f"greedy{b}"]
+        sel = mask[b] == 1
+        seq = np.concatenate([ids[b][sel], want])
+        ppos = np.concatenate([pos[b][:, sel], pos[b][:, -1:] + np.arange(1, R + 1)], 1)
+        logits = Q.forward_logits(p32, ocfg, torch.from_numpy(seq), torch.from_numpy(ppos), [0, len(seq)], pix[b], grids[b])
+        L0 = int(sel.sum())
+        for j in range(R):
+            if out[b, j] == want[j]:
+                agreed += 1
+                continue
+            top2 = torch.topk(logits[L0 - 1 + j], 2).values
+            assert float(top2[0] - top2[1]) < 0.08, (b, j, out[b].tolist(), want.tolist(), top2.tolist())   # a genuine near-tie
+            break
+    print(f"greedy tokens identical to HF generate: {agreed} of {2 * R}")
+    assert agreed >= R                                                        # and at least half of them before any near-tie
+
+
 def test_fused_decode_epilogues_are_bit_identical_to_unfused_chain(env):
     """The fused decode step (slab GEMM + finish/RoPE/KV-append, finish/RMSNorm, SwiGLU epilogue) keeps every bf16 rounding
     point of the unfused launch chain: sampled responses agree token for token."""

@@ -67,3 +67,19 @@ def test_packed_logprobs_and_logits(setup):
     rows = torch.tensor([3, 10, int(cu[1]) + 2])
     sub = Q.forward_logits(params, cfg, ids, pos, cu, torch.from_numpy(batch["pixel_values"]), batch["image_grid_thw"], rows=rows)
     np.testing.assert_allclose(sub.numpy(), logits[rows].numpy(), atol=5e-6)
+
+
+def test_kv_cache_greedy_decode_matches_hf_generate(setup, golden_dir):
+    """oracle.qwen25vl.generate_greedy (prefill + lm_layer_decode loop over a KV cache: the decode loop the CPU baseline times) vs
+    transformers' generate(do_sample=False) on the tiny model — token for token (tests/golden/generate_tiny.npz)."""
+    import os
+    z, cfg, params, batch = setup
+    gold = np.load(os.path.join(golden_dir, "generate_tiny.npz"))
+    Pn, off = batch["P"], 0
+    for b in range(2):
+        sel = batch["attention_mask"][b, :Pn] == 1
+        n = int(batch["patch_counts"][b])
+        out = Q.generate_greedy(params, cfg, torch.from_numpy(batch["input_ids"][b, :Pn][sel]), torch.from_numpy(z["position_ids"][b][:, :Pn][:, sel]),
+                                10, torch.from_numpy(batch["pixel_values"][off:off + n]), batch["image_grid_thw"][b:b + 1])
+        off += n
+        assert out.tolist() == gold[f"greedy{b}"].tolist()

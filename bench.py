@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--prompts-per-gpu", type=int, default=64,
                     help="rollout prompts per GPU and step (64 = the reference's 512-prompt rollout batch over 8 GPUs; SURVEY 8d' #3/#4)")
     ap.add_argument("--rollouts", type=int, default=8)
-    ap.add_argument("--response-cap", type=int, default=1024, help="max_response_length of the synthetic batch")
+    ap.add_argument("--response-cap", type=int, default=2048,
+                    help="max_response_length of the synthetic batch (scripts/spatialthinker_7b_grpo.sh:34: 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
@@ -136,10 +137,18 @@ def synth_reward_strings(n, rs):
 
 
 # ------------------------------------------------------------------ CPU baseline (oracle, bounded sample)
-def cpu_baseline(cfg, S_text, grid, R_mean):
-    """Times the fp32 CPU oracle on ONE STVQA-shaped sequence at reduced depth — (1,1), (2,1), (1,2) LM/ViT layers —
-    and extrapolates linearly in depth to the full model: cost/sample = 2 no-grad forwards (old, ref) + 1 forward/backward."""
+def cpu_baseline():
+    """SURVEY 8(d) CPU baseline = BASELINE.json config #1 (Qwen2.5-VL-3B shape, 2 prompts x G=4, one 224x224 image = 256 patches =
+    64 image tokens, 700 text tokens, ~512-token responses) through the build's CPU restatement of the actor path (oracle/, plain
+    PyTorch, all host cores): old-log-prob forward + ref forward + update forward/backward + AdamW + KV-cache generation.
+    BOUNDED SAMPLE (about 20 s): one update micro-batch (1 prompt x G=4 = 4 sequences of 1276 tokens) at the real 3B widths,
+    timed COMPONENT by component — one LM decoder layer, one ViT block, final norm + lm_head + log-softmax on the response rows,
+    one KV-cache decode step of one layer for the 8 concurrent rollouts, one AdamW-Kahan step on 2M parameters — fp32, plus the
+    LM layer forward in bf16; the step cost is assembled as 36 x layer + 32 x block + head (+ per-token decode x 512) and doubled
+    for the second prompt."""
+    from oracle import positions as OP
     from oracle import qwen25vl as Q
+    from oracle import rl_math as M
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:                                                    # honour the container's CPU quota (cgroup v2)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -148,54 +157,120 @@ def cpu_baseline(cfg, S_text, grid, R_mean):
     except Exception:
         pass
     torch.set_num_threads(threads)
-    t, h, w = grid
-    n_patch = t * h * w
-    n_img = n_patch // 4
-    S = S_text + n_img + R_mean
+    L_LM, L_VIT, G, n_prompt, P_txt, n_img_tok, R = 36, 32, 4, 2, 700, 64, 512
+    c = Q.VLConfig(hidden_size=2048, intermediate_size=11008, num_layers=1, num_heads=16, num_kv_heads=2, vocab_size=151936, v_depth=1,
+                   tie_word_embeddings=True)
+    H, I, D, V = c.hidden_size, c.intermediate_size, c.head_dim, c.vocab_size
+    S = P_txt + n_img_tok + R
+    T = G * S
+    gen = torch.Generator().manual_seed(0)
+    rnd = lambda *sh: torch.randn(*sh, generator=gen) * 0.02
+    kv = c.num_kv_heads * D
+    lm = {"input_layernorm.weight": torch.ones(H), "post_attention_layernorm.weight": torch.ones(H), "self_attn.q_proj.weight": rnd(H, H),
+          "self_attn.q_proj.bias": torch.zeros(H), "self_attn.k_proj.weight": rnd(kv, H), "self_attn.k_proj.bias": torch.zeros(kv),
+          "self_attn.v_proj.weight": rnd(kv, H), "self_attn.v_proj.bias": torch.zeros(kv), "self_attn.o_proj.weight": rnd(H, H),
+          "mlp.gate_proj.weight": rnd(I, H), "mlp.up_proj.weight": rnd(I, H), "mlp.down_proj.weight": rnd(H, I)}
+    p = {"model.language_model.layers.0." + k: v for k, v in lm.items()}
+    vh, vi = c.v_hidden, c.v_intermediate
+    vit = {"norm1.weight": torch.ones(vh), "norm2.weight": torch.ones(vh), "attn.qkv.weight": rnd(3 * vh, vh), "attn.qkv.bias": torch.zeros(3 * vh),
+           "attn.proj.weight": rnd(vh, vh), "attn.proj.bias": torch.zeros(vh), "mlp.gate_proj.weight": rnd(vi, vh), "mlp.gate_proj.bias": torch.zeros(vi),
+           "mlp.up_proj.weight": rnd(vi, vh), "mlp.up_proj.bias": torch.zeros(vi), "mlp.down_proj.weight": rnd(vh, vi), "mlp.down_proj.bias": torch.zeros(vh)}
+    p.update({"model.visual.blocks.0." + k: v for k, v in vit.items()})
+    n = V * H                                                # the 311M-entry tied table: a cheap ramp (timing does not depend on the values)
+    p["model.language_model.embed_tokens.weight"] = torch.arange(n, dtype=torch.float32).remainder_(997.0).mul_(4e-5).sub_(0.02).view(V, H)
+    p["model.language_model.norm.weight"] = torch.ones(H)
+
+    def timed(fn, reps=1):
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
+        return best
+
+    def grad_on(prefix, on):
+        for k, v in p.items():
+            if k.startswith(prefix):
+                v.requires_grad_(on); v.grad = None
+
+    # ---- LM decoder layer on the packed micro-batch (4 sequences x 1276 tokens)
+    pos = torch.arange(S).repeat(G)[None, :].repeat(3, 1)
+    cos, sin = Q.mrope_cos_sin(pos, D, c.rope_theta, c.mrope_section)
+    cu = [i * S for i in range(G + 1)]
+    x = torch.randn(T, H, generator=gen) * 0.1
+    with torch.no_grad():
+        Q.lm_layer(p, c, 0, x[:S], cos[:S], sin[:S], [0, S])                         # warm-up: thread pool, allocator
+        t_layer_f = timed(lambda: Q.lm_layer(p, c, 0, x, cos, sin, cu), 2)
+        p16 = {k: v.bfloat16() for k, v in p.items() if k.startswith("model.language_model.layers.0.")}
+        x16, c16, s16 = x.bfloat16(), cos.bfloat16(), sin.bfloat16()
+        t_layer_f_bf16 = timed(lambda: Q.lm_layer(p16, c, 0, x16, c16, s16, cu), 1)
+        del p16
+    grad_on("model.language_model.layers.0.", True)
+    xg = x.clone().requires_grad_(True)
+    t_layer_fb = timed(lambda: Q.lm_layer(p, c, 0, xg, cos, sin, cu).sum().backward())
+    grad_on("model.language_model.layers.0.", False)
+    # ---- ViT block on the micro-batch's ONE 16x16-patch image per sequence (the reference runs the tower per sequence: G copies)
+    grid = np.asarray([[1, 16, 16]] * G)
+    _, cu_win = OP.vision_window_index(grid, merge_size=2, window_size=112, patch_size=14)
+    N = 256 * G
+    xv = torch.randn(N, vh, generator=gen) * 0.1
+    ang = torch.randn(N, 1, c.v_head_dim, generator=gen)
+    with torch.no_grad():
+        t_vit_f = timed(lambda: Q.vit_block(p, c, 0, xv, ang.cos(), ang.sin(), cu_win), 2)
+    grad_on("model.visual.blocks.0.", True)
+    xvg = xv.clone().requires_grad_(True)
+    t_vit_fb = timed(lambda: Q.vit_block(p, c, 0, xvg, ang.cos(), ang.sin(), cu_win).sum().backward())
+    grad_on("model.visual.blocks.0.", False)
+    # ---- final norm + tied lm_head + log-softmax on the response rows (dp_actor.py:126-153)
+    rows = G * R
+    xr = torch.randn(rows, H, generator=gen) * 0.1
+    lab = torch.randint(0, V, (rows,), generator=gen)
+    head_fn = lambda xx: torch.log_softmax(Q.lm_head(p, c, xx), -1).gather(-1, lab[:, None]).sum()
+    with torch.no_grad():
+        t_head_f = timed(lambda: head_fn(xr))
+    p["model.language_model.embed_tokens.weight"].requires_grad_(True)
+    xrg = xr.clone().requires_grad_(True)
+    t_head_fb = timed(lambda: head_fn(xrg).backward())
+    p["model.language_model.embed_tokens.weight"].requires_grad_(False); p["model.language_model.embed_tokens.weight"].grad = None
+    # ---- generation: KV-cache decode, all 8 rollouts of the step in one batch, 32 tokens timed at a ~1000-token context
+    Bd, ctx, n_dec = n_prompt * G, P_txt + n_img_tok + R // 2, 32
+    kc, vc = torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen), torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen)
+    xd = torch.randn(Bd, H, generator=gen) * 0.1
+    lens = torch.full((Bd,), ctx)
+    cd, sd = Q.mrope_cos_sin(torch.full((3, Bd), ctx), D, c.rope_theta, c.mrope_section)
+
+    def dec():
+        ln = lens.clone()
+        for _ in range(n_dec):
+            Q.lm_layer_decode(p, c, 0, xd, cd, sd, kc, vc, ln); ln += 1
+    with torch.no_grad():
+        t_dec_layer = timed(dec) / n_dec
+        t_dec_head = timed(lambda: Q.lm_head(p, c, xd).argmax(-1), 2)
+    # ---- AdamW (AnyPrecisionAdamW with bf16 states + Kahan, the oracle's numpy restatement) on 2M parameters
+    n_par = 1 << 21
     rs = np.random.RandomState(0)
-
-    def run(n_lm, n_vit, grad):
-        oc = Q.VLConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_layers=n_lm, num_heads=cfg.num_heads,
-                        num_kv_heads=cfg.num_kv_heads, vocab_size=cfg.vocab_size, v_depth=n_vit, v_hidden=cfg.v_hidden, v_heads=cfg.v_heads,
-                        v_intermediate=cfg.v_intermediate, v_fullatt=[0], image_token_id=cfg.image_token_id,
-                        vision_start_token_id=cfg.vision_start_token_id, tie_word_embeddings=cfg.tie_word_embeddings,
-                        mrope_section=cfg.mrope_section)
-        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        import tiny as tiny_shapes  # shape table only
-        shapes = tiny_shapes.param_shapes(dict(hidden_size=oc.hidden_size, intermediate_size=oc.intermediate_size, num_layers=n_lm,
-                                        num_heads=oc.num_heads, num_kv_heads=oc.num_kv_heads, vocab_size=oc.vocab_size, v_depth=n_vit,
-                                        v_hidden=oc.v_hidden, v_intermediate=oc.v_intermediate, v_in_channels=3, v_temporal_patch=2,
-                                        v_patch=14, v_merge=2, tie_word_embeddings=oc.tie_word_embeddings))
-        def init(shape):                                   # timing does not depend on the values: large tables get a cheap ramp
-            n = int(np.prod(shape))
-            if n < (1 << 24):
-                return torch.randn(shape) * 0.02
-            return (torch.arange(n, dtype=torch.float32).remainder_(997.0).mul_(4e-5).sub_(0.02)).view(shape)
-        p = {k: init(s).requires_grad_(grad) for k, s in shapes.items()}
-        ids = torch.from_numpy(np.concatenate([rs.randint(0, 1000, 200), [oc.vision_start_token_id], np.full(n_img, oc.image_token_id),
-                                               rs.randint(0, 1000, S - 201 - n_img)]))
-        pos = torch.arange(S)[None, :].repeat(3, 1)
-        px = torch.randn(n_patch, 1176)
-        rows = torch.arange(S - R_mean - 1, S - 1)
-        t0 = time.perf_counter()
-        with torch.set_grad_enabled(grad):
-            lg = Q.forward_logits(p, oc, ids, pos, [0, S], px, np.asarray([grid]), rows=rows)
-            lp = torch.log_softmax(lg, -1)[:, 0].sum()
-            if grad:
-                lp.backward()
-        return time.perf_counter() - t0
-
-    run(1, 1, False)                                        # warm-up: thread pool, allocator, first-touch of the big tables
-    f11, f21, f12 = (min(run(*d, False), run(*d, False)) for d in ((1, 1), (2, 1), (1, 2)))
-    b11, b21, b12 = run(1, 1, True), run(2, 1, True), run(1, 2, True)
-    # per-layer slopes are clamped at zero: the ViT layer (~0.1 s) sits inside the timing noise of the shared part
-    full = lambda a11, a21, a12: a11 + max(a21 - a11, 0.0) * (cfg.num_layers - 1) + max(a12 - a11, 0.0) * (cfg.v_depth - 1)
-    fwd, fb = full(f11, f21, f12), full(b11, b21, b12)
-    per_sample = 2 * fwd + fb
-    return {"value": 1.0 / per_sample, "unit": "samples/s (actor path: old+ref forward, update fwd/bwd; generation excluded)",
-            "cores": threads, "kind": "port",
-            "sample": f"1 sequence of {S} tokens ({n_patch} patches) through the fp32 torch oracle at depths (LM,ViT) = (1,1),(2,1),(1,2), "
-                      f"extrapolated linearly to ({cfg.num_layers},{cfg.v_depth}); measured fwd {fwd:.1f}s, fwd+bwd {fb:.1f}s per sample"}
+    opt = M.AdamWKahanBF16(scalar_mode="cpu")
+    pa, ga = rs.standard_normal(n_par).astype(np.float32) * 0.02, rs.standard_normal(n_par).astype(np.float32) * 1e-3
+    pa = opt.step(pa, ga)
+    t_adam = timed(lambda: opt.step(pa, ga))
+    n_params_3b = 3.75e9
+    # ---- assemble one GRPO step of config #1: 8 samples = 2 micro-batches of the timed size
+    fwd = n_prompt * (L_LM * t_layer_f + L_VIT * t_vit_f + t_head_f)                 # one no-grad pass over the 8 sequences
+    fb = n_prompt * (L_LM * t_layer_fb + L_VIT * t_vit_fb + t_head_fb)
+    prefill = fwd * (P_txt + n_img_tok) / S
+    gen_s = prefill + R * (L_LM * t_dec_layer + t_dec_head)
+    adam_s = t_adam * n_params_3b / n_par
+    step_s = gen_s + 2 * fwd + fb + adam_s
+    return {"value": n_prompt * G / step_s, "unit": "samples/s (full GRPO step: gen + old + ref + update + AdamW)", "cores": threads, "kind": "port",
+            "sample": "config #1 shape (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image -> 256 patches / 64 image tokens, 700 text tokens, "
+                      "512-token responses), fp32 torch oracle: ONE micro-batch of 4 sequences (5104 tokens) timed per component — 1 LM layer "
+                      "fwd / fwd+bwd, 1 ViT block, final norm + tied lm_head + log-softmax on 2048 response rows, 32 KV-cache decode steps of 1 "
+                      "layer for the 8 rollouts, AdamW-Kahan on 2M parameters — assembled as 36 layers + 32 blocks + head per pass (x2 prompts), "
+                      "512 decode steps, 3.75B parameters",
+            "timing_s": {"gen": gen_s, "old": fwd, "ref": fwd, "update_actor": fb, "adamw": adam_s},
+            "components_s": {"lm_layer_fwd": t_layer_f, "lm_layer_fwd_bwd": t_layer_fb, "lm_layer_fwd_bf16": t_layer_f_bf16, "vit_block_fwd": t_vit_f,
+                             "vit_block_fwd_bwd": t_vit_fb, "head_fwd": t_head_f, "head_fwd_bwd": t_head_fb, "decode_layer_step": t_dec_layer,
+                             "decode_head_step": t_dec_head, "adamw_2M_params": t_adam},
+            "bf16_over_fp32_layer_fwd_time": t_layer_f_bf16 / t_layer_f,
+            "value_excl_generation_and_adamw": n_prompt * G / (2 * fwd + fb)}
 
 
 # ------------------------------------------------------------------ main
@@ -215,6 +290,7 @@ def main():
     from spatialthinker_amd.model import ParamStore, VLConfig
     from spatialthinker_amd.rollout import Generator
     from verl.utils.reward_score import spatial_sgg_compute_score
+    from verl.workers.rollout import assemble_rollout_batch
 
     if a.model == "7b":
         cfg, name = VLConfig.qwen2_5_vl_7b(), "Qwen2.5-VL-7B"
@@ -268,15 +344,12 @@ def main():
                                           pad_token_id=pad_id, seed=a.seed * 1000 + step_idx, pixel_values=pix, image_grid_thw=grids,
                                           forced_lengths=lens, return_prompt_cache=True)
         t1 = tick()
-        # ---- assemble the (B, P+R) batch exactly as vllm_rollout_spmd.py:144-188 does
-        resp_c = resp.cpu()
-        rmask = (torch.cumsum((resp_c == eos_id).long(), 1) - (resp_c == eos_id).long() == 0).long()
-        ids_f = torch.cat([torch.from_numpy(ids).repeat_interleave(G, 0), resp_c], 1)
-        mask_f = torch.cat([torch.from_numpy(mask).repeat_interleave(G, 0), rmask], 1)
-        pos_p = torch.from_numpy(pos).repeat_interleave(G, 0)
-        pos_f = torch.cat([pos_p, pos_p[..., -1:] + torch.arange(1, R + 1)], -1)
+        # ---- the (B, P+R) batch of vllm_rollout_spmd.py:144-188, assembled by the worker's own post-processing
+        out = assemble_rollout_batch(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), resp.cpu(), G, eos_id)
+        rmask, mask_f = out["response_mask"], out["attention_mask"]
         mm = np.repeat(np.array([{"pixel_values": p, "image_grid_thw": g} for p, g in zip(pix, grids)], dtype=object), G)
-        data = dict(input_ids=ids_f, attention_mask=mask_f, position_ids=pos_f, responses=resp_c, multi_modal_inputs=mm)
+        data = dict(input_ids=out["input_ids"], attention_mask=mask_f, position_ids=out["position_ids"], responses=out["responses"],
+                    multi_modal_inputs=mm)
         # ---- reward: dense spatial scorer on templated strings (no tokenizer offline), score at the last valid token
         preds, gts, problems = synth_reward_strings(B, rs)
         scores = torch.tensor([spatial_sgg_compute_score(p, g, q)["overall"] for p, g, q in zip(preds, gts, problems)], dtype=torch.float32)
@@ -324,7 +397,23 @@ def main():
 
     for w in range(a.warmup):
         one_step(w, False)
-    ops.prof_enable(ops.K_GEMM, 400000)
+    # live per-class roofline: every PROF_STRIDE-th launch of each kernel class is bracketed by hipEvents on its launch stream over
+    # the WHOLE timed region (a prime stride, so the periodic per-layer launch sequence is sampled uniformly); the event budget is
+    # sized from the step count.  Launches replayed from the decode hipGraph cannot carry events: the decode loop is timed as a
+    # whole by the generator (roofline_decode).
+    PROF_STRIDE = 13
+    classes = {  # class id: (kernel names, bound, peak per second, unit scale, unit)
+        ops.K_GEMM: ("st_gemm_nt family: gemm_tile_kernel<256,256> / gemm_nt_kernel<128,128> (bf16 MFMA 16x16x32, LDS-DMA staged)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_ATTN_FWD: ("attn_fwd128_kernel<causal> (shared-prefix segments, MFMA 32x32x16)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_ATTN_BWD: ("attn_bwd128_dq/kv/reduce kernels", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_VIT_ATTN: ("attn_fwd/bwd kernels, head dim 80 (ViT windows + full attention)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_LOGPROB: ("logprob_fwd/bwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
+        ops.K_RMSNORM: ("rmsnorm_fwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
+        ops.K_ADAMW: ("adamw_kahan_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
+    }
+    for k in classes:
+        ops.prof_enable(k, max(4096, 6000 * a.steps if k == ops.K_GEMM else 1500 * a.steps), PROF_STRIDE if k != ops.K_ADAMW else 1)
+    gen.stats = {k: 0 for k in gen.stats}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -335,18 +424,52 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    n_launch, gemm_ms, gemm_flops = ops.prof_read(ops.K_GEMM)
-    ops.prof_disable(ops.K_GEMM)
+    prof = {}
+    for k in classes:
+        seen = ops.prof_seen(k)
+        n_launch, ms, units = ops.prof_read(k)
+        ops.prof_disable(k)
+        prof[k] = (seen, n_launch, ms, units)
+    phase_max = dict(phase)
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed] + [phase[k] for k in phase], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        phase_max = {k: float(t[1 + i].item()) for i, k in enumerate(phase)}
     if rank == 0:
         samples = B * world * a.steps
         actor_t = phase["old"] + phase["ref"] + phase["update_actor"]
+
+        def roof(k):
+            names, bound, peak, scale, unit = classes[k]
+            seen, n_launch, ms, units = prof[k]
+            ach = units / (ms * 1e-3) if ms > 0 else None
+            return {"bound": bound, "kernel": names, "achieved": ach / scale if ach else None, "peak": peak / scale, "unit": unit,
+                    "frac": ach / peak if ach else None, "launches_timed": n_launch, "launches_seen": seen,
+                    "avg_launch_ms": ms / max(n_launch, 1)}
+        main_roof = roof(ops.K_GEMM)
+        # HBM traffic of the dominant kernel from the committed PMC pass over this same workload (profiles/r02_gemm_traffic.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)
+        tp = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        main_roof["traffic"] = None
+        if os.path.exists(tp) and a.model == "7b":
+            tj = json.load(open(tp))
+            main_roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            main_roof["traffic_source"] = "profiles/r02_gemm_traffic.json"
+            main_roof["traffic_over_algorithmic_operand_bytes"] = tj.get("traffic_over_algorithmic")
+        st = gen.stats
+        dec = None
+        if st["decode_s"] > 0:
+            bw = st["decode_bytes"] / st["decode_s"]
+            dec = {"bound": "hbm", "kernel": "decode iteration (hipGraph replay: gemm_tile_kernel<M<=256> x4 + attn_fwd128_kernel<false> + merge + fused "
+                                             "finishes per layer, lm_head, sampler)", "achieved": bw / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                   "frac": bw / PEAK_HBM, "traffic": None, "iterations": st["decode_steps"], "ms_per_iteration": st["decode_s"] / st["decode_steps"] * 1e3,
+                   "mean_rows_per_iteration": st["decode_row_steps"] / st["decode_steps"],
+                   "algorithmic_bytes": "every LM weight once per iteration + K/V of the live context (prompt K/V once per prompt)"}
         out = {
             "metric": "GRPO samples/sec (G=8 rollouts/prompt) Qwen2.5-VL-7B at 1/2/4/8 MI355X",
-            "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights at real shapes; STVQA-7K-shaped prompts: 766 text + 336 image tokens from "
                                      "1344 random patches; response lengths ~ clip(N(512,128),64,cap) enforced by forcing EOS; templated reward strings)",
@@ -354,18 +477,18 @@ def main():
                                    f"{npr} prompts/GPU, micro-batch {micro}, {n_opt} optimizer steps/step, max_response_length {R}",
                        "global_batch": B * world, "seq_len": P + R, "parallelism": f"dp{world}"},
             "timing_s": {k: v / a.steps for k, v in phase.items()},
+            "timing_s_max_over_ranks": {k: v / a.steps for k, v in phase_max.items()},
             "perf_throughput_tokens_per_s_per_gpu": tokens_total[0] / elapsed,
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
             "actor_mfu": (flops["old"] + flops["ref"] + flops["update"]) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "actor_mfu_reference_flops": flops.get("reference_formulation", 0.0) / actor_t / PEAK_BF16 if actor_t > 0 else None,
-            "roofline": {"bound": "mfma", "kernel": "st_gemm_nt family: gemm_tile_kernel<256,256> / gemm_nt_kernel<128,128> (bf16 MFMA 16x16x32, LDS-DMA staged)", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
-                         "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": gemm_flops / (gemm_ms * 1e-3) / PEAK_BF16 if gemm_ms > 0 else None, "traffic": None,
-                         "launches": n_launch, "avg_launch_ms": gemm_ms / max(n_launch, 1)},
+            "roofline": main_roof,
+            "roofline_classes": [roof(k) for k in classes if k != ops.K_GEMM and prof[k][1] > 0],
+            "roofline_decode": dec,
         }
         if world == 1 and not a.no_cpu_baseline and not tiny:
-            out["cpu_baseline"] = cpu_baseline(cfg, 766, grid, 512)
+            out["cpu_baseline"] = cpu_baseline()
         elif tiny and not a.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))

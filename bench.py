@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15          # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_FP8 = 5.0e15           # dense MFMA fp8 (block-scaled K=128 instructions), same table
 PEAK_HBM = 8.0e12
 
 
@@ -44,6 +45,9 @@ def parse():
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8 = BASELINE config #5's arithmetic: the LM projection GEMMs of every forward pass on the MX-fp8 (OCP e4m3, block-"
+                         "scaled) MFMA path, everything else (attention, lm_head, ViT, backward, decode) bf16")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/contract check without a GPU: ranks rendezvous over gloo, time K trivial steps, rank 0 prints the JSON line")
     return ap.parse_args()
@@ -320,6 +324,9 @@ def main():
     ref = PolicyEngine(cfg, ref_store, None)
     if a.fuse_micro_batches is not None:
         actor.fuse_micro_batches = a.fuse_micro_batches
+    if a.dtype == "fp8":
+        actor.model.enable_fp8(True)
+        ref.model.enable_fp8(True)
     gen = Generator(actor.model)
     rs = np.random.RandomState(a.seed + rank)
     eos_id, pad_id = (1014, 1013) if tiny else (151645, 151643)
@@ -410,6 +417,7 @@ def main():
         ops.K_LOGPROB: ("logprob_fwd/bwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_RMSNORM: ("rmsnorm_fwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_ADAMW: ("adamw_kahan_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
+        ops.K_GEMM_FP8: ("gemm_mxfp8_kernel (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 + e8m0 block scales)", "mfma", PEAK_FP8, 1e12, "TFLOP/s"),
     }
     for k in classes:
         ops.prof_enable(k, max(4096, 6000 * a.steps if k == ops.K_GEMM else 1500 * a.steps), PROF_STRIDE if k != ops.K_ADAMW else 1)
@@ -471,7 +479,8 @@ def main():
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (random-init weights at real shapes; STVQA-7K-shaped prompts: 766 text + 336 image tokens from "
+            "dtype": "bf16" if a.dtype == "bf16" else "fp8 (MX e4m3 forward projection GEMMs; bf16 attention / lm_head / backward / decode)",
+            "data": "synthetic (random-init weights at real shapes; STVQA-7K-shaped prompts: 766 text + 336 image tokens from "
                                      "1344 random patches; response lengths ~ clip(N(512,128),64,cap) enforced by forcing EOS; templated reward strings)",
             "config": {"workload": f"{name} dense spatial-reward GRPO step (gen + reward + old/ref log-probs + advantage + update), G={G}, "
                                    f"{npr} prompts/GPU, micro-batch {micro}, {n_opt} optimizer steps/step, max_response_length {R}",

@@ -31,7 +31,7 @@ const char* st_arch(void);            /* "gfx950" */
  * hipEventRecord on the launch stream; st_prof_read() synchronises those events and returns
  * the number of launches and their summed duration in milliseconds. */
 enum { ST_K_GEMM = 0, ST_K_ATTN_FWD = 1, ST_K_ATTN_BWD = 2, ST_K_LOGPROB = 3, ST_K_ADAMW = 4,
-       ST_K_RMSNORM = 5, ST_K_VIT_ATTN = 6, ST_K_DECODE_ATTN = 7, ST_K_COUNT = 8 };
+       ST_K_RMSNORM = 5, ST_K_VIT_ATTN = 6, ST_K_DECODE_ATTN = 7, ST_K_GEMM_FP8 = 8, ST_K_COUNT = 9 };
 int st_prof_enable(int klass, int max_events);
 int st_prof_read(int klass, int* launches, double* total_ms, double* total_units);
 int st_prof_disable(int klass);
@@ -238,6 +238,20 @@ int st_decode_finish_qkv(const float* slabs, int splits, const st_bf16* bias, co
  * into kg/vg[b, gen_len[b], :width]; if increment, gen_len[b] += 1 afterwards. */
 int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width, st_bf16* kg, st_bf16* vg,
                  int64_t gen_stride, int32_t* gen_len, const int32_t* active, int B, int increment, st_stream_t stream);
+
+/* ---- block-scaled fp8 GEMM (BASELINE.json config #5: "fp8 MFMA"; the reference has no fp8 path — its GEMMs are torch/cuBLAS bf16
+ *      behind verl/workers/actor/dp_actor.py:118-124 — this is the MI355X-native fast path for the same Linear layers) -------------
+ * MX-fp8: OCP e4m3fn elements + one e8m0 (power-of-two) scale per 32 consecutive k.
+ * st_mxfp8_quantize: x (R, K) bf16 -> q (R, K) bytes and scales[K/128][scale_rows] dwords (byte j of scales[kt][r] = scale of
+ *   k-block 4*kt + j of row r; scale = 2^(byte - 127), shared exponent = floor(log2(max|x|)) - 8, elements RNE, saturating at 448).
+ *   K % 128 == 0, scale_rows >= R and a multiple of 4.
+ * st_gemm_mxfp8_nt: out[M,N] (bf16) = dequant(A)[M,K] dequant(B)[N,K]^T (+bias)(+residual), fp32 accumulation on
+ *   v_mfma_scale_f32_16x16x128_f8f6f4 (the only fp8 MFMA that runs at twice the bf16 rate on gfx950). */
+int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int K,
+                      st_stream_t stream);
+int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                     const uint32_t* SB, int64_t sb_rows, const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out,
+                     int64_t ldc, int M, int N, int K, st_stream_t stream);
 
 /* ---- optimizer: AnyPrecisionAdamW with bf16 states + Kahan compensation, one fused pass
  *      (verl/utils/torch_functional.py:253-329; ~10 eager passes in the reference) ---------------

@@ -6,7 +6,7 @@
 
 #define ST_WAVE 64
 
-#define ST_DECODE_MAX_ROWS 256   /* rows of a decode-shaped GEMM (sequences decoded together); the plans are tuned for <= 256 */
+#define ST_DECODE_MAX_ROWS 512   /* rows of a decode-shaped GEMM (sequences decoded together): one or two 256-row tiles */
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)

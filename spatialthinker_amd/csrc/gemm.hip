@@ -339,7 +339,7 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     // 128 flop/B of L2 traffic) wins or ties from ~0.5 workgroups per CU upwards (dW of the 3584x3584 projection, 196 tiles:
     // 1098 vs 926 TF); only smaller problems fill the chip better with 128x128 tiles at 2 workgroups/CU.
     if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 128)
-        return st_gemm_tile_dispatch(6, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);
+        return st_gemm_tile_dispatch(23, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);   // 6 + LDS-staged epilogue
 #define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
     if (out_bf16) {
         if (hb && hr) GO(true, true, true, false, false);

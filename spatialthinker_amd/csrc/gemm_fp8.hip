@@ -1,0 +1,219 @@
+// gemm_fp8.hip — block-scaled fp8 ("MX-fp8": OCP e4m3fn elements, one e8m0 power-of-two scale per 32 consecutive k) GEMM for
+// gfx950, BASELINE.json config #5 ("fp8 MFMA"):   C[M,N] (bf16) = dequant(Aq)[M,K] * dequant(Bq)[N,K]^T  (+bias)(+residual).
+//
+// Why the scaled form: on CDNA4 the plain fp8 MFMA (16x16x32 / 32x32x16) runs at the bf16 rate; only
+// v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 per instruction, hardware dequantisation by the per-lane e8m0 scale) reaches the
+// ~5 PF dense fp8 peak (MI355X_MICROARCH.md, MFMA table).  One lane of that instruction holds 32 consecutive k-bytes of one row
+// — exactly one MX block — and supplies that block's scale byte, so the operand layout is the natural one.
+//
+// Structure = the bf16 256x256 tile (gemm_tiles.hip) with k counted in BYTES: 8 waves (4 x 2, 64 x 128 per wave), K-tile = 128
+// fp8 = 128-byte operand rows, so the LDS image, its XOR swizzle (16-byte chunk ^ (row >> 1) & 7, applied on the LDS-DMA source
+// address and on the fragment read) and the 64 KiB/stage budget are unchanged while every byte carries twice the flops.  Two LDS
+// stages; the LDS-DMA of K-tile t+1 flies under the 32 MFMAs of tile t; one barrier per tile.
+// Scales travel beside the operands: stored K-tile-major, S[kt][row] = one dword holding the 4 block scales of that row inside
+// K-tile kt, so a tile's 256 row-dwords are ONE 1-KiB LDS-DMA instruction; a lane reads its row's dword and shifts its own block's
+// byte down (the instruction's op_sel picks a byte per INSTRUCTION, the block index is per lane group).
+// Roofline: MFMA-bound, 2*M*N*K flop per launch against the 5 PF dense fp8 peak.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__device__ __forceinline__ void glds16q(const void* gsrc, char* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------ quantiser
+// x (R, K) bf16 row-major -> q (R, K) e4m3 bytes + scales S[K/128][Rs] dwords (byte j of S[kt][r] = e8m0 scale of k-block 4*kt+j of
+// row r).  OCP MX rule: shared exponent = floor(log2(amax)) - 8 (e4m3's largest binade), elements = RNE(x * 2^-shared), saturated to
+// +-448.  One wave per (row, 512 k): lane = 8 consecutive k (16-byte load), 4 lanes = one block, 16 lanes = one K-tile.
+__global__ __launch_bounds__(256) void mxfp8_quantize_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                            int64_t ldq, uint32_t* __restrict__ scales, int64_t scale_rows, int R, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = K / 512 + ((K % 512) ? 1 : 0);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)R * chunks) return;
+    const int r = (int)(item / chunks), k0 = (int)(item % chunks) * 512 + lane * 8;
+    const bool live = k0 < K;                                 // K is a multiple of 128: a lane is all-in or all-out
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)r * ldx + k0), f);
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;  // biased exponent of the scale 2^(floor(log2 amax) - 8)
+    e = e < 0 ? 0 : (e > 254 ? 254 : e);                      // amax == 0 (or subnormal) -> smallest scale, all elements quantise to 0
+    const float inv = __uint_as_float((uint32_t)(254 - e) << 23);   // 2^-(e - 127), exact
+    uint32_t w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(f[4 * h + j] * inv, -448.f), 448.f);
+        int packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], packed, true);
+        w[h] = (uint32_t)packed;
+    }
+    if (live) *reinterpret_cast<uint2*>(q + (int64_t)r * ldq + k0) = make_uint2(w[0], w[1]);
+    // the 4 block scales of a K-tile sit in lanes 0, 4, 8, 12 of its 16-lane group
+    const int base = lane & 48;
+    const uint32_t s0 = (uint32_t)__shfl(e, base, 64), s1 = (uint32_t)__shfl(e, base + 4, 64);
+    const uint32_t s2 = (uint32_t)__shfl(e, base + 8, 64), s3 = (uint32_t)__shfl(e, base + 12, 64);
+    if (live && (lane & 15) == 0) scales[(int64_t)(k0 >> 7) * scale_rows + r] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+}
+
+// ------------------------------------------------------------------------------ GEMM
+#define Q_BM 256
+#define Q_BN 256
+#define Q_OP_BYTES (256 * 128)                  // one operand tile: 256 rows x 128 k-bytes
+#define Q_STAGE (2 * Q_OP_BYTES + 2048)         // A, B, A scales (1 KiB), B scales (1 KiB)
+
+template <bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(512) void gemm_mxfp8_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint32_t* __restrict__ SA,
+                                                        int64_t sa_rows, const uint8_t* __restrict__ B, int64_t ldb,
+                                                        const uint32_t* __restrict__ SB, int64_t sb_rows,
+                                                        const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
+                                                        uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int TM = 4, TN = 8;                 // 16x16 MFMA tiles per wave: 64 rows x 128 columns
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {                                             // XCD-aware bijective remap + groups of 8 tile rows (as gemm_tiles.hip)
+        const int xcd = bid & 7, idx = bid >> 3, qq = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int per_group = 8 * tiles_n, group = bid / per_group, in_g = bid % per_group;
+    const int first_m = group * 8, gsz = min(tiles_m - first_m, 8);
+    const int m0 = (first_m + in_g % gsz) * Q_BM, n0 = (in_g / gsz) * Q_BN;
+
+    auto stage = [&](int kt, char* dst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int inst = wave * 4 + j, p = inst * 64 + lane, r = p >> 3, kc = (p & 7) ^ ((r >> 1) & 7);
+            int ga = m0 + r; ga = ga < M ? ga : M - 1;
+            glds16q(A + (int64_t)ga * lda + (int64_t)kt * 128 + kc * 16, dst + inst * 1024);
+            int gb = n0 + r; gb = gb < N ? gb : N - 1;
+            glds16q(B + (int64_t)gb * ldb + (int64_t)kt * 128 + kc * 16, dst + Q_OP_BYTES + inst * 1024);
+        }
+        if (wave < 2) {                           // the 256 row-scales of the tile: one instruction per operand
+            const uint32_t* S = wave == 0 ? SA : SB;
+            const int64_t rows = wave == 0 ? sa_rows : sb_rows;
+            int r4 = (wave == 0 ? m0 : n0) + lane * 4;
+            r4 = r4 + 4 <= rows ? r4 : (int)rows - 4;
+            glds16q(S + (int64_t)kt * rows + r4, dst + 2 * Q_OP_BYTES + wave * 1024);
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / 128;
+    stage(0, smem);
+    const int frow = lane & 15, kb = lane >> 4;   // this lane's MX block inside the K-tile
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt has landed (this wave's pieces; the barrier publishes all)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * Q_STAGE);
+        const char* la = smem + (kt & 1) * Q_STAGE;
+        const char* lb = la + Q_OP_BYTES;
+        const uint32_t* sa = reinterpret_cast<const uint32_t*>(la + 2 * Q_OP_BYTES);
+        const uint32_t* sb = sa + 256;
+        i32x8 af[TM];
+        int sca[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ra = wm * 64 + i * 16 + frow, sw = (ra >> 1) & 7;
+            const int4 lo = *reinterpret_cast<const int4*>(la + ra * 128 + (((2 * kb) ^ sw) << 4));
+            const int4 hi = *reinterpret_cast<const int4*>(la + ra * 128 + (((2 * kb + 1) ^ sw) << 4));
+            af[i] = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            sca[i] = (int)((sa[ra] >> (8 * kb)) & 0xffu);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int rb = wn * 128 + ni * 16 + frow, sw = (rb >> 1) & 7;
+            const int4 lo = *reinterpret_cast<const int4*>(lb + rb * 128 + (((2 * kb) ^ sw) << 4));
+            const int4 hi = *reinterpret_cast<const int4*>(lb + rb * 128 + (((2 * kb + 1) ^ sw) << 4));
+            const i32x8 bf = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int scb = (int)((sb[rb] >> (8 * kb)) & 0xffu);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)   // swapped operands (D rows = n, columns = m): a lane ends up with 4 consecutive output columns
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf, af[mi], acc[ni][mi], 0, 0, 0, scb, 0, sca[mi]);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * 128 + ni * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r >= N) break;
+                if (HAS_BIAS) v[r] += bf2f(bias[n + r]);
+                if (HAS_RES) v[r] += bf2f(res[(int64_t)m * ldr + n + r]);
+            }
+            uint16_t* cp = C + (int64_t)m * ldc + n;
+            if (n + 3 < N && ((ldc & 3) == 0)) {
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+            }
+        }
+    }
+}
+
+extern "C" {
+
+int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int K,
+                      st_stream_t stream) {
+    if (!x || !q || !scales || R <= 0 || K <= 0 || (K % 128) || (ldx & 7) || (ldq & 7) || ldx < K || ldq < K || scale_rows < R ||
+        (scale_rows & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)q) & 7))
+        return ST_EINVAL;
+    const int chunks = (K + 511) / 512;
+    hipLaunchKernelGGL(mxfp8_quantize_kernel, dim3(st_cdiv((int64_t)R * chunks, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, q, ldq,
+                       scales, scale_rows, R, K);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                     const uint32_t* SB, int64_t sb_rows, const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out,
+                     int64_t ldc, int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || !SA || !SB || !out || M <= 0 || N <= 0 || K <= 0 || (K % 128) || (lda & 15) || (ldb & 15) || lda < K || ldb < K ||
+        ldc < N || sa_rows < M || sb_rows < N || (sa_rows & 3) || (sb_rows & 3) || sa_rows < 4 || sb_rows < 4 || (((uintptr_t)A) & 15) ||
+        (((uintptr_t)B) & 15) || (((uintptr_t)SA) & 15) || (((uintptr_t)SB) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_m = st_cdiv(M, Q_BM), tiles_n = st_cdiv(N, Q_BN);
+    constexpr int smem = 2 * Q_STAGE;
+    StProfScope ps(ST_K_GEMM_FP8, s, 2.0 * (double)M * (double)N * (double)K);
+#define QGO(HB, HR)                                                                                                              \
+    do {                                                                                                                         \
+        auto kern = gemm_mxfp8_kernel<HB, HR>;                                                                                   \
+        static bool configured = false;                                                                                          \
+        if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); configured = true; } \
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), smem, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows, bias, residual, ldr,  \
+                           out, ldc, M, N, K, tiles_m, tiles_n);                                                                 \
+    } while (0)
+    if (bias && residual) QGO(true, true); else if (bias) QGO(true, false); else if (residual) QGO(false, true); else QGO(false, false);
+#undef QGO
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

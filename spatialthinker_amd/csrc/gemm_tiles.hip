@@ -66,8 +66,14 @@ struct TailArgs {
 // SW8 (with SWIGLU): gate and up are interleaved at 8-column granularity INSIDE every 16-column MFMA tile (cols 0-7 gate j..j+7,
 // cols 8-15 up j..j+7), so any WTN that is a multiple of 16 works (e.g. 80 = a 256x160 tile, 237 workgroups for the 7B MLP); the
 // up values sit 32 lanes above their gate values and come down with one v_permlane32_swap per accumulator register.
+// LEPI (256x256, 8 waves): LDS-staged epilogue.  The MFMA fragment layout gives a lane 4 consecutive columns of 16 different rows
+// per instruction, so the direct epilogue moves C, the residual and the fp32 accumulate target as 8..16-byte pieces of 16 rows (32-byte
+// segments: a residual + bias epilogue costs 41 us per round of 256 tiles, more than a third of a K = 3584 main loop).  Here the
+// accumulators go through the (now idle) operand LDS in two 256 x 128-column passes of fp32 rows padded to 528 bytes (conflict-free
+// for the 8-lane groups of ds_write_b128), and every lane then handles 8 consecutive columns of ONE row: bias / residual / C move as
+// 16-byte (fp32 target: 32-byte) row-contiguous vectors, 512 contiguous bytes per row and instruction.
 template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false,
-          bool MIDBAR = false, bool SW8 = false>
+          bool MIDBAR = false, bool SW8 = false, bool LEPI = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     static_assert(EVEN_DMA || !MIDBAR, "mid-tile barrier prologue counts DMA instructions");
     static_assert(!SWIGLU || ((SW8 || WTN % 32 == 0) && OUT_BF16 && !HAS_BIAS && !HAS_RES), "SwiGLU epilogue pairs 16-column MFMA tiles");
     static_assert(!SW8 || SWIGLU, "SW8 is a flavour of the SwiGLU epilogue");
+    static_assert(!LEPI || (BM == 256 && BN == 256 && NW == 8 && !SWIGLU), "LDS-staged epilogue: 256x256 tile, 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -409,6 +416,68 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             }
         }
     }
+    if constexpr (LEPI) {
+        if (tail.mode != 2) {                                // whole tiles; the finish launch of split tail tiles has no LDS: direct path
+            constexpr int ROWB = 128 * 4 + 16;               // fp32 row of one pass + 16 bytes: rows 4 banks apart
+            __syncthreads();                                 // every wave is done reading the operand slots; no DMA is in flight
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int nl = 0; nl < TN / 2; ++nl)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int row = wm * WTM + mi * 16 + (lane & 15), col = wn * (WTN / 2) + nl * 16 + (lane >> 4) * 4;
+                        *reinterpret_cast<f32x4*>(smem + row * ROWB + col * 4) = acc[p * (TN / 2) + nl][mi];
+                    }
+                __syncthreads();
+                const int t = threadIdx.x, c8 = (t & 15) * 8;
+                const int n = n0 + (c8 >> 6) * WTN + p * (WTN / 2) + (c8 & 63);
+                float bvals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const bool ncols = n + 7 < N;
+                if constexpr (HAS_BIAS) {
+                    if (ncols && (reinterpret_cast<uintptr_t>(bias + n) & 15) == 0) unpack8(*reinterpret_cast<const uint4*>(bias + n), bvals);
+                    else for (int r = 0; r < 8; ++r) bvals[r] = n + r < N ? bf2f(bias[n + r]) : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 32 + (t >> 4), m = m0 + row;
+                    if (m >= M || n >= N) continue;
+                    float v[8];
+                    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
+                    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
+                    if constexpr (HAS_BIAS) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += bvals[r];
+                    }
+                    if constexpr (HAS_RES) {
+                        const uint16_t* rp = res + (int64_t)m * ldr + n;
+                        float rr[8];
+                        if (ncols && (reinterpret_cast<uintptr_t>(rp) & 15) == 0) unpack8(*reinterpret_cast<const uint4*>(rp), rr);
+                        else for (int r = 0; r < 8; ++r) rr[r] = n + r < N ? bf2f(rp[r]) : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += rr[r];
+                    }
+                    if constexpr (OUT_BF16) {
+                        uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                        if (ncols && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) *reinterpret_cast<uint4*>(cp) = pack8(v);
+                        else for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+                    } else {
+                        float* cp = Cf + (int64_t)m * ldc + n;
+                        if (ncols && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) {
+                            float4 o0 = ACCUM ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            float4 o1 = ACCUM ? *reinterpret_cast<float4*>(cp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            o0.x += v[0]; o0.y += v[1]; o0.z += v[2]; o0.w += v[3]; o1.x += v[4]; o1.y += v[5]; o1.z += v[6]; o1.w += v[7];
+                            *reinterpret_cast<float4*>(cp) = o0; *reinterpret_cast<float4*>(cp + 4) = o1;
+                        } else {
+                            for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = (ACCUM ? cp[r] : 0.f) + v[r];
+                        }
+                    }
+                }
+                if (p == 0) __syncthreads();                 // the second pass overwrites the image
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + wm * WTM + mi * 16 + (lane & 15);
@@ -575,12 +644,12 @@ static int st_num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false, bool LE = false>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
                        int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s, int splits = 1,
                        int64_t slab_stride = 0) {
-    constexpr int smem = STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB>;
+    constexpr int smem = LE ? (STAGES * (BM + BN) * 128 > 256 * 528 ? STAGES * (BM + BN) * 128 : 256 * 528) : STAGES * (BM + BN) * 128;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB, false, LE>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -622,16 +691,17 @@ static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
 int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
                           const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K,
                           hipStream_t s) {
-#define TILE_GO(BM, BN, WM, WN, ST, MB)                                                                                          \
+#define TILE_GO(BM, BN, WM, WN, ST, MB) TILE_GO_LE(BM, BN, WM, WN, ST, MB, false)
+#define TILE_GO_LE(BM, BN, WM, WN, ST, MB, LE)                                                                                   \
     do {                                                                                                                         \
         if (Cb) {                                                                                                                \
-            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
-            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
-            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
-            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
+            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
+            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
+            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
+            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
         }                                                                                                                        \
-        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
-        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
+        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
+        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
     } while (0)
     switch (variant) {
         case 0: TILE_GO(128, 128, 2, 2, 2, false);
@@ -644,9 +714,11 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
         case 7: TILE_GO(128, 128, 2, 2, 2, true);
         case 8: TILE_GO(256, 256, 2, 2, 2, true);          // 4 waves x (128 x 128): one wave per SIMD, accumulators fill the AGPRs
         case 9: TILE_GO(256, 256, 2, 2, 2, false);
+        case 23: TILE_GO_LE(256, 256, 4, 2, 2, true, true);   // variant 6 with the LDS-staged epilogue
         default: return ST_EINVAL;
     }
 #undef TILE_GO
+#undef TILE_GO_LE
 }
 
 // Decode-shaped launches (M <= 256 rows, weight streaming): small-M tiles with a 3-slot ring and optional split-K into fp32

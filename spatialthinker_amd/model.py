@@ -187,6 +187,7 @@ class ParamStore:
         self.grad = self.g = None
         self.m = self.v = self.c = None
         self.wT: Dict[str, torch.Tensor] = {}
+        self.wq = None                   # MX-fp8 copies of the LM projection weights (refresh_fp8), only in fp8 mode
         if trainable:
             self.grad = torch.zeros(off, dtype=F32, device=device)
             self.g = {n: self._view(self.grad, n) for n in self.layout}
@@ -205,6 +206,16 @@ class ParamStore:
     def refresh_transposes(self):
         for n, t in self.wT.items():
             ops.transpose(self.w[n], out=t)
+        if getattr(self, "wq", None):
+            self.refresh_fp8()
+
+    def refresh_fp8(self):
+        """MX-fp8 copies (e4m3 bytes + e8m0 block scales) of the LM projection weights for the fp8 forward GEMMs (Qwen25VL.fp8);
+        re-quantised from the bf16 master weights after every optimizer step.  ~0.53 bytes per parameter on top of the bf16 store."""
+        self.wq = {}
+        for i in range(self.cfg.num_layers):
+            for nm in ("qkv_w", "o_w", "gu_w", "down_w"):
+                self.wq[f"l.{i}.{nm}"] = ops.mxfp8_quantize(self.w[f"l.{i}.{nm}"])
 
     # ---- HF state_dict interop (names of transformers Qwen2_5_VLForConditionalGeneration) -------------
     def load_hf_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -339,6 +350,27 @@ class Qwen25VL:
         self.scale = D ** -0.5
         self.v_scale = cfg.v_head_dim ** -0.5
         self.recompute_light = False     # see _lm_layer_fwd
+        self.fp8 = False                 # config #5: the LM's four projection GEMMs run forward in MX-fp8 (enable_fp8)
+
+    def enable_fp8(self, on: bool = True):
+        """Forward GEMMs of the LM layers (qkv, o, gate/up, down — 93 % of the forward FLOPs) on the block-scaled fp8 MFMA path:
+        activations are quantised on the fly (one HBM pass each), weights once per optimizer step.  Attention, norms, the lm_head,
+        the ViT and the whole backward stay bf16 (straight-through: gradients are those of the bf16 layer evaluated at the fp8
+        forward's activations).  Tolerance: DESIGN.md §4 (fp8)."""
+        self.fp8 = bool(on)
+        if on and not getattr(self.p, "wq", None):
+            self.p.refresh_fp8()
+        if not on:
+            self.p.wq = None
+
+    def _linear(self, x, name, bias=None, residual=None):
+        """y = x W^T (+bias)(+residual) for an LM projection: bf16 MFMA GEMM, or MX-fp8 when enabled and the shape fits its tile."""
+        w = self.p.w[name]
+        if self.fp8 and x.shape[0] > 256 and x.shape[1] % 128 == 0:
+            xq, xs = ops.mxfp8_quantize(x)
+            wq, ws = self.p.wq[name]
+            return ops.gemm_mxfp8_nt(xq, xs, wq, ws, bias=bias, residual=residual)
+        return ops.gemm_nt(x, w, bias=bias, residual=residual)
 
     # ---------------------------------------------------------------- batch staging
     def stage(self, input_ids, attention_mask, position_ids, response_length: int, pixel_values=None, image_grid_thw=None,
@@ -492,7 +524,7 @@ class Qwen25VL:
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
         h1, r1 = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps)
-        qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+        qkv = self._linear(h1, p + "qkv_w", bias=w[p + "qkv_b"])
         ops.rope_apply_(qkv, b.cos, b.sin, nq + nkv, D)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         if kv_out is not None:
@@ -501,10 +533,16 @@ class Qwen25VL:
         kpre, vpre = prefix_kv if prefix_kv is not None else (None, None)     # prompt K/V cached by the rollout prefill
         _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a,
                                   k_pre=kpre, v_pre=vpre, pairs=b.pairs)
-        x1 = ops.gemm_nt(a, w[p + "o_w"], residual=x0)
+        x1 = self._linear(a, p + "o_w", residual=x0)
         h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
-        gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)      # SwiGLU in the epilogue; gate|up kept only for backward
-        x2 = ops.gemm_nt(m, w[p + "down_w"], residual=x1)
+        if self.fp8 and h2.shape[0] > 256:
+            gu = self._linear(h2, p + "gu_w")
+            m = ops.swiglu_fwd(gu)
+            if save is None:
+                gu = None
+        else:
+            gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)  # SwiGLU in the epilogue; gate|up kept only for backward
+        x2 = self._linear(m, p + "down_w", residual=x1)
         if save is not None:
             # h1, h2 (RMSNorm outputs) and m (SwiGLU output) are cheap row-wise functions of tensors that are kept anyway: with
             # recompute_light the backward recomputes them (bit-identical kernels) instead of holding 1/3 of the activation

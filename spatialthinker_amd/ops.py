@@ -14,7 +14,7 @@ from .lib import lib
 
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 KL_KINDS = {"kl": 0, "abs": 1, "mse": 2, "low_var_kl": 3, "chi2": 4}
-K_GEMM, K_ATTN_FWD, K_ATTN_BWD, K_LOGPROB, K_ADAMW, K_RMSNORM, K_VIT_ATTN, K_DECODE_ATTN = range(8)
+K_GEMM, K_ATTN_FWD, K_ATTN_BWD, K_LOGPROB, K_ADAMW, K_RMSNORM, K_VIT_ATTN, K_DECODE_ATTN, K_GEMM_FP8 = range(9)
 
 
 def _s() -> int:
@@ -140,7 +140,8 @@ def gelu_bwd(x, dy):
 
 
 # ------------------------------------------------------------------ GEMM
-_SCRATCH_ELEMS = 16 * 256 * 4608
+DECODE_MAX_ROWS = 512           # ST_DECODE_MAX_ROWS of the library
+_SCRATCH_ELEMS = 16 * DECODE_MAX_ROWS * 4608
 _scratch = {}
 
 
@@ -152,6 +153,7 @@ def _skinny_scratch(device):
     return _scratch[key]
 
 
+_wide_decode = [False]            # set by the generator while it decodes more than 256 rows at once (257..512-row GEMMs use the decode plans)
 # (M, N, K) -> (tile variant, split-K count) chosen by autotune_decode_gemm; empty = library defaults everywhere
 _decode_plans = {}
 _DECODE_CANDIDATES = {64: (10, 11, 12, 21), 128: (13, 14, 19, 20), 256: (13, 14, 16, 18)}
@@ -165,7 +167,7 @@ def autotune_decode_gemm(M: int, weights, reps: int = 2):
     weights = [weights] if torch.is_tensor(weights) else list(weights)
     N, K = weights[0].shape
     key = (M, N, K)
-    if key in _decode_plans or M > 256:
+    if key in _decode_plans or M > DECODE_MAX_ROWS:
         return _decode_plans.get(key)
     dev = weights[0].device
     if len(weights) * N * K * 2 < (1 << 30):                 # too small a footprint to defeat the cache: keep the defaults
@@ -245,7 +247,7 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
     assert b.shape[1] == K, (a.shape, b.shape)
     if out_f32 is None and out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
-    if out_f32 is None and M <= 256:                         # decode-shaped: weight-streaming tiles (+ split-K slabs)
+    if out_f32 is None and (M <= 256 or (_wide_decode[0] and M <= DECODE_MAX_ROWS)):   # decode-shaped: weight-streaming tiles (+ split-K slabs)
         scratch = _skinny_scratch(a.device)
         plan = _decode_plans.get((M, N, K))
         ldr = residual.stride(0) if residual is not None else 0
@@ -305,6 +307,29 @@ def gemm_swiglu(a, gate_up_w, want_gu=True):
     lib().st_gemm_swiglu(_p(a), a.stride(0), _p(gate_up_w), gate_up_w.stride(0), _p(gu), gu.stride(0) if gu is not None else 0,
                          _p(m), m.stride(0), M, I, K, _s())
     return gu, m
+
+
+# ------------------------------------------------------------------ block-scaled fp8 (MX-fp8) GEMM
+def mxfp8_quantize(x):
+    """x (R, K) bf16 -> (q (R, K) uint8 e4m3 bytes, scales (K/128, R_pad4) int32: 4 e8m0 bytes per row and K-tile)."""
+    _chk(x, BF16, "x")
+    R, K = x.shape
+    q = torch.empty(R, K, dtype=torch.uint8, device=x.device)
+    rows = (R + 3) // 4 * 4
+    sc = torch.zeros(K // 128, rows, dtype=torch.int32, device=x.device)
+    lib().st_mxfp8_quantize(_p(x), x.stride(0), _p(q), q.stride(0), _p(sc), rows, R, K, _s())
+    return q, sc
+
+
+def gemm_mxfp8_nt(aq, sa, bq, sb, *, bias=None, residual=None, out=None):
+    """out[M,N] bf16 = dequant(aq, sa) @ dequant(bq, sb)^T (+bias)(+residual); operands from mxfp8_quantize."""
+    M, K = aq.shape
+    N = bq.shape[0]
+    assert bq.shape[1] == K and sa.shape[0] == K // 128 and sb.shape[0] == K // 128
+    out = torch.empty(M, N, dtype=BF16, device=aq.device) if out is None else out
+    lib().st_gemm_mxfp8_nt(_p(aq), aq.stride(0), _p(sa), sa.shape[1], _p(bq), bq.stride(0), _p(sb), sb.shape[1], _p(bias), _p(residual),
+                           residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, N, K, _s())
+    return out
 
 
 def gemm_nt_variant(variant, a, b, out=None, out_f32=None, accumulate=False, bias=None, residual=None):
@@ -475,7 +500,7 @@ def add_(a, b, out=None):
 
 
 # ------------------------------------------------------------------ profiling hooks
-_prof_on = [False] * 8
+_prof_on = [False] * 9
 
 
 def prof_enable(klass: int, max_events: int = 200000, stride: int = 1):

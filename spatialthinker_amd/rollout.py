@@ -27,7 +27,7 @@ from .model import BF16, F32, I32, I64, Qwen25VL
 class Generator:
     def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False, fused_decode: bool = True):
         self.m = model
-        self.max_decode_batch = 256       # sequences decoded together (rows of the decode GEMMs)
+        self.max_decode_batch = int(os.environ.get("ST_MAX_DECODE", "256"))   # sequences decoded together (rows of the decode GEMMs), <= 512
         self.compact = True               # restart the decode graph on the survivors once half of a phase's rows have finished
         self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
@@ -121,7 +121,7 @@ class Generator:
         w_bytes = 2.0 * (sum(w[f"l.{i}.{nm}"].numel() for i in range(L) for nm in ("qkv_w", "o_w", "gu_w", "down_w")) + head.numel())
         can_fuse = self.fused_decode and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
         wave = max(1, self.max_decode_batch)
-        if self.autotune and wave <= 256:
+        if self.autotune and wave <= ops.DECODE_MAX_ROWS:
             self._tune_decode(ix.round_up(min(B, wave), 32))
 
         def decode_phase(S_np: np.ndarray, until_half: bool):
@@ -130,7 +130,7 @@ class Generator:
             caller re-batches the survivors, possibly together with those of other waves).  Returns the surviving ids."""
             Ba = len(S_np)
             Bp = ix.round_up(Ba, 32) if Ba <= 256 else ix.round_up(Ba, 128)
-            fused = can_fuse and Bp <= 256
+            fused = can_fuse and Bp <= ops.DECODE_MAX_ROWS
             S_t = ti(S_np)
             S_l = S_t.long()
             rows_all = Ba * g
@@ -169,7 +169,7 @@ class Generator:
             xbuf = torch.zeros(Bp, c.hidden_size, dtype=BF16, device=dev)
             abuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # attention output, pad rows stay zero
             qbuf = torch.zeros(Bp, nq * D, dtype=BF16, device=dev)          # roped queries of the fused path (pad rows stay zero)
-            logits = torch.empty(Bp if Bp <= 256 else Ba, c.vocab_size, dtype=BF16, device=dev)
+            logits = torch.empty(Bp if Bp <= ops.DECODE_MAX_ROWS else Ba, c.vocab_size, dtype=BF16, device=dev)
             logits[:Ba].copy_(logits_g[S_l])
             tok32 = torch.zeros(Ba, dtype=I32, device=dev)
             pad_t = torch.full((Ba,), pad_token_id, dtype=I64, device=dev)
@@ -285,7 +285,8 @@ class Generator:
         # survivors of all waves are then decoded TOGETHER (they sit at different response indices: every row carries its own
         # step), re-batched again each time half of them are done — one short tail for the whole rollout batch instead of one
         # per wave.  (The unfused path has no sample-indexed cache append: its waves simply run to completion.)
-        compact = self.compact and can_fuse and wave <= 256
+        compact = self.compact and can_fuse and wave <= ops.DECODE_MAX_ROWS
+        ops._wide_decode[0] = wave > 256
         debug = bool(os.environ.get("ST_GEN_DEBUG"))
         pool = np.zeros(0, dtype=np.int64)
 

@@ -1,0 +1,117 @@
+"""MX-fp8 path (BASELINE config #5): quantiser bit-exact against the numpy oracle of the OCP MX rule; block-scaled
+GEMM against the fp32 product of the de-quantised operands (the products of two e4m3 values and a power-of-two scale are exact in
+fp32, so only the fp32 accumulation order and the final bf16 rounding differ: tolerance 2^-7 of the output scale); and the
+quantisation error itself against the bf16 GEMM, which is the number DESIGN.md quotes for the fp8 tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mxfp8 as MX  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spatialthinker_amd import ops as o
+    return o
+
+
+def _bf(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16()
+
+
+@pytest.mark.parametrize("shape", [(5, 128), (300, 1024), (64, 3584)])
+def test_quantiser_bit_exact_vs_oracle(ops, shape):
+    R, K = shape
+    rs = np.random.RandomState(R + K)
+    x = rs.standard_normal((R, K)).astype(np.float32) * np.exp(rs.uniform(-8, 6, (R, 1))).astype(np.float32)
+    x[0, :32] = 0.0                                   # an all-zero block
+    x[1 % R, 5] = 3.0e4                               # an outlier that dominates its block
+    x[2 % R, 40:44] = [448.0, -448.0, 447.0, 1e-30]
+    xb = _bf(x)
+    q, sc = ops.mxfp8_quantize(xb.cuda())
+    qo, sbo = MX.quantize(xb.float().numpy())
+    assert np.array_equal(q.cpu().numpy(), qo)
+    want_sc = MX.pack_scales(sbo, sc.shape[1])
+    assert np.array_equal(sc.cpu().numpy().view(np.uint32)[:, :R], want_sc[:, :R])
+    # round trip error of the format relative to the block maximum: half a step of the top binade (2^-4) for values below 448 * scale,
+    # up to 2^-3 where a block maximum in (448, 512) * scale saturates (the OCP MX rule clamps, it does not widen the scale)
+    dq = MX.dequantize(qo, sbo)
+    blk = np.abs(xb.float().numpy()).reshape(R, K // 32, 32).max(-1, keepdims=True)
+    err = np.abs(dq - xb.float().numpy()).reshape(R, K // 32, 32)
+    assert float((err / np.maximum(blk, 1e-30)).max()) <= 2.0 ** -3 + 1e-6
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 520, 384), (1000, 3584, 1024), (4096, 4608, 3584)])
+def test_gemm_vs_fp32_product_of_dequantised_operands(ops, shape):
+    M, N, K = shape
+    rs = np.random.RandomState(M + N + K)
+    a = _bf(rs.standard_normal((M, K))).cuda()
+    b = _bf(rs.standard_normal((N, K)) * (1 + np.arange(N)[:, None] / N)).cuda()       # asymmetric: catches a transposed C
+    aq, sa = ops.mxfp8_quantize(a)
+    bq, sb = ops.mxfp8_quantize(b)
+    qa, sba = MX.quantize(a.float().cpu().numpy())
+    qb, sbb = MX.quantize(b.float().cpu().numpy())
+    want = torch.from_numpy(MX.dequantize(qa, sba)).cuda() @ torch.from_numpy(MX.dequantize(qb, sbb)).cuda().t()
+    scale = float(want.abs().max())
+    out = ops.gemm_mxfp8_nt(aq, sa, bq, sb)
+    assert float((out.float() - want).abs().max()) < scale * 2 ** -7
+    bias, res = _bf(rs.standard_normal(N)).cuda(), _bf(rs.standard_normal((M, N))).cuda()
+    out2 = ops.gemm_mxfp8_nt(aq, sa, bq, sb, bias=bias, residual=res)
+    assert float((out2.float() - (want + bias.float() + res.float())).abs().max()) < scale * 2 ** -6
+    # quantisation error against the bf16 GEMM of the original operands (reported in DESIGN.md): a few percent of the output RMS
+    ref = a.float() @ b.float().t()
+    rel = float((out.float() - ref).norm() / ref.norm())
+    print(f"MX-fp8 GEMM {M}x{N}x{K}: relative L2 error vs the bf16-operand product = {rel:.4f}")
+    assert rel < 0.05
+
+
+def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
+    """Qwen25VL.enable_fp8 at the real 7B layer widths (1 LM layer + 2 ViT blocks, shared-prompt group of 3 rollouts): response
+    log-probs with the four LM projections on the MX-fp8 path vs the bf16 engine and vs the fp32 oracle, and the straight-through
+    backward.  Stated fp8 tolerance: max |dlogp| <= 4x the bf16 engine's own error against the oracle, gradient
+    relative error <= 3x."""
+    import test_gpu_fullsize as F
+    from oracle import qwen25vl as Q
+    from oracle import rl_math as RM
+    from spatialthinker_amd import model as mdl
+    rs = np.random.RandomState(17)
+    params = F._params()
+    cfg = mdl.VLConfig(**F.FULL)
+    store = mdl.ParamStore(cfg, trainable=True)
+    store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = mdl.Qwen25VL(cfg, store)
+    ids, mask, pos, px, g, R = F._group_batch(rs)
+    k = ids.shape[0]
+    rmask = mask[:, -R:]
+    m = rmask.astype(bool)
+    p32 = {n_: torch.from_numpy(v).clone().requires_grad_(n_.endswith(("q_proj.weight", "gate_proj.weight"))) for n_, v in params.items()}
+    lp = Q.response_log_probs(p32, Q.VLConfig(**F.FULL), torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), R, 1.0,
+                              torch.from_numpy(np.concatenate([px] * k, 0)), np.concatenate([g] * k, 0))
+    old = (lp.detach().numpy() + 0.2 * rs.standard_normal((k, R))).astype(np.float32)
+    adv = rs.standard_normal((k, 1)).astype(np.float32).repeat(R, 1) * rmask
+    _, gl = RM.actor_micro_batch_loss(lp.detach().numpy(), old, old, adv, rmask, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1)
+    lp.backward(torch.from_numpy(gl))
+    b = eng.stage(ids, mask, pos, R, px, g, groups=[0] * k)
+    assert b.pk.T_pad > 256                                    # the fp8 tile path is taken
+    dv = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    li = dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64))
+    kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
+    res = {}
+    for mode in ("bf16", "fp8"):
+        eng.enable_fp8(mode == "fp8")
+        store.grad.zero_()
+        lp_e, _ = eng.forward_backward(b, li, 1.0, **kw)
+        grads = store.export_hf(store.g)
+        err = float(np.abs(lp_e.cpu().numpy()[m] - lp.detach().numpy()[m]).max())
+        rel = {n_: float(np.linalg.norm(grads[n_].float().cpu().numpy() - t.grad.numpy()) / np.linalg.norm(t.grad.numpy()))
+               for n_, t in p32.items() if t.grad is not None}
+        res[mode] = (err, rel, lp_e.clone())
+        print(f"{mode}: max|dlogp| vs fp32 oracle {err:.4f}; grad rel err {rel}")
+    eng.enable_fp8(False)
+    assert store.wq is None
+    assert not torch.equal(res["fp8"][2], res["bf16"][2])      # the fp8 path really ran
+    assert res["fp8"][0] <= 4 * res["bf16"][0]
+    for n_ in res["bf16"][1]:
+        assert res["fp8"][1][n_] <= 3 * res["bf16"][1][n_] + 0.02, n_

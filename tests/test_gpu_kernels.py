@@ -283,7 +283,7 @@ def test_gemm_nt(ops, M_, N, K):
     assert np.abs(acc.cpu().numpy() - want.numpy()).max() < scale * 1e-5 + 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 23])
 @pytest.mark.parametrize("K", [64, 128, 192, 320])
 def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
     """Every tile/pipeline variant (2- and 3-slot rings, the mid-tile-barrier schedule) at 1, 2, 3 and 5 K-tiles — the
@@ -301,7 +301,7 @@ def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
     assert float((acc - want - 0.25).abs().max()) < scale * 1e-5 + 1e-4
 
 
-@pytest.mark.parametrize("variant", [6, 8])
+@pytest.mark.parametrize("variant", [6, 8, 23])
 @pytest.mark.parametrize("shape", [(4200, 4096, 4096), (3000, 5700, 3200), (70000, 300, 4096)])
 def test_gemm_tail_split_matches_unsplit(ops, variant, shape):
     """st_gemm_set_workspace: the tiles beyond whole rounds of the CUs are cut into K-slices (fp32 partials + a finish launch
@@ -334,6 +334,30 @@ def test_gemm_tail_split_matches_unsplit(ops, variant, shape):
         assert float((f - want - 0.5).abs().max()) < scale * 1e-5 + 1e-3, on
     assert float((outs[True][2] - outs[False][2]).abs().max()) < scale * 1e-5 + 1e-3
     assert not torch.equal(outs[True][2], outs[False][2])     # the split really ran (different fp32 summation order somewhere)
+
+
+@pytest.mark.parametrize("shape", [(300, 520, 192), (1000, 777 * 8, 256), (513, 1016, 128)])
+def test_gemm_lds_staged_epilogue_is_bit_identical_to_direct(ops, shape):
+    """Variant 23 = variant 6 with the LDS-staged epilogue (accumulators -> LDS -> row-contiguous 16-byte vectors): same MFMA
+    order, same fp32 epilogue arithmetic, so every output kind must equal variant 6 bit for bit — ragged M, N not a multiple of the
+    tile, and column counts that leave partial 8-column vectors at the edge."""
+    M_, N, K = shape
+    rs = np.random.RandomState(M_ + N)
+    a = bf(rs.standard_normal((M_, K))).cuda()
+    b = bf(rs.standard_normal((N, K)) * (1 + np.arange(N)[:, None] / N)).cuda()
+    bias, res = bf(rs.standard_normal(N)).cuda(), bf(rs.standard_normal((M_, N))).cuda()
+    for kw in ({}, {"bias": bias}, {"residual": res}, {"bias": bias, "residual": res}):
+        assert torch.equal(ops.gemm_nt_variant(23, a, b, **kw), ops.gemm_nt_variant(6, a, b, **kw)), list(kw)
+    for accumulate in (True, False):
+        f6 = torch.full((M_, N), 0.25, dtype=torch.float32, device="cuda"); f23 = f6.clone()
+        ops.gemm_nt_variant(6, a, b, out_f32=f6, accumulate=accumulate)
+        ops.gemm_nt_variant(23, a, b, out_f32=f23, accumulate=accumulate)
+        assert torch.equal(f6, f23), accumulate
+    # a strided output / residual view (row pitch > N), as the engine's qkv and gate|up buffers have
+    big = torch.zeros(M_, N + 64, dtype=torch.bfloat16, device="cuda")
+    resb = torch.zeros(M_, N + 64, dtype=torch.bfloat16, device="cuda"); resb[:, 8:N + 8] = res
+    ops.gemm_nt_variant(23, a, b, out=big[:, 8:N + 8], residual=resb[:, 8:N + 8])
+    assert torch.equal(big[:, 8:N + 8], ops.gemm_nt_variant(6, a, b, residual=res)) and float(big[:, :8].abs().max()) == 0
 
 
 def test_gemm_identity_layout(ops):

@@ -121,6 +121,16 @@ int st_gelu_bwd(const st_bf16* x, const st_bf16* dy, st_bf16* dx, int64_t n, st_
 int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
                int accumulate, int M, int N, int K, st_stream_t stream);
+/* Backward-pass operand layouts of the same GEMM tile (no transposed copies in HBM; the fragments of a contraction-major operand
+ * come from hardware transpose reads of the LDS image):
+ *   st_gemm_nn: out[M,N] = A[M,K] B[K,N]          — dX = dY W with W as stored (out_features x in_features): torch's dgrad GEMM behind
+ *               the reference's loss.backward() (verl/workers/actor/dp_actor.py:277);
+ *   st_gemm_tn: out_f32[M,N] (+)= A[K,M]^T B[K,N] — dW = dY^T X, accumulating into the flat fp32 gradient buffer (wgrad). */
+int st_gemm_nn(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, st_bf16* out, int64_t ldc, int M, int N, int K,
+               st_stream_t stream);
+int st_gemm_tn(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, float* out_f32, int64_t ldc, int accumulate, int M, int N,
+               int K, st_stream_t stream);
+
 /* Optional workspace for st_gemm_nt / st_gemm_nt_variant (device memory, `bytes` long, 256 KiB per tail slice; 128 MiB covers
  * every split the library picks).  With it, a launch whose 256x256 tiles do not fill whole rounds of the device's CUs cuts its
  * last partial round into K-slices (fp32 partials in the workspace, summed in a fixed order by a second launch that also runs the

@@ -34,6 +34,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
+// LDS-DMA from inline asm (M0 = wave-uniform LDS destination, restored afterwards): hipcc does not know a copy is in flight.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
 // Compile-time unrolled sched_group_barrier pattern (the builtin wants literal arguments): per slot one DS read, one MFMA,
 // optionally one VMEM (LDS-DMA) issue, then the slot's remaining MFMAs.
 template <int I, int SLOTS, int BASE, int EXTRA, int NVMEM>
@@ -44,6 +51,17 @@ __device__ __forceinline__ void pin_schedule() {
     constexpr int REST = BASE - 1 + (I < EXTRA ? 1 : 0);
     if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
     if constexpr (I + 1 < SLOTS) pin_schedule<I + 1, SLOTS, BASE, EXTRA, NVMEM>();
+}
+
+// ND LDS reads merged evenly with NM MFMAs (Bresenham), NV LDS-DMA issues spread over the first reads.
+template <int I, int ND, int NM, int NV>
+__device__ __forceinline__ void pin_mix() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    constexpr int M_NOW = ((I + 1) * NM) / ND - (I * NM) / ND;
+    if constexpr (M_NOW > 0) __builtin_amdgcn_sched_group_barrier(0x008, M_NOW, 0);
+    constexpr int V_NOW = ((I + 1) * NV) / ND - (I * NV) / ND;
+    if constexpr (V_NOW > 0) __builtin_amdgcn_sched_group_barrier(0x010, V_NOW, 0);
+    if constexpr (I + 1 < ND) pin_mix<I + 1, ND, NM, NV>();
 }
 
 // Tail split (1 workgroup per CU tiles only): a grid of q * CUs + r tiles spends a whole round on its last r tiles.  The launch
@@ -72,8 +90,17 @@ struct TailArgs {
 // accumulators go through the (now idle) operand LDS in two 256 x 128-column passes of fp32 rows padded to 528 bytes (conflict-free
 // for the 8-lane groups of ds_write_b128), and every lane then handles 8 consecutive columns of ONE row: bias / residual / C move as
 // 16-byte (fp32 target: 32-byte) row-contiguous vectors, 512 contiguous bytes per row and instruction.
+// AS / BS (256x256 MIDBAR tile only): operand A / B is stored CONTRACTION-MAJOR — A[k][m] (lda = pitch of a k-row) instead of A[m][k]
+// — as the backward GEMMs find their operands in memory: dX = dY W reads W[n][k'] with the contraction index n as the row (BS),
+// dW = dY^T X reads both dY[t][n] and X[t][k'] with the token index t as the row (AS + BS).  A K-tile of such an operand is staged as
+// [64 k-rows][256 m] (512-byte rows) by LDS-DMA with the swizzle on the source address; an MFMA fragment (8 consecutive k of one m)
+// is two ds_read_b64_tr_b16 (4 k each): no transposed copy of an operand ever exists in HBM.  32-byte chunk c (16 m) of k-row r sits
+// at chunk position c ^ ((r & 3) | ((r >> 3) & 1) << 2): the 8 k-rows a 32-lane half of a transpose read touches use 8 distinct
+// 32-byte slots of the 256-byte bank row.  hipcc has no memory operand for the transpose-read builtin and would drain every pending
+// LDS-DMA in front of it (s_waitcnt vmcnt(0) in the middle of each tile), so in these variants the LDS-DMA is issued from inline asm
+// (invisible to the compiler's wait insertion; the kernel's own counted waits order it) and placed by hand between MFMA chunks.
 template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false,
-          bool MIDBAR = false, bool SW8 = false, bool LEPI = false>
+          bool MIDBAR = false, bool SW8 = false, bool LEPI = false, bool AS = false, bool BS = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -93,6 +120,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     static_assert(!SWIGLU || ((SW8 || WTN % 32 == 0) && OUT_BF16 && !HAS_BIAS && !HAS_RES), "SwiGLU epilogue pairs 16-column MFMA tiles");
     static_assert(!SW8 || SWIGLU, "SW8 is a flavour of the SwiGLU epilogue");
     static_assert(!LEPI || (BM == 256 && BN == 256 && NW == 8 && !SWIGLU), "LDS-staged epilogue: 256x256 tile, 8 waves");
+    static_assert(!(AS || BS) || (MIDBAR && BM == 256 && BN == 256 && NW == 8 && !SWIGLU && STAGES == 2), "contraction-major operands: 256x256 mid-barrier tile");
+    constexpr bool KMAJ = AS || BS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -168,11 +197,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         }
         if (tail.mode == 2) nk = 0;
     }
-    A += kt_begin * 64;
-    B += kt_begin * 64;
+    A += AS ? (int64_t)kt_begin * 64 * lda : (int64_t)kt_begin * 64;
+    B += BS ? (int64_t)kt_begin * 64 * ldb : (int64_t)kt_begin * 64;
     if (!OUT_BF16 && !SWIGLU && tail.mode != 2) Cf += blockIdx.y * slab_stride;
+    if constexpr (!KMAJ) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);
+        for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);
+    }
 
     const int frow = lane & 15, fk = lane >> 4;
     int slot = 0;
@@ -328,6 +359,98 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         for (int ni = 0; ni < TN; ++ni)
             asm volatile("s_nop 7" : "+a"(acc[ni][0]), "+a"(acc[ni][1]), "+a"(acc[ni][2]), "+a"(acc[ni][3]), "+a"(acc[ni][4]), "+a"(acc[ni][5]),
                          "+a"(acc[ni][6]), "+a"(acc[ni][7]));
+    } else if constexpr (KMAJ) {
+        // ---- contraction-major operands: mid-tile-barrier schedule with hand-placed asm LDS-DMA (see the template comment)
+        const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
+        // one 1-KiB piece: j < A_PER -> A piece wave*A_PER + j, else B piece wave*B_PER + (j - A_PER)
+        auto dma_piece = [&](int kt, int slot_, int j) {
+            const bool isA = j < A_PER;
+            const int inst = isA ? wave * A_PER + j : wave * B_PER + (j - A_PER);
+            const uint32_t dst = smem32 + slot_ * STAGE + (isA ? 0 : A_BYTES) + inst * 1024;
+            const uint16_t* X = isA ? A : B;
+            const int64_t ldx = isA ? lda : ldb;
+            const int c0 = isA ? m0 : n0, C = isA ? M : N;
+            if ((isA && AS) || (!isA && BS)) {              // [64 k][256 m] image: this instruction = k-rows 2*inst, 2*inst + 1
+                const int kr = inst * 2 + (lane >> 5), sl = lane & 31;
+                const int g = (kr & 3) | (((kr >> 3) & 1) << 2);
+                int col = c0 + (((sl >> 1) ^ g) << 4) + (sl & 1) * 8;
+                col = col < C - 8 ? col : C - 8;            // columns past the edge compute garbage that is never stored
+                glds16_asm(X + (int64_t)(kt * 64 + kr) * ldx + col, dst);
+            } else {                                        // [256 rows][64 k] image, as in the NT kernel
+                const int p2 = inst * 64 + lane, r = p2 >> 3, kc = (p2 & 7) ^ ((r >> 1) & 7);
+                int gr = c0 + r; gr = gr < C ? gr : C - 1;
+                glds16_asm(X + (int64_t)gr * ldx + kt * 64 + kc * 8, dst);
+            }
+        };
+        bf16x8 af[2][TM], bfr[2][TN];
+        const int tr_g = ((lane >> 2) & 3) | (((lane >> 4) & 1) << 2);
+        const int tr_row = (lane >> 4) * 8 + ((lane & 15) >> 2);
+        auto tr_frag = [&](const char* img, int s2, int chunk) {   // two transpose reads: k +0..3 and +4..7 of column m = chunk*16 + (lane & 15)
+            const char* p0 = img + (s2 * 32 + tr_row) * 512 + ((chunk ^ tr_g) << 5) + (lane & 3) * 8;
+            const s16x4_t lo = st_lds_tr16(p0), hi = st_lds_tr16(p0 + 4 * 512);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto rd_a = [&](const char* la, int s2, int i) {
+            if constexpr (AS) af[s2][i] = tr_frag(la, s2, wm * (WTM / 16) + i);
+            else { const int ra = wm * WTM + i * 16 + frow, kc = s2 * 4 + fk; af[s2][i] = *reinterpret_cast<const bf16x8*>(la + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4)); }
+        };
+        auto rd_b = [&](const char* la, int s2, int i) {
+            const char* lb = la + A_BYTES;
+            if constexpr (BS) bfr[s2][i] = tr_frag(lb, s2, wn * (WTN / 16) + i);
+            else { const int rb = wn * WTN + i * 16 + frow, kc = s2 * 4 + fk; bfr[s2][i] = *reinterpret_cast<const bf16x8*>(lb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4)); }
+        };
+        static_assert(TM == 4 && TN == 8 && PER_WAVE == 8, "chunking below: 4 chunks of (1 A + 2 B fragments, 8 MFMAs, 2 DMA pieces)");
+        constexpr int RD_CHUNK = (AS ? 2 : 1) + (BS ? 4 : 2);       // LDS read instructions per chunk
+        // chunk c of a k-step: fragments A[c], B[2c], B[2c+1] of the NEXT k-step are read while the 8 MFMAs of B tiles 2c, 2c+1 run
+        auto chunk = [&](const char* rd_img, int rd_s, bool do_rd, int mm_s, int c) {
+            if (do_rd) { rd_a(rd_img, rd_s, c); rd_b(rd_img, rd_s, 2 * c); rd_b(rd_img, rd_s, 2 * c + 1); }
+#pragma unroll
+            for (int ni = 2 * c; ni < 2 * c + 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[mm_s][ni], af[mm_s][mi], acc[ni][mi], 0, 0, 0);
+            if (do_rd) pin_mix<0, RD_CHUNK, 8, 0>(); 
+        };
+        // prologue: tiles 0 and 1 in flight, fragments of (0, k-step 0) in registers
+        if (nk > 0) { for (int j = 0; j < PER_WAVE; ++j) dma_piece(0, 0, j); }
+        if (nk > 1) { for (int j = 0; j < PER_WAVE; ++j) dma_piece(1, 1, j); wait_vmcnt<PER_WAVE>(); } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (nk > 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { rd_a(smem, 0, c); rd_b(smem, 0, 2 * c); rd_b(smem, 0, 2 * c + 1); }
+        }
+        auto tile = [&](int kt, auto next_tag, auto dma_tag) {
+            constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_DMA = decltype(dma_tag)::value;
+            const int sc = kt & 1;
+            const char* cur = smem + sc * STAGE;
+            const char* nxt = smem + (sc ^ 1) * STAGE;
+            // phase A: MFMAs of k-step 0 with the reads of k-step 1 in their shadow
+#pragma unroll
+            for (int c = 0; c < 4; ++c) chunk(cur, 1, true, 0, c);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HAS_NEXT) {
+                wait_vmcnt<0>();                             // tile kt+1 (issued one tile ago) has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of slot kt have returned before anyone refills it
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            // phase B: MFMAs of k-step 1; reads of (kt+1, k-step 0) and the DMA of tile kt+2 into the slot just vacated, 2 pieces per chunk
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                chunk(nxt, 0, HAS_NEXT, 1, c);
+                if constexpr (HAS_DMA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(kt + 2, sc, 2 * c); dma_piece(kt + 2, sc, 2 * c + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { tile(kt, std::true_type{}, std::false_type{}); ++kt; }
+        if (kt < nk) tile(kt, std::false_type{}, std::false_type{});
     } else {
         static_assert(!MIDBAR || STAGES == 2, "mid-tile barrier schedule uses exactly two LDS slots");
         bf16x8 af[2][TM], bfr[2][TN];
@@ -684,6 +807,66 @@ static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// dX / dW forms on the production tile (256x256, 8 waves, mid-tile barrier, LDS-staged epilogue)
+template <bool AS_, bool BS_, bool OB, bool AC>
+static int launch_tile_layout(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N,
+                              int K, hipStream_t s) {
+    constexpr int smem = 256 * 528 > 2 * (256 + 256) * 128 ? 256 * 528 : 2 * (256 + 256) * 128;
+    auto kern = gemm_tile_kernel<256, 256, 4, 2, 2, false, false, OB, AC, false, true, false, true, AS_, BS_>;
+    static bool configured = false;
+    if (!configured) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
+    const int tiles_m = st_cdiv(M, 256), tiles_n = st_cdiv(N, 256), nb = tiles_m * tiles_n;
+    TailArgs tail{nullptr, nb, 1, 0, 1};
+    int tail_tiles = 0;
+    if (g_tail_ws) {                                          // same tail split as launch_tile
+        const int ncu = st_num_cus(), nkt = K / 64, r = nb % ncu;
+        const int64_t cap = g_tail_ws_bytes / ((int64_t)256 * 256 * 4);
+        int best = 1, best_cost = nkt + 4;
+        for (int S = 2; S <= 8 && r > 0; ++S) {
+            if ((int64_t)r * S > cap || S * 4 > nkt) break;
+            const int cost = st_cdiv(r * S, ncu) * (st_cdiv(nkt, S) + 14) + 20;
+            if (cost < best_cost) { best = S; best_cost = cost; }
+        }
+        if (best > 1) { tail = TailArgs{g_tail_ws, nb - r, best, 0, 1}; tail_tiles = r; }
+    }
+    hipLaunchKernelGGL(kern, dim3(tail.full_blocks + tail_tiles * tail.split, 1), dim3(512), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr,
+                       (const uint16_t*)nullptr, (int64_t)0, Cb, Cf, ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0, tail);
+    if (tail_tiles) {
+        tail.mode = 2;
+        while (tail.fin_sub * 2 <= 8 && tail_tiles * tail.fin_sub * 2 <= 4 * st_num_cus()) tail.fin_sub *= 2;
+        hipLaunchKernelGGL(kern, dim3(tail_tiles, tail.fin_sub), dim3(512), 0, s, A, lda, B, ldb, (const uint16_t*)nullptr,
+                           (const uint16_t*)nullptr, (int64_t)0, Cb, Cf, ldc, M, N, K, tiles_m, tiles_n, K / 64, (int64_t)0, tail);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+/* out[M,N] (bf16) = A[M,K] B[K,N] with B contraction-major (row pitch ldb): the dX = dY W form.  K % 64 == 0, N % 8 == 0. */
+extern "C" int st_gemm_nn(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, st_bf16* out, int64_t ldc, int M, int N, int K,
+                          st_stream_t stream) {
+    if (!A || !B || !out || M <= 0 || N < 8 || K <= 0 || (K % 64) || (N & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < N || ldc < N ||
+        (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
+    return launch_tile_layout<false, true, true, false>(A, lda, B, ldb, out, nullptr, ldc, M, N, K, s);
+}
+
+/* out_f32[M,N] (+)= A[K,M]^T B[K,N], BOTH operands contraction-major: the dW = dY^T X form.  K % 64 == 0, M % 8 == 0, N % 8 == 0. */
+extern "C" int st_gemm_tn(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, float* out_f32, int64_t ldc, int accumulate, int M,
+                          int N, int K, st_stream_t stream) {
+    if (!A || !B || !out_f32 || M < 8 || N < 8 || K <= 0 || (K % 64) || (M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || lda < M || ldb < N ||
+        ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
+    if (accumulate) return launch_tile_layout<true, true, false, true>(A, lda, B, ldb, nullptr, out_f32, ldc, M, N, K, s);
+    return launch_tile_layout<true, true, false, false>(A, lda, B, ldb, nullptr, out_f32, ldc, M, N, K, s);
 }
 
 // variant ids: 0 = 128x128 2x2 waves 2 stages, 1 = 128x128 3 stages, 2 = 256x128 4x2 2 stages, 3 = 256x128 4x2 3 stages,

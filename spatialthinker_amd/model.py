@@ -503,7 +503,12 @@ class Qwen25VL:
     # ---------------------------------------------------------------- helpers
     def _dw(self, gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gb: Optional[torch.Tensor]):
         """gw (N,K) fp32 += dy(M,N)^T x(M,K); gb (N,) += column sums of dy.  M is a multiple of 64 (padded rows are zero)."""
-        ops.gemm_nt(ops.transpose(dy), ops.transpose(x), out_f32=gw, accumulate=True)
+        if ops.layout_gemm_ok(dy.shape[1], x.shape[1], dy.shape[0]):
+            # both operands as they lie in memory (token index = contraction = row): transpose reads inside the tile, no transposed
+            # copies of dY / X in HBM (+13 % on the layer's dW GEMMs vs transposes + NT, tools/gemm_layout_ab.py)
+            ops.gemm_tn(dy, x, gw, accumulate=True)
+        else:
+            ops.gemm_nt(ops.transpose(dy), ops.transpose(x), out_f32=gw, accumulate=True)
         if gb is not None:
             ops.colsum(dy, out_f32=gb, accumulate=True)
 

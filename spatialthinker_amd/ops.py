@@ -266,6 +266,34 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
     return c
 
 
+def gemm_nn(a, b_kn, out=None):
+    """out[M,N] bf16 = a[M,K] @ b_kn[K,N] (b contraction-major, e.g. dX = dY @ W with W stored (out, in)): st_gemm_nn."""
+    _chk(a, BF16, "A"); _chk(b_kn, BF16, "B")
+    M, K = a.shape
+    N = b_kn.shape[1]
+    assert b_kn.shape[0] == K, (a.shape, b_kn.shape)
+    out = torch.empty(M, N, dtype=BF16, device=a.device) if out is None else out
+    _gemm_workspace(a.device)
+    lib().st_gemm_nn(_p(a), a.stride(0), _p(b_kn), b_kn.stride(0), _p(out), out.stride(0), M, N, K, _s())
+    return out
+
+
+def gemm_tn(a_km, b_kn, out_f32, accumulate=False):
+    """out_f32[M,N] (+)= a_km[K,M]^T @ b_kn[K,N] (both contraction-major, e.g. dW = dY^T @ X): st_gemm_tn."""
+    _chk(a_km, BF16, "A"); _chk(b_kn, BF16, "B"); _chk(out_f32, F32, "out")
+    K, M = a_km.shape
+    N = b_kn.shape[1]
+    assert b_kn.shape[0] == K and out_f32.shape == (M, N), (a_km.shape, b_kn.shape, out_f32.shape)
+    _gemm_workspace(a_km.device)
+    lib().st_gemm_tn(_p(a_km), a_km.stride(0), _p(b_kn), b_kn.stride(0), _p(out_f32), out_f32.stride(0), int(accumulate), M, N, K, _s())
+    return out_f32
+
+
+def layout_gemm_ok(M: int, N: int, K: int) -> bool:
+    """The contraction-major GEMM forms run on the 256x256 tile only: worth it from half a round of tiles on 256 CUs."""
+    return K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and (-(-M // 256)) * (-(-N // 256)) >= 128
+
+
 # ------------------------------------------------------------------ fused decode epilogues
 def gemm_nt_decode_slabs(a, b):
     """Decode-shaped GEMM (M <= 256) that leaves fp32 split-K slabs in the shared scratch; returns (scratch, splits)."""

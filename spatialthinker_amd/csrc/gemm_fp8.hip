@@ -116,7 +116,11 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_kernel(const uint8_t* __restri
 
     const int nk = K / 128;
     stage(0, smem);
-    const int frow = lane & 15, kb = lane >> 4;   // this lane's MX block inside the K-tile
+    // Operand layout of the K = 128 instruction (probed on MI355X, tools/probes/mx_layout_probe.hip): lane group g = lane >> 4 holds
+    // k = 16g .. 16g+15 in its first 16 bytes and k = 64+16g .. 64+16g+15 in the second 16 (two K = 64 halves), while the scale of
+    // MX block b (k = 32b .. 32b+31) is taken from lane row + 16b.  So a lane reads 16-byte chunks g and 4+g of its 128-byte row and
+    // supplies the scale byte of block g.
+    const int frow = lane & 15, kb = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt has landed (this wave's pieces; the barrier publishes all)
         __builtin_amdgcn_s_barrier();
@@ -131,16 +135,16 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_kernel(const uint8_t* __restri
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ra = wm * 64 + i * 16 + frow, sw = (ra >> 1) & 7;
-            const int4 lo = *reinterpret_cast<const int4*>(la + ra * 128 + (((2 * kb) ^ sw) << 4));
-            const int4 hi = *reinterpret_cast<const int4*>(la + ra * 128 + (((2 * kb + 1) ^ sw) << 4));
+            const int4 lo = *reinterpret_cast<const int4*>(la + ra * 128 + ((kb ^ sw) << 4));
+            const int4 hi = *reinterpret_cast<const int4*>(la + ra * 128 + (((4 + kb) ^ sw) << 4));
             af[i] = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             sca[i] = (int)((sa[ra] >> (8 * kb)) & 0xffu);
         }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int rb = wn * 128 + ni * 16 + frow, sw = (rb >> 1) & 7;
-            const int4 lo = *reinterpret_cast<const int4*>(lb + rb * 128 + (((2 * kb) ^ sw) << 4));
-            const int4 hi = *reinterpret_cast<const int4*>(lb + rb * 128 + (((2 * kb + 1) ^ sw) << 4));
+            const int4 lo = *reinterpret_cast<const int4*>(lb + rb * 128 + ((kb ^ sw) << 4));
+            const int4 hi = *reinterpret_cast<const int4*>(lb + rb * 128 + (((4 + kb) ^ sw) << 4));
             const i32x8 bf = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const int scb = (int)((sb[rb] >> (8 * kb)) & 0xffu);
 #pragma unroll

@@ -27,7 +27,11 @@ from .model import BF16, F32, I32, I64, Qwen25VL
 class Generator:
     def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False, fused_decode: bool = True):
         self.m = model
-        self.max_decode_batch = int(os.environ.get("ST_MAX_DECODE", "256"))   # sequences decoded together (rows of the decode GEMMs), <= 512
+        # sequences decoded together (rows of the decode GEMMs), <= 512.  An iteration streams every weight once whatever the row count, so
+        # the rollout time is (iterations) x (cost of an iteration): one 512-row wave needs ~920 iterations at 16.5 -> 7.9 ms (two row
+        # tiles until half of the rows have finished, then one) where two 256-row waves + pooled survivors need ~1430 at 7.9 ms:
+        # 11.9 s instead of 13.3 s for the bench's 512 rollouts (tools/gen_phases.py, round 2)
+        self.max_decode_batch = int(os.environ.get("ST_MAX_DECODE", "512"))
         self.compact = True               # restart the decode graph on the survivors once half of a phase's rows have finished
         self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
@@ -35,7 +39,7 @@ class Generator:
         # decode-loop accounting for the HBM roofline of the rollout (bench.py `roofline_decode`): seconds inside the replayed
         # decode iterations (device events), iterations, and the ALGORITHMIC bytes one iteration must read — every LM weight once
         # + the K/V of the live context (prompt K/V once per prompt and kv-head group, generated K/V per row)
-        self.stats = {"decode_s": 0.0, "decode_steps": 0, "decode_bytes": 0.0, "decode_row_steps": 0}
+        self.stats = {"decode_s": 0.0, "decode_steps": 0, "decode_bytes": 0.0, "decode_row_steps": 0, "prefill_s": 0.0, "phases": 0}
         self._timers: list = []
 
     def _tune_decode(self, B: int):
@@ -75,6 +79,8 @@ class Generator:
         kp = torch.empty(L, Tp + 128, width, dtype=BF16, device=dev)
         vp = torch.empty(L, Tp + 128, width, dtype=BF16, device=dev)
         last_h = torch.empty(nb, c.hidden_size, dtype=BF16, device=dev)
+        ev_p0, ev_p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_p0.record()
         i0 = 0
         while i0 < nb:
             i1, tok = i0, 0
@@ -96,6 +102,7 @@ class Generator:
             rows = torch.from_numpy((b.pk.cu_seqlens[1:] - 1).astype(np.int32)).to(dev)
             ops.rows_gather(x, rows, out=last_h[i0:i1])
             i0 = i1
+        ev_p1.record()
         head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
         # ---------------- decode state (per SAMPLE, global over the phases below)
         rep = torch.arange(nb, device=dev, dtype=I32).repeat_interleave(n)
@@ -305,6 +312,8 @@ class Generator:
             S, pool = np.sort(pool[:wave]), pool[wave:]
             pool = np.concatenate([pool, run(S, len(S) > 32)])
         torch.cuda.synchronize()
+        self.stats["prefill_s"] += ev_p0.elapsed_time(ev_p1) * 1e-3
+        self.stats["phases"] += len(self._timers)
         for ev0, ev1, steps, nbytes, rows in self._timers:
             self.stats["decode_s"] += ev0.elapsed_time(ev1) * 1e-3
             self.stats["decode_steps"] += steps

@@ -9,11 +9,15 @@ cfg = VLConfig.qwen2_5_vl_7b()
 st = ParamStore(cfg, trainable=False); st.init_random(1)
 gen = Generator(Qwen25VL(cfg, st))
 rs = np.random.RandomState(0)
-npr, G, R = 64, 8, 1024
+npr, G, R = 64, 8, 2048
 ids, mask, pos, pix, grids = synth_prompts(cfg, npr, rs, 1152, (1, 32, 42))
 for it in range(2):
     lens = np.clip(rs.normal(512, 128, npr * G), 64, R).astype(np.int64)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=1.0, eos_token_id=151645, pad_token_id=151643, seed=it,
                        pixel_values=pix, image_grid_thw=grids, forced_lengths=lens)
-    torch.cuda.synchronize(); print(f"total {time.perf_counter() - t0:.3f}s", flush=True)
+    torch.cuda.synchronize(); tot = time.perf_counter() - t0
+    st_ = gen.stats
+    print(f"total {tot:.3f}s: prefill {st_['prefill_s']:.3f}s, decode loops {st_['decode_s']:.3f}s over {st_['decode_steps']} iterations in {st_['phases']} phases, "
+          f"rest (graph capture, host bookkeeping, syncs) {tot - st_['prefill_s'] - st_['decode_s']:.3f}s", flush=True)
+    gen.stats = {k: 0 for k in gen.stats}

@@ -4,6 +4,7 @@ import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialthinker_amd import ops
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 10496
+VA, VB = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (6, 23)
 H, QKV, I2, I = 3584, 4608, 37888, 18944
 ops._gemm_workspace(torch.device("cuda"))
 def timeit(fn, iters=6):
@@ -16,7 +17,7 @@ def timeit(fn, iters=6):
 shapes = [("qkv+bias", T, QKV, H, "bias"), ("o+res", T, H, H, "res"), ("down+res", T, H, I, "res"), ("dx_qkv", T, H, QKV, ""), ("dx_o", T, H, H, ""),
           ("dx_gu", T, H, I2, ""), ("dx_down", T, I, H, ""), ("dw_qkv", QKV, H, T, "acc"), ("dw_o", H, H, T, "acc"), ("dw_gu", I2, H, T, "acc"),
           ("dw_down", H, I, T, "acc"), ("lm_head", 2048, 152064, H, "")]
-tot = {6: 0.0, 23: 0.0}
+tot = {VA: 0.0, VB: 0.0}
 for name, M, N, K, kind in shapes:
     a = torch.randn(M, K, device="cuda").bfloat16(); b = torch.randn(N, K, device="cuda").bfloat16()
     bias = torch.randn(N, device="cuda").bfloat16(); res = torch.randn(M, N, device="cuda").bfloat16()
@@ -26,13 +27,13 @@ for name, M, N, K, kind in shapes:
         elif kind == "bias": ops.gemm_nt_variant(v, a, b, out=c, bias=bias)
         elif kind == "res": ops.gemm_nt_variant(v, a, b, out=c, residual=res)
         else: ops.gemm_nt_variant(v, a, b, out=c)
-    for v in (6, 23): run(v)
-    ts = {6: [], 23: []}
+    for v in (VA, VB): run(v)
+    ts = {VA: [], VB: []}
     for _ in range(7):
-        for v in (6, 23): ts[v].append(timeit(lambda: run(v)))
-    m6, m23 = statistics.median(ts[6]), statistics.median(ts[23])
-    tot[6] += m6; tot[23] += m23
+        for v in (VA, VB): ts[v].append(timeit(lambda: run(v)))
+    m6, m23 = statistics.median(ts[VA]), statistics.median(ts[VB])
+    tot[VA] += m6; tot[VB] += m23
     fl = 2.0 * M * N * K / 1e6
-    print(f"{name:10s} {M:6d}x{N:6d}x{K:6d}: direct {m6:8.1f} us ({fl / m6:5.0f} TF)   lds-staged {m23:8.1f} us ({fl / m23:5.0f} TF)   {100 * (m6 / m23 - 1):+5.1f} %", flush=True)
+    print(f"{name:10s} {M:6d}x{N:6d}x{K:6d}: v{VA} {m6:8.1f} us ({fl / m6:5.0f} TF)   v{VB} {m23:8.1f} us ({fl / m23:5.0f} TF)   {100 * (m6 / m23 - 1):+5.1f} %", flush=True)
     del a, b, bias, res, c, f
-print(f"sum: direct {tot[6] / 1e3:.2f} ms, lds-staged {tot[23] / 1e3:.2f} ms ({100 * (tot[6] / tot[23] - 1):+.1f} %)")
+print(f"sum: variant {VA} {tot[VA] / 1e3:.2f} ms, variant {VB} {tot[VB] / 1e3:.2f} ms ({100 * (tot[VA] / tot[VB] - 1):+.1f} %)")

@@ -11,18 +11,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_main_runs_two_grpo_steps(tmp_path):
-    cmd = [sys.executable, "-m", "verl.trainer.main", "data.train_files=synthetic:stvqa@train", "data.val_files=", "data.rollout_batch_size=4",
+    cmd = [sys.executable, "-m", "verl.trainer.main", "data.train_files=synthetic:stvqa@train", "data.val_files=synthetic:stvqa@val", "data.val_batch_size=32",
+           "worker.rollout.val_override_config={'temperature': 0.5, 'n': 1}", "trainer.val_generations_to_log=1", "data.rollout_batch_size=4",
            "data.max_prompt_length=64", "data.max_response_length=16", "worker.actor.model.model_path=random:tiny",
            "worker.actor.global_batch_size=2", "worker.actor.micro_batch_size_per_device_for_update=4",
            "worker.actor.micro_batch_size_per_device_for_experience=8", "worker.actor.optim.strategy=adamw_bf16",
            "worker.actor.fsdp.torch_dtype=bf16", "worker.actor.padding_free=true", "worker.rollout.n=4", "worker.reward.score_function=spatial_sgg",
            "algorithm.use_kl_loss=true", "algorithm.kl_penalty=low_var_kl", "algorithm.kl_coef=1.0e-2", "trainer.max_steps=2",
-           "trainer.total_episodes=1", "trainer.n_gpus_per_node=1", "trainer.val_before_train=false", "trainer.logger=['console']",
+           "trainer.total_episodes=1", "trainer.n_gpus_per_node=1", "trainer.val_before_train=true", "trainer.logger=['console']",
            f"trainer.save_checkpoint_path={tmp_path}/ckpt"]
     env = dict(os.environ, PYTHONPATH=ROOT)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("step ")]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("step ") and "actor/pg_loss" in l]          # training steps (validation logs its own lines)
     assert len(lines) == 2, p.stdout[-2000:]
     for key in ("actor/pg_loss", "actor/kl_loss", "actor/grad_norm", "actor/lr", "timing_s/gen", "timing_s/update_actor", "reward/overall",
                 "perf/throughput", "critic/advantages/mean", "response_length/mean", "perf/mfu_actor"):
@@ -34,6 +35,21 @@ def test_main_runs_two_grpo_steps(tmp_path):
     assert last in ("2", "3")
     assert os.path.exists(tmp_path / "ckpt" / f"global_step_{last}" / "actor" / "huggingface" / "model.safetensors")
     assert os.path.exists(tmp_path / "ckpt" / f"global_step_{last}" / "actor" / "optim_world_size_1_rank_0.pt")
+    # validation (ray_trainer.py:358-411): before training (step 0 line), after training, with the reference's metric names
+    v0 = [l for l in p.stdout.splitlines() if l.startswith("step 0:")]
+    assert len(v0) == 1 and "val/reward_score" in v0[0] and "val/overall_reward" in v0[0] and "val/format_reward" in v0[0], p.stdout[-1500:]
+    assert "Final validation metrics: val/reward_score" in p.stdout and "[val generation @ step" in p.stdout
+    ck = tmp_path / "ckpt" / f"global_step_{last}"
+    for f in ("dataloader.pt", "actor/huggingface/config.json", "actor/huggingface/generation_config.json"):
+        assert os.path.exists(ck / f), f
+    # resume: the run continues with the step after the checkpoint and the next batches of the sampler
+    cmd2 = [c for c in cmd if not c.startswith(("trainer.max_steps", "trainer.val_before_train"))] + \
+           [f"trainer.max_steps={int(last) + 1}", "trainer.val_before_train=false", f"trainer.load_checkpoint_path={ck}"]
+    p2 = subprocess.run(cmd2, cwd=ROOT, env=dict(env, ST_SKIP_FINAL_SAVE="1"), capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stdout[-3000:] + p2.stderr[-3000:]
+    steps2 = [l.split(":")[0] for l in p2.stdout.splitlines() if l.startswith("step ") and "actor/pg_loss" in l]
+    assert f"step {int(last) + 1}" in steps2 and "step 1" not in steps2, steps2
+    assert f"Load from checkpoint: {ck}" in p2.stdout
 
 
 def test_config1_3b_vanilla_grpo_r1v_2x4_224px(tmp_path):

@@ -44,7 +44,7 @@ def main():
     processor = get_processor(mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
     reward_fn = CustomRewardManager(tokenizer, cfg.worker.reward)
 
-    def dataset(spec):
+    def dataset(spec, train: bool):
         if not spec:
             return None
         if spec.startswith("synthetic:") or is_synthetic(mc.model_path):
@@ -59,15 +59,17 @@ def main():
                 w_px, h_px = (int(v) for v in name[2].lower().split("x"))
                 grid, text = (1, h_px // mcfg.v_patch, w_px // mcfg.v_patch), ((8, 12) if tiny else (200, 500))
             return SyntheticSTVQADataset(mcfg, tokenizer, size=max(4 * cfg.data.rollout_batch_size, 64), max_prompt_length=cfg.data.max_prompt_length,
-                                         seed=cfg.data.seed + (1 if spec.endswith("@val") else 0), grid=grid, text_tokens=text)
+                                         seed=cfg.data.seed + (0 if train else 1), grid=grid, text_tokens=text)
+        # ray_trainer.py:267-313: the train set takes mixed_data / text_only, the validation set does not; both keep the dataset's own
+        # shuffle (seed 42) — data.shuffle / data.seed drive the SAMPLER
+        extra = dict(mixed_data=cfg.data.mixed_data, text_only=cfg.data.text_only) if train else {}
         return RLHFDataset(spec, tokenizer, processor, prompt_key=cfg.data.prompt_key, answer_key=cfg.data.answer_key, image_key=cfg.data.image_key,
                            max_prompt_length=cfg.data.max_prompt_length, truncation="right", format_prompt=cfg.data.format_prompt,
-                           min_pixels=cfg.data.min_pixels, max_pixels=cfg.data.max_pixels, text_only=cfg.data.text_only,
-                           mixed_data=cfg.data.mixed_data, shuffle=cfg.data.shuffle, seed=cfg.data.seed)
+                           min_pixels=cfg.data.min_pixels, max_pixels=cfg.data.max_pixels, **extra)
 
     # the trainer validates the batch-size relations on the user's numbers BEFORE the worker scales global_batch_size by
     # rollout.n (ray_trainer.py:238-263 runs before fsdp_workers.py:130-136 in the reference too)
-    trainer = RayPPOTrainer(cfg, tokenizer, processor, None, None, reward_fn, reward_fn, dataset(cfg.data.train_files), dataset(cfg.data.val_files))
+    trainer = RayPPOTrainer(cfg, tokenizer, processor, None, None, reward_fn, reward_fn, dataset(cfg.data.train_files, True), dataset(cfg.data.val_files, False))
     role = "actor_rollout" if cfg.algorithm.disable_kl else "actor_rollout_ref"      # colocated roles (ray/base.py:453-493)
     wg = SPMDWorkerGroup(FSDPWorker(cfg.worker, role))
     trainer.set_worker_groups(wg, wg)

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
+    ap.add_argument("--recompute-light", action="store_true", help="recompute the RMSNorm / SwiGLU outputs in the backward instead of keeping them (-1/3 activation memory)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = BASELINE config #5's arithmetic: the LM projection GEMMs of every forward pass on the MX-fp8 (OCP e4m3, block-"
@@ -324,6 +325,8 @@ def main():
     ref = PolicyEngine(cfg, ref_store, None)
     if a.fuse_micro_batches is not None:
         actor.fuse_micro_batches = a.fuse_micro_batches
+    if a.recompute_light:
+        actor.model.recompute_light = True
     if a.dtype == "fp8":
         actor.model.enable_fp8(True)
         ref.model.enable_fp8(True)

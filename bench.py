@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--prompts-per-gpu", type=int, default=64,
                     help="rollout prompts per GPU and step (64 = the reference's 512-prompt rollout batch over 8 GPUs; SURVEY 8d' #3/#4)")
     ap.add_argument("--rollouts", type=int, default=8)
+    ap.add_argument("--image", default=None, help="WxH pixels of the synthetic image instead of the STVQA-shaped 588x448 (SURVEY 8d': 224x224 / "
+                                                  "448x448 / 896x896 -> 256 / 1024 / 4096 patches, with 700 text tokens)")
     ap.add_argument("--response-cap", type=int, default=2048,
                     help="max_response_length of the synthetic batch (scripts/spatialthinker_7b_grpo.sh:34: 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -308,6 +310,9 @@ def main():
     tiny = a.model == "tiny"
     grid = (1, 8, 8) if tiny else (1, 32, 42)                       # STVQA-shaped 588x448 -> 1344 patches -> 336 image tokens
     tb, ta = (8, 12) if tiny else (200, 564)
+    if a.image and not tiny:
+        w_px, h_px = (int(v) for v in a.image.lower().split("x"))
+        grid, (tb, ta) = (1, h_px // cfg.v_patch, w_px // cfg.v_patch), (200, 498)
     n_img = grid[1] * grid[2] // 4
     P = (tb + ta + 2 + n_img + 63) // 64 * 64
     R = 64 if tiny else a.response_cap
@@ -483,8 +488,8 @@ def main():
             "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.dtype == "bf16" else "fp8 (MX e4m3 forward projection GEMMs; bf16 attention / lm_head / backward / decode)",
-            "data": "synthetic (random-init weights at real shapes; STVQA-7K-shaped prompts: 766 text + 336 image tokens from "
-                                     "1344 random patches; response lengths ~ clip(N(512,128),64,cap) enforced by forcing EOS; templated reward strings)",
+            "data": f"synthetic (random-init weights at real shapes; prompts: {tb + ta + 2} text + {n_img} image tokens from "
+                                     f"{grid[1] * grid[2]} random patches; response lengths ~ clip(N(512,128),64,cap) enforced by forcing EOS; templated reward strings)",
             "config": {"workload": f"{name} dense spatial-reward GRPO step (gen + reward + old/ref log-probs + advantage + update), G={G}, "
                                    f"{npr} prompts/GPU, micro-batch {micro}, {n_opt} optimizer steps/step, max_response_length {R}",
                        "global_batch": B * world, "seq_len": P + R, "parallelism": f"dp{world}"},

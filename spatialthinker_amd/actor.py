@@ -119,7 +119,7 @@ class PolicyEngine:
         self.fuse_micro_batches = 8
         if hyper is not None:
             self.model.recompute_light = True
-        self.fuse_experience = 4      # no-grad log-prob passes run this many reference micro-batches at once: rows are independent
+        self.fuse_experience = int(os.environ.get("ST_FUSE_EXPERIENCE", "4"))      # no-grad log-prob passes run this many reference micro-batches at once: rows are independent
                                       # there (no loss normalisation), the result is bit-identical, the GEMMs see 4x the rows
         self.opt_steps = 0            # t of AdamW (state["step"])
         self.sched_steps = 0          # lr_scheduler.step() calls so far: once per update_policy call (fsdp_workers.py:453)

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const int q_base = blockIdx.x * Q_TILE;
     if (q_base >= Lq) return;
     const int kvh = h / (n_q / n_kv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
     const int q_idx = q_base + wave * 32 + qc;           // row inside the sequence
     const bool q_ok = q_idx < Lq;
@@ -258,7 +258,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
                                                             const uint16_t* __restrict__ k_pre, int64_t ldk_pre,
                                                             const uint16_t* __restrict__ v_pre, int64_t ldv_pre) {
     constexpr int D = 128;
+#ifdef FWD_ONE_PER_CU
+    __shared__ __attribute__((aligned(1024))) char smem[2 * F2_STAGE + 32768];      // experiment: one workgroup per CU
+#else
     __shared__ __attribute__((aligned(1024))) char smem[2 * F2_STAGE];
+#endif
     const int seq = blockIdx.z, h = blockIdx.y;
     const int s0 = q_beg[seq], Lq = q_end[seq] - s0;
     const int sk = k_beg[seq], L = k_end[seq] - sk;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
     const int q_base = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * Q_TILE;
     if (q_base >= Lq) return;
     const int kvh = h / (n_q / n_kv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
     const int q_idx = q_base + wave * 32 + qc;
     const bool q_ok = q_idx < Lq;
@@ -324,7 +328,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
             st_glds16(vb_ + (int64_t)(row0 + key) * ldv_ + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
         }
     };
-    if (n_tiles > 0) stage(0, smem);
+    // Full tiles of the own keys take the cheap path: source = wave-uniform tile base + a lane-constant 32-bit offset per copy
+    // (the general path spends ~16 integer VALU instructions per copy on clamping and 64-bit address arithmetic, ~130 per tile,
+    // and plain VALU work does not hide under MFMAs on this part — tools/probes/mfma_valu_overlap.hip)
+    uint32_t koff[4], voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int inst = wave * 4 + j;
+        const int row = inst * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+        koff[j] = (uint32_t)(row * (int)ldk + c * 8) * 2u;
+        const int u = 2 * inst + (lane >> 5), slot = lane & 31;
+        voff[j] = (uint32_t)(((u >> 2) * 8 + (slot >> 2)) * (int)ldv + (u & 3) * 32 + (slot & 3) * 8) * 2u;
+    }
+    auto stage_any = [&](int t, char* dst) {
+        const bool pre = t < n_pre;
+        const int kt0 = (pre ? t : t - n_pre) * KV_TILE;
+        if (pre || kt0 + KV_TILE > L) { stage(t, dst); return; }
+        const char* kt = reinterpret_cast<const char*>(kbase + (int64_t)(sk + kt0) * ldk);
+        const char* vt = reinterpret_cast<const char*>(vbase + (int64_t)(sk + kt0) * ldv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st_glds16(kt + koff[j], dst + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st_glds16(vt + voff[j], dst + F2_V_OFF + (wave * 4 + j) * 1024);
+    };
+    if (n_tiles > 0) stage_any(0, smem);
+#ifdef FWD_SKEW
+    {   // experiment: start the two co-resident waves of a SIMD half a tile period apart (attention)
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if ((hwid >> FWD_SKEW_BIT) & 1) __builtin_amdgcn_s_sleep(FWD_SKEW);
+    }
+#endif
 
     // lane-constant LDS offsets
     const int k_row_off = qc * 256, k_swz = qc & 15;                       // rows kb*32+qc: (row & 15) == (qc & 15)
@@ -338,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 1 < n_tiles) stage(t + 1, smem + ((t + 1) & 1) * F2_STAGE);
+        if (t + 1 < n_tiles) stage_any(t + 1, smem + ((t + 1) & 1) * F2_STAGE);
         if (causal_t && kt0 > q_base + wave * 32 + 31) continue;        // tile entirely above this wave's diagonal
         if (q_base + wave * 32 >= Lq) continue;                         // decode: most waves of a tile hold no query row at all
         const char* ks = smem + (t & 1) * F2_STAGE;
@@ -378,16 +412,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         const float m_new = fmaxf(m_i, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);          // m_i = -inf -> 0
-        float rs = 0.f;
+        // two elements per v_pk_fma_f32 / v_pk_add_f32: plain VALU instructions are paid in full next to the MFMAs
+        hw_f32x2_t rs2 = {0.f, 0.f};
+        const hw_f32x2_t sc2 = {scale_log2, scale_log2}, nm2 = {-m_use, -m_use};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], scale_log2, -m_use));
-                sacc[kb][r] = p;
-                rs += p;
+            for (int r = 0; r < 16; r += 2) {
+                hw_f32x2_t x = {sacc[kb][r], sacc[kb][r + 1]};
+                x = __builtin_elementwise_fma(x, sc2, nm2);
+                x[0] = __builtin_amdgcn_exp2f(x[0]);
+                x[1] = __builtin_amdgcn_exp2f(x[1]);
+                sacc[kb][r] = x[0];
+                sacc[kb][r + 1] = x[1];
+                rs2 += x;
             }
-        rs = st_half_sum(rs);
+        float rs = st_half_sum(rs2[0] + rs2[1]);
         l_i = l_i * alpha + rs;
         m_i = m_new;
         if (!__all(alpha == 1.f)) {
@@ -503,7 +543,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     const int q_base = blockIdx.x * Q_TILE;
     if (q_base >= L) return;
     const int kvh = h / (n_q / n_kv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
     const int q_idx = q_base + wave * 32 + qc;
     const bool q_ok = q_idx < L;
@@ -625,7 +665,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
     const int k_base = blockIdx.x * 128;
     if (k_base >= L) return;
     const int group = n_q / n_kv;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kc = lane & 31, half = lane >> 5;
     const int key_idx = k_base + wave * 32 + kc;
     const bool k_ok = key_idx < L;
@@ -754,6 +794,27 @@ __device__ __forceinline__ void stage_dual(const uint16_t* __restrict__ base, in
     }
 }
 
+// Full tiles: copy `inst` (rows 4*inst .. 4*inst+3) reads from the wave-uniform address of its first row + a lane part that needs
+// two lane-constant registers and two VALU instructions: row r0 = lane >> 4 of the four, 16-byte chunk (lane & 15) ^ swz16(row) =
+// cx ^ (inst & 3) with cx = (lane & 15) ^ (r0 << 2).  (The general path below clamps rows and builds 64-bit addresses: ~16 integer VALU
+// instructions per copy, ~130 per tile — and plain VALU work does not hide under MFMAs: tools/probes/mfma_valu_overlap.hip.)  The
+// empty asm keeps hipcc from hoisting the per-copy offsets out of the tile loop into registers the kernels do not have.
+struct StageLane { uint32_t cx4, r0ld; };
+__device__ __forceinline__ StageLane stage_lane(int64_t ld, int lane) {
+    const int r0 = lane >> 4;
+    return {(uint32_t)(((lane & 15) ^ (r0 << 2)) << 4), (uint32_t)(r0 * (int)ld) * 2u};
+}
+template <int ROWS>
+__device__ __forceinline__ void stage_dual_fast(const uint16_t* __restrict__ tile_base, int64_t ld, uint32_t cx4, uint32_t r0ld, char* dst, int wave) {
+    asm volatile("" : "+v"(cx4));
+#pragma unroll
+    for (int j = 0; j < ROWS / 16; ++j) {
+        const int inst = wave * (ROWS / 16) + j;
+        const char* tb = reinterpret_cast<const char*>(tile_base + (int64_t)(inst * 4) * ld);
+        st_glds16(tb + ((cx4 ^ (uint32_t)((inst & 3) << 4)) + r0ld), dst + inst * 1024);
+    }
+}
+
 // lane-constant byte offsets of the transpose reads inside a dual-use image: entry [2*b + j] = d-block b (32 d), key/row
 // group j (rows +0..3 / +8..11 of a 16-row k-slot; the +8 rows and the k-slot base are immediates at the call site)
 __device__ __forceinline__ void tr_dual_offsets(uint32_t (&a)[8], int lane) {
@@ -783,6 +844,29 @@ __device__ __forceinline__ void tr_issue8_dual(uint2 (&f)[8], const uint32_t (&a
                  : "memory");
 }
 
+// Order of an S / dP loop: NPAIR (fragment read pair, MFMA pair) steps with the reads running AHEAD steps in front of their MFMAs
+// (hipcc otherwise issues a step's two ds_read_b128 right in front of its MFMAs and waits lgkmcnt(0): the LDS latency is exposed
+// once per step, eight times per 32 x 32 block).  RD = LDS reads per step, MM = MFMAs per step.
+template <int I, int NPAIR, int AHEAD, int RD, int MM>
+__device__ __forceinline__ void pin_sloop() {
+    if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, RD * AHEAD, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+    if constexpr (I + AHEAD < NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+    if constexpr (I + 1 < NPAIR) pin_sloop<I + 1, NPAIR, AHEAD, RD, MM>();
+}
+
+#ifndef BWD_FAST_STAGE
+#define BWD_FAST_STAGE 1
+#endif
+#ifndef SL_AHEAD
+#define SL_AHEAD 2
+#endif
+#ifndef KV0_AHEAD
+#define KV0_AHEAD 1
+#endif
+#ifndef KV1_AHEAD
+#define KV1_AHEAD 4
+#endif
 #define B2_KV_STAGE 32768          // dq kernel: K image 16 KiB + V image 16 KiB
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* __restrict__ q, int64_t ldq,
@@ -791,6 +875,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
                                                                const uint16_t* __restrict__ dout, int64_t lddo,
                                                                const uint16_t* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
+                                                               float* __restrict__ lse2_out,
                                                                const int32_t* __restrict__ seg_b, const int32_t* __restrict__ seg_e,
                                                                const int32_t* __restrict__ pre_b, const int32_t* __restrict__ pre_e,
                                                                int T, int n_q, int n_kv,
@@ -802,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
     const int q_base = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * Q_TILE;
     if (q_base >= L) return;
     const int kvh = h / (n_q / n_kv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
     const int q_idx = q_base + wave * 32 + qc;
     const bool q_ok = q_idx < L;
@@ -831,8 +916,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
         }
     }
     dlt = st_half_sum(dlt);
-    if (q_ok && half == 0) delta[(int64_t)h * T + s0 + q_idx] = dlt;
     const float lse2 = q_ok ? lse[(int64_t)h * T + s0 + q_idx] * LOG2E : 0.f;
+    if (q_ok && half == 0) { delta[(int64_t)h * T + s0 + q_idx] = dlt; lse2_out[(int64_t)h * T + s0 + q_idx] = lse2; }
     f32x16 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -844,9 +929,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
     const int n_pre = (Lp + KV_TILE - 1) / KV_TILE;
     const int kv_end = CAUSAL ? min(L, q_base + Q_TILE) : L;
     const int n_tiles = n_pre + (kv_end + KV_TILE - 1) / KV_TILE;
+    const StageLane sl_k = stage_lane(ldk, lane), sl_v = stage_lane(ldv, lane);
     auto stage = [&](int t, char* dst) {
         const bool pre = t < n_pre;
         const int kt0 = (pre ? t : t - n_pre) * KV_TILE, row0 = pre ? pb : s0, Lc = pre ? Lp : L;
+        if (BWD_FAST_STAGE && kt0 + KV_TILE <= Lc) {
+            stage_dual_fast<KV_TILE>(k + (int64_t)(row0 + kt0) * ldk + kvh * D, ldk, sl_k.cx4, sl_k.r0ld, dst, wave);
+            stage_dual_fast<KV_TILE>(v + (int64_t)(row0 + kt0) * ldv + kvh * D, ldv, sl_k.cx4, sl_v.r0ld, dst + 16384, wave);
+            return;
+        }
         stage_dual<KV_TILE>(k + (int64_t)row0 * ldk + kvh * D, ldk, kt0, Lc, dst, wave, lane);
         stage_dual<KV_TILE>(v + (int64_t)row0 * ldv + kvh * D, ldv, kt0, Lc, dst + 16384, wave, lane);
     };
@@ -879,23 +970,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
             const char* kp = ks + kb * 32 * 256 + nat_row;
             const char* vp = vs + kb * 32 * 256 + nat_row;
+            bf16x8 kfr[8], vfr[8];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int off = ((2 * s + half) ^ nat_swz) << 4;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + off);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vp + off);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);     // S^T  = K Q^T
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], pacc, 0, 0, 0);    // dP^T = V dO^T
+                kfr[s] = *reinterpret_cast<const bf16x8*>(kp + off);
+                vfr[s] = *reinterpret_cast<const bf16x8*>(vp + off);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -lse2));
-                if (need_mask) {
-                    const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    p = ((key < Lc) && (!causal_t || key <= q_idx)) ? p : 0.f;
-                }
-                sacc[r] = p * (pacc[r] - dlt) * scale;                                         // dS^T
+            for (int s = 0; s < 8; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc, 0, 0, 0);     // S^T  = K Q^T
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], dof[s], pacc, 0, 0, 0);    // dP^T = V dO^T
             }
+            pin_sloop<0, 8, SL_AHEAD, 2, 2>();
+            __builtin_amdgcn_sched_barrier(0);
+            // P first (16 independent fma + exp chains), then ONE wave-uniform branch for the tiles that need a mask: with the test
+            // inside the element loop hipcc wraps every element in its own exec-mask region and the exp latency is exposed 16 times
+            {
+                const hw_f32x2_t sc2 = {scale_log2, scale_log2}, nl2 = {-lse2, -lse2};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    hw_f32x2_t x = {sacc[r], sacc[r + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, nl2);
+                    sacc[r] = __builtin_amdgcn_exp2f(x[0]);
+                    sacc[r + 1] = __builtin_amdgcn_exp2f(x[1]);
+                }
+            }
+            if (need_mask) {
+                const int key0 = kt0 + kb * 32 + 4 * half;
+                const int lim = causal_t ? min(Lc - 1, q_idx) : Lc - 1;                        // visible keys: key <= lim
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = (key0 + (r & 3) + 8 * (r >> 2) <= lim) ? sacc[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = sacc[r] * (pacc[r] - dlt);                  // dS^T / scale (the factor goes on dQ at the end)
             auto dq_step = [&](int rb, uint2 (&tf)[8]) {
                 uint4 pw;
                 pw.x = st_pk_bf16(sacc[rb + 0], sacc[rb + 1]);
@@ -921,8 +1030,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
         for (int g = 0; g < 4; ++g) {
             const int d = b * 32 + 8 * g + 4 * half;
             uint2 w;
-            w.x = st_pk_bf16(acc[b][4 * g + 0], acc[b][4 * g + 1]);
-            w.y = st_pk_bf16(acc[b][4 * g + 2], acc[b][4 * g + 3]);
+            w.x = st_pk_bf16(acc[b][4 * g + 0] * scale, acc[b][4 * g + 1] * scale);
+            w.y = st_pk_bf16(acc[b][4 * g + 2] * scale, acc[b][4 * g + 3] * scale);
             *reinterpret_cast<uint2*>(op + d) = w;
         }
 }
@@ -965,7 +1074,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
     const int k_base = blockIdx.x * 128;
     if (k_base >= Lk) return;
     const int kvh = hq / (n_q / n_kv);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kc = lane & 31, half = lane >> 5;
     const int key_idx = k_base + wave * 32 + kc;
     const bool k_ok = key_idx < Lk;
@@ -996,10 +1105,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
     const int n_stage = (L - q_start + QR - 1) / QR;
     const uint16_t* qbase = q + (int64_t)s0 * ldq + hq * D;
     const uint16_t* dobase = dout + (int64_t)s0 * lddo + hq * D;
+    const StageLane sl_q = stage_lane(ldq, lane), sl_do = stage_lane(lddo, lane);
     auto stage = [&](int i, char* dst) {
         const int qt0 = q_start + i * QR;
-        stage_dual<QR>(qbase, ldq, qt0, L, dst, wave, lane);
-        stage_dual<QR>(dobase, lddo, qt0, L, dst + IMG, wave, lane);
+        if (BWD_FAST_STAGE && qt0 + QR <= L) {
+            stage_dual_fast<QR>(qbase + (int64_t)qt0 * ldq, ldq, sl_q.cx4, sl_q.r0ld, dst, wave);
+            stage_dual_fast<QR>(dobase + (int64_t)qt0 * lddo, lddo, sl_q.cx4, sl_do.r0ld, dst + IMG, wave);
+        } else {
+            stage_dual<QR>(qbase, ldq, qt0, L, dst, wave, lane);
+            stage_dual<QR>(dobase, lddo, qt0, L, dst + IMG, wave, lane);
+        }
         if (wave == 0) {                                   // 4-byte DMA: QR lse rows then QR delta rows
 #pragma unroll
             for (int e = 0; e < EXTRA; ++e) {
@@ -1048,36 +1163,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
             f32x16 sacc, pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; if constexpr (MODE == 0) pacc[r] = 0.f; }
+            bf16x8 qfr[8], dofr[MODE == 0 ? 8 : 1];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int off = nat_row + (((2 * s + half) ^ nat_swz) << 4);
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(qs + off);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], sacc, 0, 0, 0);          // S  = Q K^T   (rows q, cols key)
-                if constexpr (MODE == 0) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(dos + off);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, vf[s], pacc, 0, 0, 0);      // dP = dO V^T
-                }
+                qfr[s] = *reinterpret_cast<const bf16x8*>(qs + off);
+                if constexpr (MODE == 0) dofr[s] = *reinterpret_cast<const bf16x8*>(dos + off);
             }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[s], kf[s], sacc, 0, 0, 0);     // S  = Q K^T   (rows q, cols key)
+                if constexpr (MODE == 0) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr[s], vf[s], pacc, 0, 0, 0);      // dP = dO V^T
+            }
+            if constexpr (MODE == 0) pin_sloop<0, 8, KV0_AHEAD, 2, 2>(); else pin_sloop<0, 8, KV1_AHEAD, 1, 1>();
+            __builtin_amdgcn_sched_barrier(0);
             const bool need_mask = (qt0 + 32 > L) || (k_base + wave * 32 + 32 > Lk) || (CAUSAL && qt0 < k_base + wave * 32 + 31);
-            uint32_t pk[8];                                    // packed bf16 P (dV) or dS (dK), rows 2i, 2i+1
+            // P for all 16 elements first (independent fma + exp chains; the staged lse is already in log2 units), then ONE wave-uniform
+            // branch for the sub-tiles that need a mask, then dS / the bf16 packing
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 8 * g + 4 * half);
-                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (MODE == 0) d4 = *reinterpret_cast<const f32x4*>(s_dlt + 8 * g + 4 * half);
-                float x[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -l4[j] * LOG2E));
-                    if (need_mask) {
-                        const int qi = qt0 + 8 * g + 4 * half + j;
-                        p = (k_ok && (qi < L) && (!CAUSAL || qi >= Lk || key_idx <= qi)) ? p : 0.f;
-                    }
-                    x[j] = MODE == 0 ? p * (pacc[r] - d4[j]) * scale : p;
+                for (int j = 0; j < 4; j += 2) {
+                    hw_f32x2_t x = {sacc[4 * g + j], sacc[4 * g + j + 1]};
+                    const hw_f32x2_t sc2 = {scale_log2, scale_log2}, nl2 = {-l4[j], -l4[j + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, nl2);
+                    sacc[4 * g + j] = __builtin_amdgcn_exp2f(x[0]);
+                    sacc[4 * g + j + 1] = __builtin_amdgcn_exp2f(x[1]);
                 }
-                pk[2 * g] = st_pk_bf16(x[0], x[1]);
-                pk[2 * g + 1] = st_pk_bf16(x[2], x[3]);
+            }
+            if (need_mask) {                                   // visible: lo <= qi < L with lo = the key's own row (causal; dependents lie behind Lk)
+                const int lo = k_ok ? (CAUSAL ? key_idx : 0) : 0x3fffffff;
+                const int q0 = qt0 + 4 * half - lo;
+                const uint32_t span = (uint32_t)max(L - lo, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = ((uint32_t)(q0 + 8 * (r >> 2) + (r & 3)) < span) ? sacc[r] : 0.f;
+            }
+            uint32_t pk[8];                                    // packed bf16 P (dV) or dS / scale (dK), rows 2i, 2i+1
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (MODE == 0) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dlt + 8 * g + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc[4 * g + j] *= pacc[4 * g + j] - d4[j];
+                }
+                pk[2 * g] = st_pk_bf16(sacc[4 * g], sacc[4 * g + 1]);
+                pk[2 * g + 1] = st_pk_bf16(sacc[4 * g + 2], sacc[4 * g + 3]);
             }
             auto kv_step = [&](int ks2, uint2 (&tf)[8]) {
                 uint4 pw;
@@ -1101,9 +1233,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d = b * 32 + 8 * g + 4 * half;
+            const float f = MODE == 0 ? scale : 1.f;           // dS was kept without the softmax scale
             uint2 w;
-            w.x = st_pk_bf16(acc[b][4 * g + 0], acc[b][4 * g + 1]);
-            w.y = st_pk_bf16(acc[b][4 * g + 2], acc[b][4 * g + 3]);
+            w.x = st_pk_bf16(acc[b][4 * g + 0] * f, acc[b][4 * g + 1] * f);
+            w.y = st_pk_bf16(acc[b][4 * g + 2] * f, acc[b][4 * g + 3] * f);
             *reinterpret_cast<uint2*>(pp + d) = w;
         }
 }
@@ -1182,7 +1315,7 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
 }
 
 int64_t st_attn_bwd_workspace_bytes(int T, int n_q, int D) {
-    return D == 128 ? (int64_t)2 * n_q * T * 128 * (int64_t)sizeof(uint16_t) : 0;
+    return D == 128 ? (int64_t)2 * n_q * T * 128 * (int64_t)sizeof(uint16_t) + (int64_t)n_q * T * (int64_t)sizeof(float) : 0;   // dK / dV partials + lse in log2 units
 }
 
 // D = 128 backward over segments: dQ (+ delta), per-head dK and dV partials, group reduce
@@ -1195,13 +1328,14 @@ static int attn_bwd128_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, i
     if (!workspace || workspace_bytes < st_attn_bwd_workspace_bytes(T, n_q, 128)) return ST_EINVAL;
     uint16_t* part_k = (uint16_t*)workspace;
     uint16_t* part_v = part_k + (int64_t)n_q * T * 128;
+    float* lse2 = (float*)(part_v + (int64_t)n_q * T * 128);       // written by the dQ kernel (with delta), read by the dK / dV kernels
     const dim3 gq(st_cdiv(max_seg, Q_TILE), n_q, n_seg), gkv(st_cdiv(max_seg, 128), n_q, n_seg);
 #define ST_BWD2(CC)                                                                                                            \
     hipLaunchKernelGGL((attn_bwd128_dq_kernel<CC>), gq, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, out, ldo, lse,     \
-                       delta, seg_b, seg_e, pre_b, pre_e, T, n_q, n_kv, scale, dq, lddq);                                      \
-    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 0, 64, 2>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse,    \
+                       delta, lse2, seg_b, seg_e, pre_b, pre_e, T, n_q, n_kv, scale, dq, lddq);                                      \
+    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 0, 64, 2>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse2,   \
                        delta, seg_b, seg_e, dep_e, T, n_q, n_kv, scale, part_k);                                               \
-    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 1, 64, 2>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse,    \
+    hipLaunchKernelGGL((attn_bwd128_kv_kernel<CC, 1, 64, 2>), gkv, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dout, lddo, lse2,   \
                        delta, seg_b, seg_e, dep_e, T, n_q, n_kv, scale, part_v);                                               \
     hipLaunchKernelGGL(attn_bwd128_reduce_kernel, dim3(st_cdiv((int64_t)2 * n_kv * T * 16, 256)), dim3(256), 0, s, part_k,     \
                        part_v, t_end_ptr, t_end_val, T, n_kv, n_q / n_kv, dk, lddk, dv, lddv)

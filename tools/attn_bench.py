@@ -10,6 +10,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("ST_LIB"):                 # A/B a differently built library (tools/attn_ab.sh)
+    import spatialthinker_amd.lib as _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ["ST_LIB"])
 from spatialthinker_amd import ops  # noqa: E402
 
 

@@ -412,22 +412,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         const float m_new = fmaxf(m_i, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);          // m_i = -inf -> 0
-        // two elements per v_pk_fma_f32 / v_pk_add_f32: plain VALU instructions are paid in full next to the MFMAs
-        hw_f32x2_t rs2 = {0.f, 0.f};
-        const hw_f32x2_t sc2 = {scale_log2, scale_log2}, nm2 = {-m_use, -m_use};
+        float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                hw_f32x2_t x = {sacc[kb][r], sacc[kb][r + 1]};
-                x = __builtin_elementwise_fma(x, sc2, nm2);
-                x[0] = __builtin_amdgcn_exp2f(x[0]);
-                x[1] = __builtin_amdgcn_exp2f(x[1]);
-                sacc[kb][r] = x[0];
-                sacc[kb][r + 1] = x[1];
-                rs2 += x;
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], scale_log2, -m_use));
+                sacc[kb][r] = p;
+                rs += p;
             }
-        float rs = st_half_sum(rs2[0] + rs2[1]);
+        rs = st_half_sum(rs);
         l_i = l_i * alpha + rs;
         m_i = m_new;
         if (!__all(alpha == 1.f)) {
@@ -987,16 +981,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_dq_kernel(const uint16_t* 
             __builtin_amdgcn_sched_barrier(0);
             // P first (16 independent fma + exp chains), then ONE wave-uniform branch for the tiles that need a mask: with the test
             // inside the element loop hipcc wraps every element in its own exec-mask region and the exp latency is exposed 16 times
-            {
-                const hw_f32x2_t sc2 = {scale_log2, scale_log2}, nl2 = {-lse2, -lse2};
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    hw_f32x2_t x = {sacc[r], sacc[r + 1]};
-                    x = __builtin_elementwise_fma(x, sc2, nl2);
-                    sacc[r] = __builtin_amdgcn_exp2f(x[0]);
-                    sacc[r + 1] = __builtin_amdgcn_exp2f(x[1]);
-                }
-            }
+            for (int r = 0; r < 16; ++r) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -lse2));
             if (need_mask) {
                 const int key0 = kt0 + kb * 32 + 4 * half;
                 const int lim = causal_t ? min(Lc - 1, q_idx) : Lc - 1;                        // visible keys: key <= lim
@@ -1185,13 +1171,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kv_kernel(const uint16_t* 
             for (int g = 0; g < 4; ++g) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 8 * g + 4 * half);
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    hw_f32x2_t x = {sacc[4 * g + j], sacc[4 * g + j + 1]};
-                    const hw_f32x2_t sc2 = {scale_log2, scale_log2}, nl2 = {-l4[j], -l4[j + 1]};
-                    x = __builtin_elementwise_fma(x, sc2, nl2);
-                    sacc[4 * g + j] = __builtin_amdgcn_exp2f(x[0]);
-                    sacc[4 * g + j + 1] = __builtin_amdgcn_exp2f(x[1]);
-                }
+                for (int j = 0; j < 4; ++j) sacc[4 * g + j] = __builtin_amdgcn_exp2f(fmaf(sacc[4 * g + j], scale_log2, -l4[j]));
             }
             if (need_mask) {                                   // visible: lo <= qi < L with lo = the key's own row (causal; dependents lie behind Lk)
                 const int lo = k_ok ? (CAUSAL ? key_idx : 0) : 0x3fffffff;

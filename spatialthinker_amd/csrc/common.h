@@ -119,3 +119,13 @@ struct StProfScope {
 
 #define ST_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 static inline int st_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int st_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+

@@ -404,7 +404,8 @@ int st_decode_finish_norm(const float* slabs, int splits, const st_bf16* residua
     switch (splits) {
         case 1: ST_FN(1); break; case 2: ST_FN(2); break; case 3: ST_FN(3); break; case 4: ST_FN(4); break;
         case 5: ST_FN(5); break; case 6: ST_FN(6); break; case 7: ST_FN(7); break; case 8: ST_FN(8); break;
-        default: return ST_EINVAL;                          // decode_plan never splits deeper than 8
+        case 9: ST_FN(9); break; case 10: ST_FN(10); break; case 11: ST_FN(11); break; case 12: ST_FN(12); break;
+        default: return ST_EINVAL;                          // decode_plan never splits deeper than 12
     }
 #undef ST_FN
     ST_CHECK_LAUNCH();

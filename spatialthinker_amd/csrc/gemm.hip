@@ -380,19 +380,35 @@ static int launch_decode_tiles(int variant, int splits, const uint16_t* A, int64
 // wide outputs (gate/up, lm_head) stream W with one tile per workgroup and no split; narrow outputs (qkv, o, down) have too
 // few column tiles to fill 256 CUs and split K into ~256-512 workgroups.  A host-side autotuner may override the choice
 // through st_gemm_nt_decode_variant.
+// Split count of a one-workgroup-per-CU decode tile: whole rounds over the CUs, each costing its K-tiles plus ~20 K-tile steps of
+// prologue / fp32 slab epilogue (fitted on MI355X: 256x128 tile, 7B down projection at 256 / 512 rows: 78 / 86 us at 4 slices,
+// 53 / 93 at 9 — one full round beats 1.1 rounds by a third).
+static int decode_fill_split(int tiles, int kt, int max_sp) {
+    const int ncu = st_num_cus();
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= max_sp && kt / sp >= 4; ++sp) {
+        const double cost = (double)st_cdiv(tiles * sp, ncu) * (st_cdiv(kt, sp) + 20.0);
+        if (cost < best_cost - 1e-9) { best = sp; best_cost = cost; }
+    }
+    return best;
+}
+
 static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant, int* splits) {
     const int bm = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
     const bool wide = N >= 16384;
     const int mt = st_cdiv(M, 256);                          // 256-row tiles (2 for the 257..512-row decode batches)
     int v, bn, row_tiles = mt;
     if (bm == 64) { v = (wide || K >= 8192) ? 11 : 10; bn = v == 11 ? 128 : 64; }
-    else if (bm == 128) { v = wide ? 14 : 13; bn = wide ? 128 : 64; }
+    else if (bm == 128) { v = (wide || K >= 8192) ? 14 : 13; bn = v == 14 ? 128 : 64; }     // down at 128 rows: 128x128 x 9 slices 39 us vs 62
     else if (wide) {
         // 256x256 tiles are ~10 % faster per flop than 256x128 but quantise worse on 256 CUs: compare the last-round fill
         const int t18 = mt * st_cdiv(N, 256), t16 = mt * st_cdiv(N, 128);
         const double e18 = 1.1 * t18 / (double)(st_cdiv(t18, 256) * 256), e16 = t16 / (double)(st_cdiv(t16, 256) * 256);
         v = e18 >= e16 ? 18 : 16; bn = v == 18 ? 256 : 128;
     } else if (K >= 8192) { v = 16; bn = 128; }
+    else if (N >= 4096 && mt > 1) { v = 16; bn = 128; }                  // qkv at 257..512 rows: 36 us vs 48 (128x64 tiles), tools/decode_gemm_tune.py
+    else if (N >= 4096) { v = 14; bn = 128; row_tiles = st_cdiv(M, 128); }   // qkv at <= 256 rows: 25 us vs 34
     else { v = 13; bn = 64; row_tiles = st_cdiv(M, 128); }
     int sp = 1;
     if (!wide) {
@@ -401,6 +417,7 @@ static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant
         if (bm == 64 && sp < 4 && tiles <= 128) sp = 4;
         if (bm == 64 && K >= 8192) sp = 8;
         if (sp > 8) sp = 8;
+        if (bm >= 128) sp = decode_fill_split(tiles, K / 64, 12);       // fill whole rounds of CUs (tools/decode_gemm_tune.py, M = 128 / 256 / 512)
         while (sp > 1 && (K / 64) / sp < 4) --sp;                       // keep >= 4 K-tiles per slice
         while (sp > 1 && (int64_t)sp * M * N > scratch_elems) --sp;
         if (sp < 1) sp = 1;

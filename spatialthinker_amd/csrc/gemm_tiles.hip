@@ -757,15 +757,6 @@ extern "C" int st_gemm_set_workspace(void* ws, int64_t bytes) {
     return 0;
 }
 
-static int st_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
-    return n;
-}
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false, bool LE = false>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
@@ -933,6 +924,14 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
         case 20: DEC_GO(128, 256, 2, 4, 2);
         case 21: DEC_GO(64, 128, 1, 4, 2);
         case 22: DEC_GO(256, 192, 4, 2, 2);
+        // 28 = the training tile (256x256, mid-tile barrier schedule; bf16 outputs through the LDS-staged epilogue) with split-K slabs:
+        // 257..512-row decode batches have 2 row tiles, and few column tiles x many K-slices of this tile beat the 256x128 ring
+        case 28:
+            if (splits > 1 || splits < 0) return launch_tile<256, 256, 4, 2, 2, false, false, false, false, true>(A, lda, B, ldb, nullptr, nullptr, 0, nullptr, slabs, N, M, N, K, s, splits < 0 ? 1 : splits, (int64_t)M * N);
+            if (bias && res) return launch_tile<256, 256, 4, 2, 2, true, true, true, false, true, true>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);
+            if (bias) return launch_tile<256, 256, 4, 2, 2, true, false, true, false, true, true>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);
+            if (res) return launch_tile<256, 256, 4, 2, 2, false, true, true, false, true, true>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);
+            return launch_tile<256, 256, 4, 2, 2, false, false, true, false, true, true>(A, lda, B, ldb, bias, res, ldr, Cb, nullptr, ldc, M, N, K, s);
         default: return ST_EINVAL;
     }
 #undef DEC_GO

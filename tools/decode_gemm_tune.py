@@ -12,8 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialthinker_amd import ops  # noqa: E402
 from spatialthinker_amd.lib import lib  # noqa: E402
 
-SHAPES = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gateup", 37888, 3584), ("down", 3584, 18944), ("lmhead", 152064, 3584)]
-VARIANTS = {64: [10, 11, 12, 21], 128: [13, 14, 19, 20], 256: [16, 18, 22, 13, 14]}
+SHAPES = [("qkv", 4608, 3584), ("o", 3584, 3584), ("down", 3584, 18944)] if os.environ.get("ST_TUNE_NARROW") else [("qkv", 4608, 3584), ("o", 3584, 3584), ("gateup", 37888, 3584), ("down", 3584, 18944), ("lmhead", 152064, 3584)]
+VARIANTS = {64: [10, 11, 12, 21, 13, 14], 128: [13, 14, 19, 20, 16], 256: [16, 18, 28, 13, 14]}
+SPLITS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 18)
 
 
 def timeit(fn, n=32):
@@ -42,6 +43,7 @@ def main():
     scratch = torch.empty(64 << 20, dtype=torch.float32, device=dev)
     for M in Ms:
         bm = 64 if M <= 64 else (128 if M <= 128 else 256)
+        ops._wide_decode[0] = M > 256                       # 257..512-row decode batches: two 256-row tiles per projection
         for name, N, K in SHAPES:
             a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
             # the decode loop streams ~15 GB of weights per step: every layer's W arrives cold.  Rotate over enough copies of
@@ -63,7 +65,7 @@ def main():
             line = f"M={M:3d} {name:7s} N={N:6d} K={K:5d}: default plan {t0 * 1e6:7.1f}us ({gb / t0 / 1e3:4.2f} TB/s, err {e0:.1e}) |"
             best = (t0, "default")
             for v in [0] + VARIANTS[bm]:
-                for sp in ((1,) if v == 0 else (1, 2, 4, 8)):
+                for sp in ((1,) if v == 0 else SPLITS):
                     if sp > 1 and sp * M * N > scratch.numel():
                         continue
                     if sp > 1 and N > 40000:

@@ -159,6 +159,9 @@ int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int6
  * same bf16 rounding points as st_gemm_nt + st_swiglu_fwd (HF Qwen2MLP.forward), bit-identical to that pair. */
 int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
                           int M, int I, int K, st_stream_t stream);
+/* tuning entry for st_gemm_swiglu_decode: the same operation on an explicit tile (variant 1..7, see gemm_tiles.hip) */
+int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out,
+                                  int64_t ldc, int M, int I, int K, st_stream_t stream);
 /* tuning entry for the decode-shaped GEMM: explicit tile variant (10..18, see gemm_tiles.hip) and split-K count */
 int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
                               const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,

@@ -968,6 +968,27 @@ extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate
     return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, m_out, ldm, M, I, K, s, gu_out, ldgu);
 }
 
+/* tuning entry: the decode gate/up + SwiGLU GEMM on an explicit tile (tools/decode_swiglu_tune.py):
+ * 1 = 256x160 3 slots (8-column interleave)   2 = 256x192 2 slots   3 = 256x256 2 slots   4 = 256x256 mid-tile barrier (training tile)
+ * 5 = 256x192 mid-tile barrier   6 = 128x128 3 slots   7 = 64x128 3 slots */
+extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out,
+                                             int64_t ldc, int M, int I, int K, st_stream_t stream) {
+    if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+        ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 3: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 4: return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 5: return launch_tile_swiglu<256, 192, 4, 2, 2, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 6: return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 7: return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        default: return ST_EINVAL;
+    }
+}
+
 extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
                                      int M, int I, int K, st_stream_t stream) {
     if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||

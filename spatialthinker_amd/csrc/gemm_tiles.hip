@@ -34,11 +34,34 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
+// ST_GEMM_TRACE builds (tools/gemm_phase_trace.py, never the shipped library): wave 0 of every workgroup sums the shader-clock
+// cycles it spends between fixed points of the K loop and leaves the sums in st_gemm_trace_buf[workgroup][8].
+#ifdef ST_GEMM_TRACE
+__device__ unsigned long long* st_gemm_trace_ptr = nullptr;
+extern "C" int st_gemm_trace_set(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(st_gemm_trace_ptr), &buf, sizeof(buf)); }
+#define TR_DECL unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = 0
+#define TR_START() do { __builtin_amdgcn_sched_barrier(0); tr_prev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TR_POINT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tr_acc[i] += t_ - tr_prev; tr_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TR_FLUSH() do { if (st_gemm_trace_ptr && wave == 0 && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) st_gemm_trace_ptr[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + i_] = tr_acc[i_]; } } while (0)
+#else
+#define TR_DECL
+#define TR_START()
+#define TR_POINT(i)
+#define TR_FLUSH()
+#endif
+
 // LDS-DMA from inline asm (M0 = wave-uniform LDS destination, restored afterwards): hipcc does not know a copy is in flight.
 __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_dst_uniform) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit lane offset: no address arithmetic on the VALU
+__device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst_uniform) : "memory");
 }
 
 // Compile-time unrolled sched_group_barrier pattern (the builtin wants literal arguments): per slot one DS read, one MFMA,
@@ -99,8 +122,18 @@ struct TailArgs {
 // 32-byte slots of the 256-byte bank row.  hipcc has no memory operand for the transpose-read builtin and would drain every pending
 // LDS-DMA in front of it (s_waitcnt vmcnt(0) in the middle of each tile), so in these variants the LDS-DMA is issued from inline asm
 // (invisible to the compiler's wait insertion; the kernel's own counted waits order it) and placed by hand between MFMA chunks.
+// PP (8 waves, 2 slots): PING-PONG schedule.  Waves w and w + 4 share a SIMD (tools/probes/wave_simd_map.hip).  With the mid-tile
+// barrier both of them issue their MFMAs in the same phase and wait at the barrier in the same phase: a phase timer in wave 0
+// (tools/gemm_phase_trace.py) shows 37 % of a K-tile parked at the barrier, the matrix pipe idle.  Here the K-tile has four slots with a
+// barrier after each, and the two wave groups run the same program ONE SLOT APART, so in every slot one wave of a SIMD issues its 32
+// MFMAs of a k-step alone while the other does its LDS fragment reads / LDS-DMA issues / waits:
+//     group 0:  M0(t)  R0(t)  M1(t)  R1(t)  M0(t+1) ...        M_k = MFMAs of k-step k (fragments already in registers)
+//     group 1:  R1(t-1) M0(t) R0(t)  M1(t)  R1(t)   ...        R0  = read fragments (t, k1);  R1 = issue DMA(t+2) into slot t, read (t+1, k0)
+// Tile t+1 is published by the barrier that closes the slot in which group 0 runs M1(t) and group 1 R0(t): both wait for their own
+// copies there.  Slot t is refilled from R1(t) on, after both groups' reads of (t, k1) have returned (lgkmcnt(0) before their barrier).
+#define KMAJ_ANY(a, b) ((a) || (b))
 template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false,
-          bool MIDBAR = false, bool SW8 = false, bool LEPI = false, bool AS = false, bool BS = false>
+          bool MIDBAR = false, bool SW8 = false, bool LEPI = false, bool AS = false, bool BS = false, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -121,6 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     static_assert(!SW8 || SWIGLU, "SW8 is a flavour of the SwiGLU epilogue");
     static_assert(!LEPI || (BM == 256 && BN == 256 && NW == 8 && !SWIGLU), "LDS-staged epilogue: 256x256 tile, 8 waves");
     static_assert(!(AS || BS) || (MIDBAR && BM == 256 && BN == 256 && NW == 8 && !SWIGLU && STAGES == 2), "contraction-major operands: 256x256 mid-barrier tile");
+    static_assert(!PP || (MIDBAR && NW == 8 && STAGES == 2 && !KMAJ_ANY(AS, BS)), "ping-pong schedule: 8 waves, two LDS slots, row-major operands");
     constexpr bool KMAJ = AS || BS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -207,6 +241,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 
     const int frow = lane & 15, fk = lane >> 4;
     int slot = 0;
+    TR_DECL;
+    TR_START();
     auto tile_body = [&](int kt, auto prefetch_tag) {
         constexpr bool PREFETCH = decltype(prefetch_tag)::value;
         // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
@@ -217,8 +253,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             const int mine = (wave < A_INST % NW || A_INST % NW == 0 ? A_PER : A_PER - 1) + (wave < B_INST % NW || B_INST % NW == 0 ? B_PER : B_PER - 1);
             if (mine == PER_WAVE) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<PER_WAVE - 1>();
         }
+        TR_POINT(0);                                         // 0: waiting for this wave's copies of tile kt
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                       // keep LDS reads / DMA issue below the barrier
+        TR_POINT(1);                                         // 1: barrier (the other waves' copies / their reads of the slot)
         const char* la = smem + slot * STAGE;
         const char* lb = la + A_BYTES;
         // fragment double-buffering: the LDS reads of k-step s+1 are issued BEFORE the MFMAs of k-step s, so the ~130-cycle
@@ -239,6 +277,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         };
         load_frags(0, af[0], bfr[0]);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ST_GEMM_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TR_POINT(2);                                         // 2: fragment reads of k-step 0 issued and returned
+#endif
         // the LDS-DMA issues of the next K-tile (~100 cycles of issue each) are spread between the MFMAs of k-step 0 as well,
         // instead of sitting in front of them with the matrix pipe idle
         if constexpr (PREFETCH) {
@@ -258,11 +300,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             pin_schedule<0, SLOTS, BASE, EXTRA, PREFETCH ? PER_WAVE : 0>();
         }
         __builtin_amdgcn_sched_barrier(0);
+        TR_POINT(3);                                         // 3: DMA issues + MFMAs of k-step 0 + reads of k-step 1 (all issued)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][ni], af[1][mi], acc[ni][mi], 0, 0, 0);
+        TR_POINT(4);                                         // 4: MFMAs of k-step 1 issued
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     };
     constexpr bool BIG4 = MIDBAR && NW == 4 && TM == 8 && TN == 8;
@@ -476,16 +520,99 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_[ni], a_[mi], acc[ni][mi], 0, 0, 0);
         };
         constexpr int SLOTS = TM + TN, BASE = (TM * TN) / SLOTS, EXTRA = TM * TN - BASE * SLOTS;
+        if constexpr (PP) {
+            const int grp = wave >> 2;                       // 0: waves 0-3, 1: their SIMD partners 4-7
+            // LDS-DMA sources: wave-uniform 64-bit base (advanced per K-tile in SGPRs) + one lane-constant 32-bit offset per copy, so an
+            // issue costs no VALU instruction (plain VALU work of the partner wave takes issue slots from the MFMA wave)
+            const char* Abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
+            const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)n0 * ldb);
+            uint32_t aoff[A_PER], boff[B_PER];
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                const int inst = wave * A_PER + j, p2 = inst * 64 + lane, r = p2 >> 3, kc = (p2 & 7) ^ ((r >> 1) & 7);
+                aoff[j] = (uint32_t)min(r, M - 1 - m0) * (uint32_t)(lda * 2) + kc * 16;
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                const int inst = wave * B_PER + j, p2 = inst * 64 + lane, r = p2 >> 3, kc = (p2 & 7) ^ ((r >> 1) & 7);
+                boff[j] = (uint32_t)min(r, N - 1 - n0) * (uint32_t)(ldb * 2) + kc * 16;
+            }
+            const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
+            auto stage_pp = [&](int kt_, int slot_) {
+                const char* ab = Abase + (int64_t)kt_ * 128;
+                const char* bb = Bbase + (int64_t)kt_ * 128;
+                const uint32_t dst = smem32 + slot_ * STAGE;
+#pragma unroll
+                for (int j = 0; j < A_PER; ++j) glds16_saddr(ab, aoff[j], dst + (wave * A_PER + j) * 1024);
+#pragma unroll
+                for (int j = 0; j < B_PER; ++j) glds16_saddr(bb, boff[j], dst + A_BYTES + (wave * B_PER + j) * 1024);
+            };
+            if (nk > 1) stage(1, smem + STAGE);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (nk > 0) load_frags(smem, 0, af[0], bfr[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }          // group 1 runs one slot behind
+            TR_START();
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* cur = smem + (kt & 1) * STAGE;
+                const char* nxt = smem + ((kt + 1) & 1) * STAGE;
+                const bool has_next = kt + 1 < nk;
+                // ---- M0: MFMAs of k-step 0, alone on the SIMD
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(2);
+                mfmas(af[0], bfr[0]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                TR_POINT(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                TR_POINT(1);
+                // ---- R0: fragments of (kt, k-step 1); group 1 also waits here for its copies of tile kt+1
+                load_frags(cur, 1, af[1], bfr[1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (grp == 1 && has_next) wait_vmcnt<0>();
+                TR_POINT(2);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                TR_POINT(3);
+                // ---- M1: MFMAs of k-step 1; group 0 waits for its copies of tile kt+1 behind them
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(2);
+                mfmas(af[1], bfr[1]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 0 && has_next) wait_vmcnt<0>();
+                TR_POINT(4);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                TR_POINT(5);
+                // ---- R1: refill slot kt with tile kt+2 (every wave's reads of it have returned), fragments of (kt+1, k-step 0)
+                if (has_next) {
+                    if (kt + 2 < nk) stage_pp(kt + 2, kt & 1);
+                    load_frags(nxt, 0, af[0], bfr[0]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                TR_POINT(6);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                TR_POINT(7);
+            }
+            if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        } else {
         // prologue: tiles 0 and 1 in flight (tile 0 was issued above), fragments of (0, k-step 0) in registers
         if (nk > 1) { stage(1, smem + STAGE); wait_vmcnt<PER_WAVE>(); } else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (nk > 0) load_frags(smem, 0, af[0], bfr[0]);
+        TR_START();
         auto tile = [&](int kt, auto next_tag, auto dma_tag) {
             constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_DMA = decltype(dma_tag)::value;
             const char* cur = smem + (kt & 1) * STAGE;
             const char* nxt = smem + ((kt + 1) & 1) * STAGE;
             // phase A: MFMAs of k-step 0 with the reads of k-step 1 in their shadow
+            TR_POINT(4);                                     // 4: phase B of the previous tile (MFMAs k-step 1, reads, DMA issues)
             load_frags(cur, 1, af[1], bfr[1]);
             mfmas(af[0], bfr[0]);
             // the reads are spread over the first 5/8 of the phase's MFMAs so that the last of them has time to return before the
@@ -495,13 +622,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             pin_schedule<0, SLOTS, FBASE, FEXTRA, 0>();
             if constexpr (TM * TN > FRONT) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - FRONT, 0);
             __builtin_amdgcn_sched_barrier(0);
+            TR_POINT(0);                                     // 0: phase A issued (MFMAs of k-step 0 + reads of k-step 1)
             if constexpr (HAS_NEXT) {
                 wait_vmcnt<0>();                             // tile kt+1 (issued one tile ago) has landed
+                TR_POINT(1);                                 // 1: waiting for this wave's copies of tile kt+1
                 // the fragment reads of slot kt must have RETURNED (not merely been issued) before another wave's LDS-DMA may refill
                 // the slot; the k-step-1 MFMAs behind the barrier need them anyway, so the wait costs nothing here
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                TR_POINT(2);                                 // 2: fragment reads returned
                 __builtin_amdgcn_s_barrier();                // ... for every wave, and every wave is done reading slot kt
                 asm volatile("" ::: "memory");
+                TR_POINT(3);                                 // 3: barrier
                 if constexpr (HAS_DMA) stage(kt + 2, smem + (kt & 1) * STAGE);
                 load_frags(nxt, 0, af[0], bfr[0]);           // phase B: reads of (kt+1, k-step 0) under the MFMAs of (kt, k-step 1)
             }
@@ -513,8 +644,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{}, std::true_type{});
         if (kt + 1 < nk) { tile(kt, std::true_type{}, std::false_type{}); ++kt; }
         if (kt < nk) tile(kt, std::false_type{}, std::false_type{});
+        }
     }
 
+    TR_FLUSH();
     if constexpr (!SWIGLU) {
         if (piece >= 0) {                                    // K-slice of a tail tile: accumulators to the workspace, fragment order
             float4* wp = reinterpret_cast<float4*>(tail.ws) + ((int64_t)(piece * NW + wave) * (TN * TM)) * 64 + lane;
@@ -758,12 +891,12 @@ extern "C" int st_gemm_set_workspace(void* ws, int64_t bytes) {
 }
 
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false, bool LE = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false, bool LE = false, bool PP_ = false>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
                        int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s, int splits = 1,
                        int64_t slab_stride = 0) {
     constexpr int smem = LE ? (STAGES * (BM + BN) * 128 > 256 * 528 ? STAGES * (BM + BN) * 128 : 256 * 528) : STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB, false, LE>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB, false, LE, false, false, PP_>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -865,17 +998,18 @@ extern "C" int st_gemm_tn(const st_bf16* A, int64_t lda, const st_bf16* B, int64
 int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
                           const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K,
                           hipStream_t s) {
-#define TILE_GO(BM, BN, WM, WN, ST, MB) TILE_GO_LE(BM, BN, WM, WN, ST, MB, false)
-#define TILE_GO_LE(BM, BN, WM, WN, ST, MB, LE)                                                                                   \
+#define TILE_GO(BM, BN, WM, WN, ST, MB) TILE_GO_PP(BM, BN, WM, WN, ST, MB, false, false)
+#define TILE_GO_LE(BM, BN, WM, WN, ST, MB, LE) TILE_GO_PP(BM, BN, WM, WN, ST, MB, LE, false)
+#define TILE_GO_PP(BM, BN, WM, WN, ST, MB, LE, PPV)                                                                                   \
     do {                                                                                                                         \
         if (Cb) {                                                                                                                \
-            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
-            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
-            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
-            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
+            if (bias && res) return launch_tile<BM, BN, WM, WN, ST, true, true, true, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);   \
+            if (bias) return launch_tile<BM, BN, WM, WN, ST, true, false, true, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);         \
+            if (res) return launch_tile<BM, BN, WM, WN, ST, false, true, true, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);          \
+            return launch_tile<BM, BN, WM, WN, ST, false, false, true, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                  \
         }                                                                                                                        \
-        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
-        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB, LE>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
+        if (accumulate) return launch_tile<BM, BN, WM, WN, ST, false, false, false, true, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);      \
+        return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
     } while (0)
     switch (variant) {
         case 0: TILE_GO(128, 128, 2, 2, 2, false);
@@ -889,10 +1023,12 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
         case 8: TILE_GO(256, 256, 2, 2, 2, true);          // 4 waves x (128 x 128): one wave per SIMD, accumulators fill the AGPRs
         case 9: TILE_GO(256, 256, 2, 2, 2, false);
         case 23: TILE_GO_LE(256, 256, 4, 2, 2, true, true);   // variant 6 with the LDS-staged epilogue
+        case 31: TILE_GO_PP(256, 256, 4, 2, 2, true, true, true);   // variant 23 on the ping-pong schedule
         default: return ST_EINVAL;
     }
 #undef TILE_GO
 #undef TILE_GO_LE
+#undef TILE_GO_PP
 }
 
 // Decode-shaped launches (M <= 256 rows, weight streaming): small-M tiles with a 3-slot ring and optional split-K into fp32

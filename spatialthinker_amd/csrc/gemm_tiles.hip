@@ -12,11 +12,29 @@
 // 2.5 PF MFMA peak — above the ~34 TB/s aggregate L2 bandwidth; 256x128 needs 29 TB/s, 256x256 19.5 TB/s.
 #include "common.h"
 #include <type_traits>
+#ifndef ST_DMA_RUNS
+#define ST_DMA_RUNS 1
+#endif
 #include <stdlib.h>
 
 __device__ __forceinline__ void glds16t(const void* gsrc, char* lds_dst_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+// Copy J of a wave's run of consecutive 1-KiB pieces: the 1024*J bytes go into the instruction's immediate offset (which the hardware
+// adds to BOTH the global and the LDS address), so the run shares ONE M0 value; gsrc is the piece's true source address.
+template <int J> __device__ __forceinline__ void glds16_run(const void* gsrc, char* lds_run_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(gsrc) - J * 1024),
+                                     (__attribute__((address_space(3))) void*)lds_run_base, 16, J * 1024, 0);
+}
+__device__ __forceinline__ void glds16_run_j(int j, const void* gsrc, char* lds_run_base) {
+    switch (j) {
+        case 0: glds16_run<0>(gsrc, lds_run_base); break;
+        case 1: glds16_run<1>(gsrc, lds_run_base); break;
+        case 2: glds16_run<2>(gsrc, lds_run_base); break;
+        default: glds16_run<3>(gsrc, lds_run_base); break;
+    }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -34,15 +52,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-// ST_GEMM_TRACE builds (tools/gemm_phase_trace.py, never the shipped library): wave 0 of every workgroup sums the shader-clock
-// cycles it spends between fixed points of the K loop and leaves the sums in st_gemm_trace_buf[workgroup][8].
+// ST_GEMM_TRACE builds (tools/gemm_phase_trace.py, never the shipped library): every wave sums the shader-clock cycles it
+// spends between fixed points of the K loop and leaves the sums in st_gemm_trace_ptr[workgroup][wave][8].
 #ifdef ST_GEMM_TRACE
 __device__ unsigned long long* st_gemm_trace_ptr = nullptr;
 extern "C" int st_gemm_trace_set(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(st_gemm_trace_ptr), &buf, sizeof(buf)); }
 #define TR_DECL unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = 0
 #define TR_START() do { __builtin_amdgcn_sched_barrier(0); tr_prev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TR_POINT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tr_acc[i] += t_ - tr_prev; tr_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define TR_FLUSH() do { if (st_gemm_trace_ptr && wave == 0 && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) st_gemm_trace_ptr[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + i_] = tr_acc[i_]; } } while (0)
+#define TR_FLUSH() do { if (st_gemm_trace_ptr && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) st_gemm_trace_ptr[((blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 + i_] = tr_acc[i_]; } } while (0)
 #else
 #define TR_DECL
 #define TR_START()
@@ -188,7 +206,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             if (!EVEN_DMA && inst >= A_INST) break;
             const int p = inst * 64 + lane, r = p >> 3, cpos = p & 7, kc = cpos ^ ((r >> 1) & 7);
             int gr = m0 + r; gr = gr < M ? gr : M - 1;
-            glds16t(A + (int64_t)gr * lda + kt * 64 + kc * 8, dst + inst * 1024);
+            if constexpr (EVEN_DMA && A_PER <= 4 && ST_DMA_RUNS) glds16_run_j(j, A + (int64_t)gr * lda + kt * 64 + kc * 8, dst + wave * A_PER * 1024);
+            else glds16t(A + (int64_t)gr * lda + kt * 64 + kc * 8, dst + inst * 1024);
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
@@ -208,7 +227,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             } else {
                 gr = n0 + r; gr = gr < N ? gr : N - 1;
             }
-            glds16t(B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + inst * 1024);
+            if constexpr (EVEN_DMA && B_PER <= 4 && ST_DMA_RUNS) glds16_run_j(j, B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + wave * B_PER * 1024);
+            else glds16t(B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + inst * 1024);
         }
     };
 
@@ -538,14 +558,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                 boff[j] = (uint32_t)min(r, N - 1 - n0) * (uint32_t)(ldb * 2) + kc * 16;
             }
             const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
-            auto stage_pp = [&](int kt_, int slot_) {
-                const char* ab = Abase + (int64_t)kt_ * 128;
-                const char* bb = Bbase + (int64_t)kt_ * 128;
+            // copy j of tile kt_ (j < A_PER: A piece, else B piece) into slot_
+            auto dma_pp = [&](int kt_, int slot_, int j) {
                 const uint32_t dst = smem32 + slot_ * STAGE;
+                if (j < A_PER) glds16_saddr(Abase + (int64_t)kt_ * 128, aoff[j], dst + (wave * A_PER + j) * 1024);
+                else glds16_saddr(Bbase + (int64_t)kt_ * 128, boff[j - A_PER], dst + A_BYTES + (wave * B_PER + j - A_PER) * 1024);
+            };
+            constexpr int DMA_R1 = PER_WAVE / 2;             // copies issued in R1(kt); the rest ride between the MFMAs of M0(kt+1)
+            auto mfmas_dma = [&](bf16x8 (&a_)[TM], bf16x8 (&b_)[TN], int kt_, int slot_, bool on) {
+                // MFMAs in source order with one LDS-DMA issue after every (TM*TN / (PER_WAVE - DMA_R1))-th of them: a burst of issues
+                // would park the wave (in-order issue) behind the texture addresser while the matrix pipe drains
+                constexpr int NREST = PER_WAVE - DMA_R1, EVERY = (TM * TN) / NREST;
 #pragma unroll
-                for (int j = 0; j < A_PER; ++j) glds16_saddr(ab, aoff[j], dst + (wave * A_PER + j) * 1024);
-#pragma unroll
-                for (int j = 0; j < B_PER; ++j) glds16_saddr(bb, boff[j], dst + A_BYTES + (wave * B_PER + j) * 1024);
+                for (int idx = 0; idx < TM * TN; ++idx) {
+                    const int ni = idx / TM, mi = idx % TM;
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ni][mi]) : "v"(b_[ni]), "v"(a_[mi]));
+                    if (idx % EVERY == EVERY / 2 && idx / EVERY < NREST && on) dma_pp(kt_, slot_, DMA_R1 + idx / EVERY);
+                }
             };
             if (nk > 1) stage(1, smem + STAGE);
             wait_vmcnt<0>();
@@ -559,10 +588,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                 const char* cur = smem + (kt & 1) * STAGE;
                 const char* nxt = smem + ((kt + 1) & 1) * STAGE;
                 const bool has_next = kt + 1 < nk;
-                // ---- M0: MFMAs of k-step 0, alone on the SIMD
+                // ---- M0: MFMAs of k-step 0, alone on the SIMD; the second half of tile kt+1's copies (slot kt-1 is free since R1(kt-1))
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(2);
-                mfmas(af[0], bfr[0]);
+                mfmas_dma(af[0], bfr[0], kt + 1, (kt + 1) & 1, kt >= 1 && has_next);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 TR_POINT(0);
@@ -590,7 +619,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
                 TR_POINT(5);
                 // ---- R1: refill slot kt with tile kt+2 (every wave's reads of it have returned), fragments of (kt+1, k-step 0)
                 if (has_next) {
-                    if (kt + 2 < nk) stage_pp(kt + 2, kt & 1);
+                    if (kt + 2 < nk) {
+#pragma unroll
+                        for (int j = 0; j < DMA_R1; ++j) dma_pp(kt + 2, kt & 1, j);
+                    }
                     load_frags(nxt, 0, af[0], bfr[0]);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }

@@ -2,6 +2,9 @@
 rounds in one process (median of 7): python tools/gemm_epi_ab.py [T]"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("ST_LIB"):
+    import spatialthinker_amd.lib as _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ["ST_LIB"])
 from spatialthinker_amd import ops
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 10496
 VA, VB = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (6, 23)

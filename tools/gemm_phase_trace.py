@@ -19,13 +19,14 @@ NAMES_RING = ["wait copies", "barrier", "frag reads k0 (exposed)", "DMA issue + 
 NAMES_MID = ["phase A issue (MFMA k0 + reads k1)", "wait copies", "frag reads returned", "barrier", "phase B (MFMA k1 + reads + DMA issue)"]
 
 
-def report(title, buf, n_wg, nk, names, flops_per_ktile_wave):
+def report(title, buf, n_wg, nk, names, flops_per_ktile_wave, nw=8):
     torch.cuda.synchronize()
-    t = buf[:n_wg * 8].view(n_wg, 8).double().mean(0).cpu().numpy()
-    tot = t[:5].sum()
-    print(f"{title}: {tot / nk:7.0f} cycles per K-tile per wave (MFMA-only time of the SIMD's two waves: {2 * flops_per_ktile_wave / 1024:.0f})")
+    t = buf[:n_wg * nw * 8].view(n_wg, nw, 8).double().mean(0).cpu().numpy() / nk        # [wave][point]
+    tot = t[:, :len(names)].sum(1)
+    print(f"{title}: {tot.mean():7.0f} cycles per K-tile per wave (MFMA-only time of the SIMD's two waves: {2 * flops_per_ktile_wave / 1024:.0f})")
+    print("    " + " " * 42 + "".join(f"   wave{w}" for w in range(nw)))
     for i, nm in enumerate(names):
-        print(f"    {nm:42s} {t[i] / nk:7.0f} cycles  {100 * t[i] / tot:5.1f} %")
+        print(f"    {nm:42s}" + "".join(f"{t[w, i]:8.0f}" for w in range(nw)))
 
 
 def main():
@@ -64,10 +65,8 @@ def main():
         buf.zero_()
         ops.gemm_nt_variant(31, a, w, out=out)
     torch.cuda.synchronize()
-    t = buf[:n_wg * 8].view(n_wg, 8).double().mean(0).cpu().numpy() / (K // 64)
-    print(f"ping-pong schedule (variant 31), wave 0 (group 0): {t.sum():.0f} cycles per K-tile")
-    for nm, v in zip(["M0 issue", "barrier", "R0 reads (+ wait copies, group 1)", "barrier", "M1 issue (+ wait copies, group 0)", "barrier", "R1 DMA issue + reads", "barrier"], t):
-        print(f"    {nm:42s} {v:7.0f} cycles")
+    report("ping-pong schedule (variant 31)", buf, n_wg, K // 64, ["M0 issue", "barrier", "R0 reads (+ wait copies, group 1)", "barrier",
+           "M1 issue (+ wait copies, group 0)", "barrier", "R1 DMA issue + reads", "barrier"], 64 * 128 * 64 * 2)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdint.h>
 
+// MODE 3 / 4: LDS-DMA / registers with the ROW-STRIDED pattern of a GEMM operand tile: a copy = 8 rows x 128 B, rows PITCH bytes apart
+#define PITCH 7168
 template <int MODE, int DEPTH>   // MODE 0: DMA   1: registers + ds_write   2: alternate copies between the two paths
 __global__ __launch_bounds__(512) void fill(const char* __restrict__ src, int iters, int window, float* sink) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -18,13 +20,14 @@ __global__ __launch_bounds__(512) void fill(const char* __restrict__ src, int it
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const char* p = src + ((off + d * 1024) & (uint32_t)(window - 1));
-            const bool dma = MODE == 0 || (MODE == 2 && (d & 1) == 0);
+            if (MODE >= 3) p = src + ((((off >> 10) + d * 8) * PITCH) & (uint32_t)(window - 1) & ~127u) + (lane >> 3) * PITCH + (lane & 7) * 16;
+            const bool dma = MODE == 0 || MODE == 3 || (MODE == 2 && (d & 1) == 0);
             if (dma) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)(mine + d * 1024), 16, 0, 0);
             else r[d] = *reinterpret_cast<const uint4*>(p);
         }
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            const bool dma = MODE == 0 || (MODE == 2 && (d & 1) == 0);
+            const bool dma = MODE == 0 || MODE == 3 || (MODE == 2 && (d & 1) == 0);
             if (!dma) *reinterpret_cast<uint4*>(mine + d * 1024 + lane * 16) = r[d];
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -51,13 +54,15 @@ static void run(const char* src, float* sink, int window, const char* name) {
 int main() {
     const int window = 2 << 20;
     char* src; float* sink;
-    hipMalloc(&src, window); hipMemset(src, 1, window); hipMalloc(&sink, 4);
+    hipMalloc(&src, window + 16 * PITCH); hipMemset(src, 1, window + 16 * PITCH); hipMalloc(&sink, 4);
     printf("L2-resident source (2 MiB window), 256 workgroups x 8 waves:\n");
     run<0, 4>(src, sink, window, "LDS-DMA");        run<0, 8>(src, sink, window, "LDS-DMA");        run<0, 16>(src, sink, window, "LDS-DMA");
     run<1, 4>(src, sink, window, "registers + ds_write_b128"); run<1, 8>(src, sink, window, "registers + ds_write_b128"); run<1, 16>(src, sink, window, "registers + ds_write_b128");
     run<2, 4>(src, sink, window, "alternating");    run<2, 8>(src, sink, window, "alternating");    run<2, 16>(src, sink, window, "alternating");
+    run<3, 4>(src, sink, window, "LDS-DMA, row-strided");  run<3, 8>(src, sink, window, "LDS-DMA, row-strided");  run<3, 16>(src, sink, window, "LDS-DMA, row-strided");
+    run<4, 8>(src, sink, window, "registers, row-strided");
     const int big = 1 << 30;
-    char* src2; hipMalloc(&src2, big); hipMemset(src2, 1, big);
+    char* src2; hipMalloc(&src2, (size_t)big + 16 * PITCH); hipMemset(src2, 1, (size_t)big + 16 * PITCH);
     printf("HBM source (1 GiB window):\n");
     run<0, 8>(src2, sink, big, "LDS-DMA");  run<0, 16>(src2, sink, big, "LDS-DMA");
     run<1, 8>(src2, sink, big, "registers + ds_write_b128");  run<1, 16>(src2, sink, big, "registers + ds_write_b128");

@@ -274,6 +274,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
     const int qc = lane & 31, half = lane >> 5;
     const int q_idx = q_base + wave * 32 + qc;
     const bool q_ok = q_idx < Lq;
+    // An item without keys (decode: the chunks of a sample's cache beyond its current length — three of four items of the generated
+    // partials for most of a rollout) leaves lse = -inf, which is all st_attn_merge looks at, and is gone before it touches Q: the
+    // launch used to spend most of its time on ~2.5 us of Q loads and zero stores per empty workgroup, 16 of them per CU.
+    if ((CAUSAL ? min(L, q_base + Q_TILE) : L) <= 0 && (!pre_beg || pre_end[seq] - pre_beg[seq] <= 0)) {
+        if (q_ok && half == 0) lse[(int64_t)h * T + (o_beg ? o_beg[seq] : s0) + q_idx] = -INFINITY;
+        return;
+    }
 
     bf16x8 qf[8];
     {

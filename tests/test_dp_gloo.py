@@ -1,4 +1,4 @@
-"""World-size-2 CPU (gloo) tests of the data-parallel path: the bucketed gradient all-reduce + averaging that replaces FSDP's
+"""World-size-2 and -4 CPU (gloo) tests of the data-parallel path: the bucketed gradient all-reduce + averaging that replaces FSDP's
 reduce-scatter, rank sharding of the rollout batch, and cross-rank metric gathering."""
 import os
 import socket
@@ -36,14 +36,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_bucketed_grad_allreduce_averages_over_ranks(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_grad_allreduce_averages_over_ranks(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     want = sum(torch.randn(1_000_003, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
     for r in range(world):
         got = torch.load(tmp_path / f"g{r}.pt")
         torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7)
-        assert torch.load(tmp_path / f"m{r}.pt") == [{"rank": 0, "loss": 0.0}, {"rank": 1, "loss": 0.5}]
+        assert torch.load(tmp_path / f"m{r}.pt") == [{"rank": q, "loss": 0.5 * q} for q in range(world)]
 
 
 def _overlap_worker(rank, world, port, out_dir):
@@ -70,9 +70,9 @@ def _overlap_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_early_slices_plus_remainder_equal_one_full_allreduce(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_early_slices_plus_remainder_equal_one_full_allreduce(tmp_path, world):
     """GradReducer: slices sent while backward is still running + the remainder sent by finish() = the plain averaged all-reduce."""
-    world = 2
     mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     want = sum(torch.randn(700_001, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)) / world
     for r in range(world):

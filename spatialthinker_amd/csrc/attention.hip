@@ -282,17 +282,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         return;
     }
 
-    bf16x8 qf[8];
-    {
-        const int64_t R = s0 + (q_ok ? q_idx : 0);
-        const uint16_t* qp = qgroup > 0 ? q + (R / qgroup) * ldq + ((int64_t)h * qgroup + R % qgroup) * D + half * 8
-                                        : q + R * ldq + (int64_t)h * D + half * 8;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            uint4 r = q_ok ? *reinterpret_cast<const uint4*>(qp + s * 16) : make_uint4(0, 0, 0, 0);
-            qf[s] = *reinterpret_cast<bf16x8*>(&r);
-        }
-    }
     f32x16 o[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -359,6 +348,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         for (int j = 0; j < 4; ++j) st_glds16(vt + voff[j], dst + F2_V_OFF + (wave * 4 + j) * 1024);
     };
     if (n_tiles > 0) stage_any(0, smem);
+    // Q after the first tile's copies are on their way: the two latencies overlap (a decode item is ~5 us of prologue + 3.3 us per tile)
+    bf16x8 qf[8];
+    {
+        const int64_t R = s0 + (q_ok ? q_idx : 0);
+        const uint16_t* qp = qgroup > 0 ? q + (R / qgroup) * ldq + ((int64_t)h * qgroup + R % qgroup) * D + half * 8
+                                        : q + R * ldq + (int64_t)h * D + half * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 r = q_ok ? *reinterpret_cast<const uint4*>(qp + s * 16) : make_uint4(0, 0, 0, 0);
+            qf[s] = *reinterpret_cast<bf16x8*>(&r);
+        }
+    }
 #ifdef FWD_SKEW
     {   // experiment: start the two co-resident waves of a SIMD half a tile period apart (attention)
         uint32_t hwid;

@@ -9,7 +9,7 @@ from spatialthinker_amd.rollout import Generator
 LEN = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 npr = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-cfg = VLConfig.qwen2_5_vl_7b()
+cfg = VLConfig.qwen2_5_vl_3b() if os.environ.get("ST_MODEL") == "3b" else VLConfig.qwen2_5_vl_7b()
 st = ParamStore(cfg, trainable=False); st.init_random(1)
 gen = Generator(Qwen25VL(cfg, st))
 rs = np.random.RandomState(0)

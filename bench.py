@@ -18,6 +18,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL across processes)
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -9,6 +9,8 @@ import os
 import subprocess
 import sys
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL across processes)
+
 
 def _maybe_spawn(n_gpus: int) -> bool:
     if "RANK" in os.environ or n_gpus <= 1:

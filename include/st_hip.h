@@ -166,6 +166,12 @@ int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int64_t lda, co
 int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
                               const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,
                               float* scratch, int64_t scratch_elems, int M, int N, int K, st_stream_t stream);
+/* Inspection entries (no launch, host only): the (tile variant, split-K count) st_gemm_nt_skinny / st_gemm_nt_decode_slabs pick for a
+ * decode-shaped GEMM of this size, and the tile id (st_gemm_swiglu_decode_variant numbering) st_gemm_swiglu_decode picks — the
+ * production-shape parity tests assert that the 7B plans (128x128 / 256x128 / 256x256 tiles, the 256x160 SwiGLU tile, split-K >= 4)
+ * are the ones under test.  Variant ids: gemm_tiles.hip (st_gemm_tile_decode). */
+int st_gemm_decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant_out, int* splits_out);
+int st_gemm_swiglu_decode_plan(int M, int I, int* variant_out);
 /* out (C, R) = in (R, C)^T, bf16 (operand re-layout for the backward GEMMs). */
 int st_transpose(const st_bf16* in, int64_t ldin, st_bf16* out, int64_t ldout, int R, int C, st_stream_t stream);
 /* column sums: out_f32 (C,) (+)= sum_r in[r, c]  (bias gradients). */

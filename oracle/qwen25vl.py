@@ -75,7 +75,7 @@ def mrope_cos_sin(position_ids: torch.Tensor, head_dim: int, theta: float, secti
     """HF :525-538 (rotary_emb.forward) + :557-599 (section select): position_ids (3,T) ->
     cos, sin (T, head_dim) with the frequency band i taking its angle from row
     [t,h,w][chunk(i) % 3], chunks = section*2 over the duplicated (freqs, freqs) layout."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    inv_freq = (1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))).to(position_ids.device)
     freqs = position_ids.to(torch.float32)[:, :, None] * inv_freq[None, None, :]   # (3,T,hd/2)
     emb = torch.cat((freqs, freqs), dim=-1)                                        # (3,T,hd)
     cos, sin = emb.cos(), emb.sin()
@@ -105,7 +105,7 @@ def dense_attention(q, k, v, cu_seqlens, causal: bool):
         s = torch.matmul(qs, ks.transpose(1, 2)) * scale
         if causal:
             L = b - a
-            s = s.masked_fill(torch.ones(L, L, dtype=torch.bool).triu(1), float("-inf"))
+            s = s.masked_fill(torch.ones(L, L, dtype=torch.bool, device=s.device).triu(1), float("-inf"))
         out[a:b] = torch.matmul(torch.softmax(s, dim=-1), vs).transpose(0, 1)
     return out
 
@@ -233,7 +233,7 @@ def lm_layer_decode(p, cfg: VLConfig, i: int, x: torch.Tensor, cos: torch.Tensor
     v = (h @ p[b_ + "self_attn.v_proj.weight"].t() + p[b_ + "self_attn.v_proj.bias"]).reshape(B, cfg.num_kv_heads, D)
     q = q * c + rotate_half(q) * s_
     k = k * c + rotate_half(k) * s_
-    ar = torch.arange(B)
+    ar = torch.arange(B, device=x.device)
     k_cache[ar, lens] = k
     v_cache[ar, lens] = v
     rep = cfg.num_heads // cfg.num_kv_heads
@@ -241,7 +241,7 @@ def lm_layer_decode(p, cfg: VLConfig, i: int, x: torch.Tensor, cos: torch.Tensor
     ks = k_cache[:, :S].repeat_interleave(rep, dim=2)                       # (B, S, Hq, D)
     vs = v_cache[:, :S].repeat_interleave(rep, dim=2)
     sc = torch.einsum("bhd,bshd->bhs", q, ks) / math.sqrt(D)
-    sc = sc.masked_fill(torch.arange(S)[None, None, :] > lens[:, None, None], float("-inf"))
+    sc = sc.masked_fill(torch.arange(S, device=x.device)[None, None, :] > lens[:, None, None], float("-inf"))
     a = torch.einsum("bhs,bshd->bhd", torch.softmax(sc, dim=-1), vs).reshape(B, -1)
     x = x + a @ p[b_ + "self_attn.o_proj.weight"].t()
     h = rms_norm(x, p[b_ + "post_attention_layernorm.weight"], cfg.rms_eps)

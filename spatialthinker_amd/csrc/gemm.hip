@@ -425,6 +425,15 @@ static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant
     *variant = v; *splits = sp;
 }
 
+extern "C" int st_gemm_decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant_out, int* splits_out) {
+    if (M <= 0 || M > ST_DECODE_MAX_ROWS || N <= 0 || K <= 0 || (K % BK) || !variant_out || !splits_out) return ST_EINVAL;
+    int v, sp;
+    decode_plan(M, N, K, scratch_elems, &v, &sp);
+    const int kt_per = st_cdiv(K / 64, sp);
+    *variant_out = v; *splits_out = st_cdiv(K / 64, kt_per);             // slices actually launched
+    return 0;
+}
+
 /* tuning entry: explicit tile variant (st_gemm_tile_decode ids) and split count for a decode-shaped GEMM */
 extern "C" int st_gemm_nt_decode_variant(int variant, int splits, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb,
                                          const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, int64_t ldc,

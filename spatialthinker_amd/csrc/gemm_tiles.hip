@@ -1157,24 +1157,39 @@ extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int6
     }
 }
 
+// Tile choice of the decode gate/up + SwiGLU GEMM (ids of st_gemm_swiglu_decode_variant).
+// One row tile (M <= 256) or two (257..512): the only freedom is the column tile.  Cost ~ rounds over 256 CUs x tile width; the 7B
+// gate/up (I = 18944) gives 148 tiles at 128 output columns (0.58 of the CUs) and 198 at 96 (-10 % time).  A 256x160 tile as 8x1
+// waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
+// 256x160 with the 8-column interleave (id 1): 3-slot ring (two K-tiles of weights in flight: the 2-slot variants sit parked on HBM
+// latency half of the time) and 237 workgroups for I = 18944: 90 us vs 102 us (256x192) on MI355X.
+static int swiglu_decode_plan(int M, int I) {
+    if (M <= 64) return 7;
+    if (M <= 128) return 6;
+    auto cost = [&](int cols) { const int t = st_cdiv(M, 256) * st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
+    if (cost(80) <= cost(96) && cost(80) <= cost(128)) return 1;
+    if (cost(96) <= cost(128)) return 2;
+    return 3;
+}
+extern "C" int st_gemm_swiglu_decode_plan(int M, int I, int* variant_out) {
+    if (M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || !variant_out) return ST_EINVAL;
+    *variant_out = swiglu_decode_plan(M, I);
+    return 0;
+}
+
 extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
                                      int M, int I, int K, st_stream_t stream) {
     if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
         ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 64) return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
-    if (M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
-    // One row tile (M <= 256): the only freedom is the column tile.  Cost ~ rounds over 256 CUs x tile width; the 7B gate/up
-    // (I = 18944) gives 148 tiles at 128 output columns (0.58 of the CUs) and 198 at 96 (-10 % time).  A 256x160 tile as 8x1
-    // waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
-    auto cost = [&](int cols) { const int t = st_cdiv(M, 256) * st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
-    // 256x160 with the 8-column interleave: 3-slot ring (two K-tiles of weights in flight: the 2-slot variants sit parked on HBM
-    // latency half of the time) and 237 workgroups for I = 18944
-    if (cost(80) <= cost(96) && cost(80) <= cost(128))                                         // 90 us vs 102 us (256x192) on MI355X
-        return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
-    if (cost(96) <= cost(128)) return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
-    return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    switch (swiglu_decode_plan(M, I)) {
+        case 7: return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 6: return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        default: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    }
 }
 
 extern "C" int st_gemm_nt_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,

@@ -153,7 +153,6 @@ def _skinny_scratch(device):
     return _scratch[key]
 
 
-_wide_decode = [False]            # set by the generator while it decodes more than 256 rows at once (257..512-row GEMMs use the decode plans)
 # (M, N, K) -> (tile variant, split-K count) chosen by autotune_decode_gemm; empty = library defaults everywhere
 _decode_plans = {}
 _DECODE_CANDIDATES = {64: (10, 11, 12, 21), 128: (13, 14, 19, 20), 256: (13, 14, 16, 18)}
@@ -239,15 +238,17 @@ def gemm_tail_split(enable: bool, device="cuda"):
     lib().st_gemm_set_workspace(_p(ws) if enable else None, ws.numel() if (enable and ws is not None) else 0)
 
 
-def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulate=False):
-    """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(+residual).  Returns bf16 `out` (allocated if needed) unless `out_f32` given."""
+def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulate=False, decode=False):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(+residual).  Returns bf16 `out` (allocated if needed) unless `out_f32` given.
+    decode=True (the rollout generator's call sites only): 257..512-row GEMMs also take the weight-streaming decode plans; every
+    other caller gets st_gemm_nt above 256 rows, whatever ran before in the process."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K, (a.shape, b.shape)
     if out_f32 is None and out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
-    if out_f32 is None and (M <= 256 or (_wide_decode[0] and M <= DECODE_MAX_ROWS)):   # decode-shaped: weight-streaming tiles (+ split-K slabs)
+    if out_f32 is None and (M <= 256 or (decode and M <= DECODE_MAX_ROWS)):   # decode-shaped: weight-streaming tiles (+ split-K slabs)
         scratch = _skinny_scratch(a.device)
         plan = _decode_plans.get((M, N, K))
         ldr = residual.stride(0) if residual is not None else 0
@@ -287,6 +288,21 @@ def gemm_tn(a_km, b_kn, out_f32, accumulate=False):
     _gemm_workspace(a_km.device)
     lib().st_gemm_tn(_p(a_km), a_km.stride(0), _p(b_kn), b_kn.stride(0), _p(out_f32), out_f32.stride(0), int(accumulate), M, N, K, _s())
     return out_f32
+
+
+def decode_plan(M: int, N: int, K: int):
+    """(tile variant, split-K slices) the library picks for a decode-shaped GEMM (st_gemm_decode_plan; inspection only)."""
+    import ctypes
+    v, sp = ctypes.c_int(0), ctypes.c_int(0)
+    lib().st_gemm_decode_plan(M, N, K, _SCRATCH_ELEMS, ctypes.addressof(v), ctypes.addressof(sp))
+    return v.value, sp.value
+
+
+def swiglu_decode_plan(M: int, I: int) -> int:
+    import ctypes
+    v = ctypes.c_int(0)
+    lib().st_gemm_swiglu_decode_plan(M, I, ctypes.addressof(v))
+    return v.value
 
 
 def layout_gemm_ok(M: int, N: int, K: int) -> bool:

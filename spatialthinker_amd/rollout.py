@@ -41,6 +41,7 @@ class Generator:
         # + the K/V of the live context (prompt K/V once per prompt and kv-head group, generated K/V per row)
         self.stats = {"decode_s": 0.0, "decode_steps": 0, "decode_bytes": 0.0, "decode_row_steps": 0, "prefill_s": 0.0, "phases": 0}
         self._timers: list = []
+        self.tap = None                   # test hook, see iteration(); needs use_graph=False
 
     def _tune_decode(self, B: int):
         w = self.m.p.w
@@ -232,7 +233,7 @@ class Generator:
                     for layer in range(L):
                         p = f"l.{layer}."
                         h1, _ = ops.rmsnorm_fwd(x, w[p + "in_norm"], c.rms_eps, want_rstd=False)
-                        qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"])
+                        qkv = ops.gemm_nt(h1, w[p + "qkv_w"], bias=w[p + "qkv_b"], decode=True)
                         ops.rope_apply_(qkv[:Ba], cos, sin, nq + nkv, D)
                         ops.kv_append_(qkv[:Ba], nq * D, nq * D + width, width, kg[layer][s_first:s_first + Ba], vg[layer][s_first:s_first + Ba], glen)
                         ops.attn_fwd_ranges(qkv, kp[layer], vp[layer], qb1, qe1, kb1, ke1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
@@ -240,12 +241,14 @@ class Generator:
                         ops.attn_fwd_ranges(qkv, kgv[layer], vgv[layer], qb2, qe2, kb2, ke2, g, nkv, nkv, D, m.scale, parts, lse_parts,
                                             o_beg=ob2, q_group=g)
                         ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)      # writes the (B, n_q*D) layout directly
-                        x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x)
+                        x1 = ops.gemm_nt(abuf, w[p + "o_w"], residual=x, decode=True)
                         h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
-                        mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"]))
-                        x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1)
+                        mm = ops.swiglu_fwd(ops.gemm_nt(h2, w[p + "gu_w"], decode=True))
+                        x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1, decode=True)
                     hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
-                ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits)
+                ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits, decode=True)
+                if self.tap is not None:                      # test hook (eager iterations only): this iteration's tokens and next logits
+                    self.tap(S_np, live.clone(), gen_len.clone(), tok32.clone(), logits[:Ba].clone())
                 gen_len.add_(1); pos.add_(1)
 
             # the decode iteration is launch-bound (~10 launches x layers): capture it once per phase into a hipGraph and replay
@@ -293,7 +296,6 @@ class Generator:
         # step), re-batched again each time half of them are done — one short tail for the whole rollout batch instead of one
         # per wave.  (The unfused path has no sample-indexed cache append: its waves simply run to completion.)
         compact = self.compact and can_fuse and wave <= ops.DECODE_MAX_ROWS
-        ops._wide_decode[0] = wave > 256
         debug = bool(os.environ.get("ST_GEN_DEBUG"))
         pool = np.zeros(0, dtype=np.int64)
 

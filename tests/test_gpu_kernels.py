@@ -407,7 +407,7 @@ def _attn_case(rs, lens, n_q, n_kv, D):
     ([5], 2, 1, 128, True), ([130, 64, 1, 257], 4, 2, 128, True), ([200, 77], 7, 1, 128, True),
     ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False),
     ([700, 129, 383], 7, 1, 128, True), ([450, 65], 2, 2, 128, False)])      # many K/V tiles: the staged pipelines wrap their rings
-def test_attn_fwd(ops, lens, n_q, n_kv, D, causal):
+def test_attn_fwd(ops, measured, lens, n_q, n_kv, D, causal):
     rs = np.random.RandomState(sum(lens) + D)
     qkv, cu = _attn_case(rs, lens, n_q, n_kv, D)
     T = qkv.shape[0]
@@ -419,6 +419,7 @@ def test_attn_fwd(ops, lens, n_q, n_kv, D, causal):
     want = Q.dense_attention(xf[:, :n_q * D].reshape(T, n_q, D), xf[:, n_q * D:(n_q + n_kv) * D].reshape(T, n_kv, D),
                              xf[:, (n_q + n_kv) * D:].reshape(T, n_kv, D), cu, causal).reshape(T, n_q * D)
     err = np.abs(out.float().cpu().numpy() - want.numpy()).max()
+    measured(f"attn_fwd_D{D}_{'c' if causal else 'f'}_{sum(lens)}", err)
     assert err < 2e-2, err                                           # P is rounded to bf16 before PV (as flash-attn does)
     # spiked key forces the online-softmax rescale branch on a late tile
     qkv2 = qkv.clone().float()
@@ -429,14 +430,16 @@ def test_attn_fwd(ops, lens, n_q, n_kv, D, causal):
     xf2 = x2.float().cpu()
     want2 = Q.dense_attention(xf2[:, :n_q * D].reshape(T, n_q, D), xf2[:, n_q * D:(n_q + n_kv) * D].reshape(T, n_kv, D),
                               xf2[:, (n_q + n_kv) * D:].reshape(T, n_kv, D), cu, causal).reshape(T, n_q * D)
-    assert np.abs(out2.float().cpu().numpy() - want2.numpy()).max() < 2e-2
+    err2 = np.abs(out2.float().cpu().numpy() - want2.numpy()).max()
+    measured(f"attn_fwd_spiked_D{D}_{'c' if causal else 'f'}_{sum(lens)}", err2)
+    assert err2 < 2e-2, err2
 
 
 @pytest.mark.parametrize("lens,n_q,n_kv,D,causal", [
     ([5], 2, 1, 128, True), ([130, 64, 1, 257], 4, 2, 128, True), ([200, 77], 7, 1, 128, True),
     ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False),
     ([700, 129, 383], 7, 1, 128, True), ([450, 65], 2, 2, 128, False)])      # many K/V tiles: the staged pipelines wrap their rings
-def test_attn_bwd(ops, lens, n_q, n_kv, D, causal):
+def test_attn_bwd(ops, measured, lens, n_q, n_kv, D, causal):
     rs = np.random.RandomState(sum(lens) + D + 1)
     qkv, cu = _attn_case(rs, lens, n_q, n_kv, D)
     T = qkv.shape[0]
@@ -455,6 +458,7 @@ def test_attn_bwd(ops, lens, n_q, n_kv, D, causal):
     got, want = dqkv.float().cpu().numpy(), xf.grad.numpy()
     for name, sl in (("dq", slice(0, n_q * D)), ("dk", slice(n_q * D, (n_q + n_kv) * D)), ("dv", slice((n_q + n_kv) * D, None))):
         err = np.abs(got[:, sl] - want[:, sl]).max() / (np.abs(want[:, sl]).max() + 1e-9)
+        measured(f"attn_bwd_{name}_D{D}_{'c' if causal else 'f'}_{sum(lens)}", err)
         assert err < 2e-2, (name, err)
 
 
@@ -504,7 +508,7 @@ def test_decode_fused_ops_bit_identical(ops, M, B):
 
 # ------------------------------------------------------------------ shared-prefix (segment) attention
 @pytest.mark.parametrize("groups", [[(70, [33, 1, 64])], [(200, [150, 129]), (65, [5]), (0, [90])], [(333, [257, 64, 100, 31])]])
-def test_attn_seg_shared_prefix_fwd_bwd(ops, groups):
+def test_attn_seg_shared_prefix_fwd_bwd(ops, measured, groups):
     """Packed [prompt][resp_1]..[resp_k] with the prompt stored once vs dense fp32 attention over every full sequence
     (autograd sums the prompt gradients of the k rollouts)."""
     n_q, n_kv, D = 4, 2, 128
@@ -555,9 +559,12 @@ def test_attn_seg_shared_prefix_fwd_bwd(ops, groups):
         loss = loss + (own * do.float().cpu()[b:e]).sum()
     loss.backward()
     gr = leaf.grad
-    assert float((out.float().cpu()[:T] - ref_out[:T]).abs().max()) < 2e-2
+    e_f = float((out.float().cpu()[:T] - ref_out[:T]).abs().max())
+    measured(f"attn_seg_fwd_{T}", e_f)
+    assert e_f < 2e-2, e_f
     for name, got, want in (("dq", dq, gr[:, :n_q * D]), ("dk", dk, gr[:, n_q * D:(n_q + n_kv) * D]), ("dv", dv, gr[:, (n_q + n_kv) * D:])):
         err = float((got.float().cpu()[:T] - want[:T]).abs().max())
+        measured(f"attn_seg_{name}_{T}_rel", err / float(want.abs().max()))
         assert err < 0.02 * float(want.abs().max()) + 1e-2, (name, err, float(want.abs().max()))
 
 

@@ -19,7 +19,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert len(argtypes) == len(argnames)
         if name not in ("st_version", "st_arch", "st_prof_enable", "st_prof_read", "st_prof_disable", "st_prof_set_stride", "st_prof_hint_units", "st_prof_seen",
                             "st_attn_bwd_workspace_bytes",
-                            "st_gemm_set_workspace"):
+                            "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan"):
             assert argnames[-1] == "stream", f"{name}: every compute entry takes the stream last"
 
 
@@ -49,3 +49,19 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     else:
         raise AssertionError("lib() must raise when libst_hip.so is missing")
     importlib.reload(L)
+
+
+def test_decode_plan_query_is_host_only_and_picks_the_7b_tiles():
+    """st_gemm_decode_plan / st_gemm_swiglu_decode_plan launch nothing (inspection of the tile choice): callable without a GPU.  The
+    7B decode shapes select the 128x128 / 256x128 / 256x256 decode tiles, the 256x160 SwiGLU tile and split-K >= 4 — the plans the
+    production-shape GPU parity tests (tests/test_gpu_production_shapes.py) exercise."""
+    from spatialthinker_amd import ops
+    seen, splits = set(), []
+    for M in (64, 224, 384, 512):
+        for N, K in ((4608, 3584), (3584, 3584), (3584, 18944), (152064, 3584)):
+            v, sp = ops.decode_plan(M, N, K)
+            seen.add(v); splits.append(sp)
+            assert 1 <= sp <= 12 and (K // 64) // sp >= 4
+    assert {14, 16, 18} <= seen and max(splits) >= 4
+    assert ops.swiglu_decode_plan(64, 18944) == 7 and ops.swiglu_decode_plan(128, 18944) == 6
+    assert ops.swiglu_decode_plan(256, 18944) == 1 and ops.swiglu_decode_plan(512, 18944) == 1

@@ -43,7 +43,7 @@ def main():
     scratch = torch.empty(64 << 20, dtype=torch.float32, device=dev)
     for M in Ms:
         bm = 64 if M <= 64 else (128 if M <= 128 else 256)
-        ops._wide_decode[0] = M > 256                       # 257..512-row decode batches: two 256-row tiles per projection
+        wide = M > 256                                      # 257..512-row decode batches: two 256-row tiles per projection (ops.gemm_nt(decode=True))
         for name, N, K in SHAPES:
             a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
             # the decode loop streams ~15 GB of weights per step: every layer's W arrives cold.  Rotate over enough copies of
@@ -59,7 +59,7 @@ def main():
             def nextw():
                 cnt[0] += 1
                 return ws[cnt[0] % ncopy]
-            t0 = timeit(lambda: ops.gemm_nt(a, nextw(), bias=bias, out=out))
+            t0 = timeit(lambda: ops.gemm_nt(a, nextw(), bias=bias, out=out, decode=wide))
             e0 = (out.float() - ref).abs().max().item()
             gb = N * K * 2 / 1e9
             line = f"M={M:3d} {name:7s} N={N:6d} K={K:5d}: default plan {t0 * 1e6:7.1f}us ({gb / t0 / 1e3:4.2f} TB/s, err {e0:.1e}) |"

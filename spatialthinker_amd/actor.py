@@ -121,6 +121,7 @@ class PolicyEngine:
             self.model.recompute_light = True
         self.fuse_experience = int(os.environ.get("ST_FUSE_EXPERIENCE", "4"))      # no-grad log-prob passes run this many reference micro-batches at once: rows are independent
                                       # there (no loss normalisation), the result is bit-identical, the GEMMs see 4x the rows
+        self.last_prompt_cache_hit = False   # did the latest compute_log_prob run on the rollout's prompt K/V? (perf/prompt_cache_hit)
         self.opt_steps = 0            # t of AdamW (state["step"])
         self.sched_steps = 0          # lr_scheduler.step() calls so far: once per update_policy call (fsdp_workers.py:453)
         self._norm_buf = torch.zeros(1, dtype=F32, device=store.device) if hyper is not None else None
@@ -173,7 +174,8 @@ class PolicyEngine:
         mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
         mb *= max(1, int(self.fuse_experience))
         R = data["responses"].shape[1]
-        if prompt_cache is not None and self._cache_matches(data, prompt_cache, R):
+        self.last_prompt_cache_hit = bool(prompt_cache is not None and self._cache_matches(data, prompt_cache, R))
+        if self.last_prompt_cache_hit:
             n = prompt_cache["n"]
             outs = []
             for s in range(0, N, mb):

@@ -28,6 +28,9 @@ def test_main_runs_two_grpo_steps(tmp_path):
     for key in ("actor/pg_loss", "actor/kl_loss", "actor/grad_norm", "actor/lr", "timing_s/gen", "timing_s/update_actor", "reward/overall",
                 "perf/throughput", "critic/advantages/mean", "response_length/mean", "perf/mfu_actor"):
         assert key in lines[-1], key
+    # the mini-batch balance permutation (rollout 4 / global 2 = 2 mini-batches) is applied after the log-prob passes, so the old-policy
+    # pass runs on the rollout's prompt K/V cache in every step
+    assert all("perf/prompt_cache_hit:1 " in l + " " for l in lines), lines[-1]
     assert "actor/lr:0" in lines[0].replace("actor/lr:0 ", "actor/lr:0 ") or "actor/lr:1e-06" in lines[0]
     # like the reference, the step counter is incremented before the max_steps check (ray_trainer.py:567-569), so the final
     # save after an early break is labelled max_steps + 1

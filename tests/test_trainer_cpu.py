@@ -55,7 +55,7 @@ class StubWorkerGroup:
 
     def __init__(self):
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
-        self.updates, self.saved, self.loaded, self.gen_meta = [], [], [], []
+        self.updates, self.saved, self.loaded, self.gen_meta, self.logprob_rows, self.gen_rows = [], [], [], [], [], []
 
     def gather_objects(self, obj):
         if self.world_size == 1:
@@ -71,6 +71,7 @@ class StubWorkerGroup:
         n = int(prompts.meta_info.get("n", self.n))
         self.gen_meta.append(dict(prompts.meta_info))
         ids = prompts.batch["input_ids"]
+        self.gen_rows.append([int(ids[i, -1]) - 100 for i in range(len(prompts)) for _ in range(n)])
         rows = []
         for i in range(len(prompts)):
             tok = int(ids[i, -1]) % 50 + 10
@@ -81,7 +82,9 @@ class StubWorkerGroup:
         return DataProto.from_dict(assemble_rollout_batch(ids, prompts.batch["attention_mask"], prompts.batch["position_ids"], resp, n, EOS))
 
     def compute_log_probs(self, data):
-        return DataProto.from_dict({"old_log_probs": -data.batch["responses"].float() / 100.0}, meta_info={"temperature": 1.0})
+        self.logprob_rows.append(list(data.non_tensor_batch["ground_truth"]))
+        return DataProto.from_dict({"old_log_probs": -data.batch["responses"].float() / 100.0},
+                                   meta_info={"temperature": 1.0, "prompt_cache_hit": True})
 
     def compute_ref_log_probs(self, data):
         return DataProto.from_dict({"ref_log_probs": -data.batch["responses"].float() / 90.0})
@@ -188,6 +191,10 @@ def test_step_row_alignment_balance_and_metrics(tmp_path, capsys):
             assert b["responses"][i + j, 0].item() == tok and int(b["response_mask"][i + j].sum()) == j + 2
             assert torch.equal(b["input_ids"][i + j], torch.cat([b["prompts"][i + j], b["responses"][i + j]]))
     assert len(set(nt["uid"])) == 4
+    # the old / ref log-prob passes see the rows in GENERATION order (row r <-> prompt r // n: what the rollout's prompt K/V cache is
+    # keyed by); the mini-batch balance permutation is applied afterwards, for update_actor only
+    assert [int(g[2:]) for g in wg.logprob_rows[0]] == wg.gen_rows[0]
+    assert [int(g[2:]) for g in nt["ground_truth"]] != wg.gen_rows[0]       # ... and update_actor got the Karmarkar-Karp group order
     # default config: use_kl_loss off -> the KL penalty branch (ray_trainer.py:658-665) shapes the rewards; RLOO inside each group
     # of 2 is then A = r_i - r_other on the PENALISED rewards
     assert not torch.equal(b["token_level_rewards"], b["token_level_scores"])
@@ -198,6 +205,7 @@ def test_step_row_alignment_balance_and_metrics(tmp_path, capsys):
     lens = b["attention_mask"].sum(-1).tolist()
     out = capsys.readouterr().out
     line = [l for l in out.splitlines() if l.startswith("step 1:")][0]
+    assert "perf/prompt_cache_hit:1" in line
     for key in ("global_seqlen/balanced_max", "global_seqlen/minmax_diff", "minibatch_seqlen/balanced_max", "reward/overall", "actor/pg_loss",
                 "critic/score/mean", "response_length/mean", "timing_s/gen", "timing_s/update_actor", "perf/throughput", "perf/total_num_tokens"):
         assert key in line, key
@@ -323,3 +331,88 @@ def test_two_ranks_shard_rows_and_rank0_logs_global_metrics(tmp_path):
     # validation: 5 rows -> one batch padded to 6, 3 per rank; the padded duplicate is dropped from the score
     v = [l for l in r0["out"].splitlines() if l.startswith("step 0:")][0]
     assert "val/reward_score:0.1" in v and "val/overall_reward:0.1" in v
+
+
+def _migrate_worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ST_SKIP_FINAL_SAVE="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr, wg, cfg = make_trainer(tmp, ["trainer.max_steps=1", "trainer.balance_mode=migrate", "data.rollout_batch_size=8",
+                                         "worker.actor.global_batch_size=8", "algorithm.adv_estimator=rloo", "algorithm.use_kl_loss=true"], n_rows=16, n=2)
+        tr.fit()
+    d = wg.updates[0]
+    torch.save({"gt": list(d.non_tensor_batch["ground_truth"]), "lens": d.batch["attention_mask"].sum(-1).tolist(),
+                "resp_len": d.batch["response_mask"].sum(-1).tolist(), "adv": d.batch["advantages"][:, 0].tolist(),
+                "scores": d.batch["token_level_scores"].sum(-1).tolist(), "old": d.batch["old_log_probs"].clone(),
+                "resp": d.batch["responses"].clone(), "gen_rows": wg.gen_rows[0]}, os.path.join(tmp, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_balance_mode_migrate_reproduces_the_reference_row_migration(tmp_path):
+    """trainer.balance_mode=migrate on two gloo ranks: the global (rank-major) row list is cut into world_size equal-size sets by the
+    golden-pinned Karmarkar-Karp partitioner (tests/golden/balance.json pins it against the reference's own function) and rank r trains
+    on set r in partition order — verl/trainer/ray_trainer.py:526-541.  Group statistics (RLOO here) still cover whole groups although
+    their members now sit on different ranks, and every per-row tensor travelled with its row."""
+    world = 2
+    mp.spawn(_migrate_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"m{i}.pt") for i in range(world)]
+    # global order before the migration: rank 0's generated rows, then rank 1's (prompt-major, n = 2 rollouts each)
+    glob_rows = r[0]["gen_rows"] + r[1]["gen_rows"]
+    assert len(glob_rows) == 16
+    P_len = {row: 2 + row % 4 for row in set(glob_rows)}
+    resp_len = [2 + (j % 2) for j in range(16)]                              # sample j of a prompt answers with j + 1 tokens + EOS
+    lens = [P_len[row] + resp_len[j] for j, row in enumerate(glob_rows)]
+    parts = get_seqlen_balanced_partitions(lens, 2, True)
+    for rank in range(world):
+        want = [(glob_rows[j], resp_len[j]) for j in parts[rank]]
+        got = [(int(g[2:]), int(L)) for g, L in zip(r[rank]["gt"], r[rank]["resp_len"])]
+        assert got == want, rank
+        assert r[rank]["lens"] == [lens[j] for j in parts[rank]]
+        assert torch.equal(r[rank]["old"], -r[rank]["resp"].float() / 100.0)          # old_log_probs belong to the migrated rows
+    # the two rollouts of a prompt may now live on different ranks; RLOO (k = 2): A_i = r_i - r_other over the WHOLE group
+    by_row = {}
+    for rank in range(world):
+        for g, sc, adv in zip(r[rank]["gt"], r[rank]["scores"], r[rank]["adv"]):
+            by_row.setdefault(g, []).append((sc, adv))
+    split_groups = 0
+    for g, items in by_row.items():
+        assert len(items) == 2
+        (s0, a0), (s1, a1) = items
+        assert abs(a0 - (s0 - s1)) < 1e-5 and abs(a1 - (s1 - s0)) < 1e-5
+    for rank in range(world):
+        split_groups += sum(1 for g in set(r[rank]["gt"]) if r[rank]["gt"].count(g) == 1)
+    assert split_groups > 0                                                  # the migration really scattered at least one group
+
+
+def test_dataloader_state_saved_after_an_epoch_end_draws_a_new_permutation():
+    """A checkpoint written after the loops end naturally (training_steps = len x episodes) stores the state BETWEEN epochs: a
+    resume must continue with the NEXT epoch's permutation (StatefulDataLoader semantics), not replay the finished one."""
+    ds = Rows(12)
+    ref = ResumableDataLoader(ds, 4, True, 9, collate_fn)
+    full = [b["row"].tolist() for _ in range(3) for b in ref]
+    a = ResumableDataLoader(ds, 4, True, 9, collate_fn)
+    first = [b["row"].tolist() for b in a]                              # one whole epoch, exhausted naturally
+    state = a.state_dict()
+    assert state["batches_yielded"] == 0 and state["epochs_done"] == 1
+    b_ = ResumableDataLoader(ds, 4, True, 9, collate_fn)
+    b_.load_state_dict(state)
+    second = [b["row"].tolist() for b in b_]
+    assert first == full[:3] and second == full[3:6] and second != first
+
+
+@pytest.mark.parametrize("rows,world", [(1, 8), (3, 8), (5, 4), (7, 8), (2, 2)])
+def test_ragged_last_batch_is_padded_cyclically_to_the_world_size(rows, world):
+    """drop_last=False validation loaders: a last batch of 1..world-1 rows is padded by cycling its rows until every rank gets the
+    same number (>= 1) — pad_dataproto_to_divisor of the reference (verl/protocol.py:48-66)."""
+    ds = Rows(rows)
+    shards = []
+    for r in range(world):
+        ld = ResumableDataLoader(ds, -(-rows // world) * world, False, 1, collate_fn, False, 0, r, world)
+        items = [b["row"].tolist() for b in ld]
+        assert len(items) == 1 and len(items[0]) >= 1
+        shards.append(items[0])
+    assert len({len(x) for x in shards}) == 1
+    flat = [x for sh in shards for x in sh]
+    want = (list(range(rows)) * (len(flat) // rows + 1))[:len(flat)]
+    assert flat == want

@@ -130,6 +130,9 @@ TrainerConfig = _build("TrainerConfig", {
     "logger": (Tuple[str, ...], ("console", "wandb")), "nnodes": (int, 1), "n_gpus_per_node": (int, 8), "critic_warmup": (int, 0),
     "val_freq": (int, -1), "val_before_train": (bool, True), "val_only": (bool, False), "val_generations_to_log": (int, 0),
     "save_freq": (int, -1), "save_limit": (int, -1), "save_checkpoint_path": (Optional[str], None), "load_checkpoint_path": (Optional[str], None),
+    # extension (not a reference key): "local" keeps a prompt's rollouts on the GPU that generated them and balances each rank's
+    # mini-batches; "migrate" reproduces the reference's cross-rank row migration (ray_trainer.py:526-541) — RayPPOTrainer._migrate_batch
+    "balance_mode": (str, "local"),
 }, {"post_init": _trainer_post})
 
 AUTO_KEYS = {"worker.actor.global_batch_size_per_device", "worker.actor.disable_kl", "worker.actor.use_kl_loss", "worker.actor.kl_penalty",

@@ -65,16 +65,18 @@ def _dist_sum(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def compute_advantage(data: DataProto, adv_estimator: str, gamma: float = 1.0, lam: float = 1.0):
-    """ray_trainer.py:148-175.  GRPO runs the HIP kernel; the other estimators are host math (core_algos)."""
+def compute_advantage(data: DataProto, adv_estimator: str, gamma: float = 1.0, lam: float = 1.0, whole_batch: bool = False):
+    """ray_trainer.py:148-175.  GRPO runs the HIP kernel; the other estimators are host math (core_algos).
+    whole_batch: `data` already holds every rank's rows (migrate mode), so batch-wide statistics need no cross-rank sum."""
     rew, mask, index = data.batch["token_level_rewards"], data.batch["response_mask"], data.non_tensor_batch["uid"]
     est = AdvantageEstimator(adv_estimator).value
+    _sum = (lambda t: t) if whole_batch else _dist_sum
     if est == "grpo":
         adv, ret = core_algos.compute_grpo_outcome_advantage(rew, mask, index)
     elif est == "gae":
-        adv, ret = core_algos.compute_gae_advantage_return(rew, data.batch["values"], mask, gamma, lam, all_reduce=_dist_sum)
+        adv, ret = core_algos.compute_gae_advantage_return(rew, data.batch["values"], mask, gamma, lam, all_reduce=_sum)
     elif est == "reinforce_plus_plus":
-        adv, ret = core_algos.compute_reinforce_plus_plus_outcome_advantage(rew, mask, gamma, all_reduce=_dist_sum)
+        adv, ret = core_algos.compute_reinforce_plus_plus_outcome_advantage(rew, mask, gamma, all_reduce=_sum)
     elif est == "remax":
         adv, ret = core_algos.compute_remax_outcome_advantage(rew, data.batch["reward_baselines"], mask)
     else:
@@ -206,15 +208,19 @@ class RayPPOTrainer:
         return out
 
     # ------------------------------------------------------------------------------------------------
-    def _balance_batch(self, batch: DataProto, metrics: Dict[str, Any], logging_prefix: str = "global_seqlen") -> None:
+    def _balance_batch(self, batch: DataProto, metrics: Dict[str, Any], logging_prefix: str = "global_seqlen", reorder: bool = True):
         """ray_trainer.py:526-541 in two parts.
         (1) Statistics: the reference partitions the GLOBAL list of sequence lengths into world_size sets with Karmarkar-Karp and
             logs min/max/minmax_diff (contiguous chunks) vs balanced_min/max (its partition): same list, same partitioner, same keys.
         (2) Reorder: the reference then permutes rows so DP rank r receives partition r.  Here the G rollouts of a prompt stay on
             the GPU that generated them (one prompt copy per group in every pass, prompt K/V re-used for the old log-probs), so
             the partitioner is applied where this design has a choice: each rank's rollout GROUPS are spread over its optimizer
-            steps (mini-batches of global_batch_size_per_device rows) with equal group counts and balanced token sums, and the
-            batch is reordered accordingly — ranks then reach each gradient all-reduce after similar amounts of work."""
+            steps (mini-batches of global_batch_size_per_device rows) with equal group counts and balanced token sums — ranks then
+            reach each gradient all-reduce after similar amounts of work.  Only update_actor's mini-batch split depends on that
+            order, so fit() applies the permutation (returned here when reorder=False) AFTER the old / ref log-prob passes: those
+            see the rows in generation order, which is what lets the old-policy pass re-use the rollout's prompt K/V cache
+            (PolicyEngine._cache_matches; perf/prompt_cache_hit reports it).
+        trainer.balance_mode=migrate is the reference-faithful alternative (_migrate_batch)."""
         lens = batch.batch["attention_mask"].sum(-1).tolist()
         glob = self._gather_list(lens)
         world = max(1, len(glob) // max(1, len(lens)))
@@ -230,9 +236,29 @@ class RayPPOTrainer:
             gl = [sum(lens[g * n:(g + 1) * n]) for g in range(n_groups)]
             gparts = get_seqlen_balanced_partitions(gl, k_partitions=n_mini, equal_size=True)
             idx = torch.tensor([g * n + j for p in gparts for g in p for j in range(n)])
-            batch.reorder(idx)
             sums = [sum(gl[g] for g in p) for p in gparts]
             metrics.update({"minibatch_seqlen/balanced_min": min(sums), "minibatch_seqlen/balanced_max": max(sums)})
+            if reorder:
+                batch.reorder(idx)
+            return idx
+        return None
+
+    def _migrate_batch(self, batch: DataProto, metrics: Dict[str, Any], logging_prefix: str = "global_seqlen") -> DataProto:
+        """trainer.balance_mode=migrate: the reference's _balance_batch to the letter (ray_trainer.py:526-541 +
+        verl/utils/seqlen_balancing.py:150-181).  The whole rollout batch is assembled in global row order (rank-major = the order
+        the single driver holds it in), partitioned into world_size equal-size sets by Karmarkar-Karp over the per-row token counts,
+        reordered partition by partition, and rank r continues with chunk r — so every rank's micro-batch composition (hence its
+        token-mean loss terms) is the reference's.  Costs what the reference pays: every row (with its pixel values) crosses the
+        host fabric once per step, the rollouts of a prompt scatter over the ranks (no shared-prompt packing across them) and the
+        rollout's prompt K/V cache no longer matches the rows (perf/prompt_cache_hit = 0).  Off by default."""
+        parts_in = self._gather(batch)
+        world = len(parts_in)
+        whole = DataProto.concat(parts_in) if world > 1 else batch
+        lens = whole.batch["attention_mask"].sum(-1).tolist()
+        parts = get_seqlen_balanced_partitions(lens, k_partitions=world, equal_size=True)
+        metrics.update(log_seqlen_unbalance(lens, parts, logging_prefix))
+        whole.reorder(torch.tensor([j for p in parts for j in p]))
+        return whole.chunk(world)[self.rank] if world > 1 else whole
 
     def _validate(self) -> Dict[str, Any]:
         """ray_trainer.py:358-411, data-parallel: every rank generates and scores ITS rows of each validation batch (in chunks
@@ -294,7 +320,10 @@ class RayPPOTrainer:
         os.makedirs(os.path.join(path, "actor"), exist_ok=True)
         self.actor_rollout_wg.save_checkpoint(os.path.join(path, "actor"))
         if self.rank == 0:
-            torch.save({"dataloader": self.train_dataloader.state_dict(), "kl_coef": self.kl_ctrl.kl_coef}, os.path.join(path, "dataloader.pt"))
+            # dataloader.pt holds the loader's bare state_dict, as the reference writes it (ray_trainer.py:498-500); the adaptive KL
+            # coefficient (driver state the reference loses on resume) rides along as one extra key
+            state = dict(self.train_dataloader.state_dict(), kl_coef=self.kl_ctrl.kl_coef)
+            torch.save(state, os.path.join(path, "dataloader.pt"))
             with open(os.path.join(root, CHECKPOINT_TRACKER), "w") as f:
                 f.write(str(self.global_step))
 
@@ -310,8 +339,8 @@ class RayPPOTrainer:
         dl = os.path.join(p, "dataloader.pt")
         if os.path.exists(dl):
             st = torch.load(dl, weights_only=False)
-            self.train_dataloader.load_state_dict(st["dataloader"])
             self.kl_ctrl.kl_coef = st.get("kl_coef", self.kl_ctrl.kl_coef)
+            self.train_dataloader.load_state_dict(st["dataloader"] if "dataloader" in st else st)      # round-2 files nested it
         else:
             print(f"No dataloader state found at {dl}, will start from scratch.")
 
@@ -359,10 +388,19 @@ class RayPPOTrainer:
                         reward_tensor, reward_metrics = self.reward_fn(batch)
                         batch.batch["token_level_scores"] = reward_tensor
                         metrics.update({f"reward/{k}": v for k, v in reduce_metrics(self._gather_metric_lists(reward_metrics)).items()})
-                    self._balance_batch(batch, metrics)
+                    pending_order = None
+                    migrated = getattr(cfg.trainer, "balance_mode", "local") == "migrate"
+                    if migrated:
+                        batch = self._migrate_batch(batch, metrics)
+                    else:
+                        pending_order = self._balance_batch(batch, metrics, reorder=False)
                     batch.meta_info["global_token_num"] = torch.sum(batch.batch["attention_mask"], dim=-1).tolist()
                     with _timer("old", timing_raw):
-                        batch = batch.union(self.actor_rollout_wg.compute_log_probs(batch))
+                        old = self.actor_rollout_wg.compute_log_probs(batch)
+                        hit = old.meta_info.pop("prompt_cache_hit", None)
+                        if hit is not None:                               # did the old-policy pass run on the rollout's prompt K/V?
+                            metrics["perf/prompt_cache_hit"] = float(np.mean(self._gather_list([float(hit)])))
+                        batch = batch.union(old)
                     if self.use_reference_policy:
                         with _timer("ref", timing_raw):
                             batch = batch.union(self.ref_policy_wg.compute_ref_log_probs(batch))
@@ -372,7 +410,17 @@ class RayPPOTrainer:
                             metrics.update(kl_metrics)
                         else:
                             batch.batch["token_level_rewards"] = batch.batch["token_level_scores"]
-                        batch = compute_advantage(batch, est, cfg.algorithm.gamma, cfg.algorithm.lam)
+                        if migrated and self.world > 1:
+                            # after the migration a rank holds PARTS of rollout groups: the group statistics are formed over the whole
+                            # batch, as on the reference's driver (ray_trainer.py:667-672), and every rank keeps its rows' share
+                            keys = [k for k in ("token_level_rewards", "response_mask", "values", "reward_baselines") if k in batch.batch.keys()]
+                            whole = DataProto.concat(self._gather(batch.select(batch_keys=keys, non_tensor_batch_keys=["uid"])))
+                            mine = compute_advantage(whole, est, cfg.algorithm.gamma, cfg.algorithm.lam, whole_batch=True).chunk(self.world)[self.rank]
+                            batch.batch["advantages"], batch.batch["returns"] = mine.batch["advantages"].clone(), mine.batch["returns"].clone()
+                        else:
+                            batch = compute_advantage(batch, est, cfg.algorithm.gamma, cfg.algorithm.lam)
+                    if pending_order is not None:                         # mini-batch balance: only update_actor's split depends on it
+                        batch.reorder(pending_order)
                     if cfg.trainer.critic_warmup <= self.global_step:
                         with _timer("update_actor", timing_raw):
                             actor_out = self.actor_rollout_wg.update_actor(batch)

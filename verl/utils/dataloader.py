@@ -41,11 +41,11 @@ class ResumableDataLoader:
         return out
 
     def local_rows(self, global_batch: List[int]) -> List[int]:
+        if len(global_batch) % self.world:          # a ragged last batch (drop_last=False): pad by cycling until the divisor is met,
+            need = self.world - len(global_batch) % self.world       # as pad_dataproto_to_divisor (verl/protocol.py:48-66) — a batch of
+            reps = -(-need // len(global_batch))                      # fewer than world/2 rows needs more than one lap
+            global_batch = global_batch + (global_batch * reps)[:need]
         per = len(global_batch) // self.world
-        if len(global_batch) % self.world:          # a ragged last batch (drop_last=False): pad by cycling, as pad_dataproto_to_divisor
-            need = self.world - len(global_batch) % self.world
-            global_batch = global_batch + global_batch[:need]
-            per = len(global_batch) // self.world
         return global_batch[self.rank * per:(self.rank + 1) * per]
 
     def __iter__(self) -> Iterator[Dict[str, Any]]:
@@ -60,6 +60,7 @@ class ResumableDataLoader:
             yield item
         self.epochs_done += 1
         self.batches_yielded = 0
+        self._epoch_start_state = self.gen.get_state()     # a state saved between epochs resumes with a NEW permutation, not a replay
 
     # ---------------------------------------------------------------- checkpoint interface (StatefulDataLoader's names)
     def state_dict(self) -> Dict[str, Any]:

@@ -30,6 +30,8 @@ from .rollout import assemble_rollout_batch
 
 
 class FSDPWorker:
+    _warned_padding = False
+
     def __init__(self, config, role: Literal["actor", "critic", "rollout", "ref", "actor_rollout", "actor_rollout_ref"]):
         self.config, self.role = config, role
         self.world_size = int(os.environ.get("WORLD_SIZE", 1))
@@ -42,6 +44,15 @@ class FSDPWorker:
         self._is_ref = role in ("ref", "actor_rollout_ref")
         if role == "critic":
             raise NotImplementedError("the critic is only used by adv_estimator=gae, outside the GRPO path")
+        # options of the reference this engine does not implement are rejected, never silently ignored
+        if int(getattr(self.config.actor, "ulysses_sequence_parallel_size", 1)) > 1:
+            raise NotImplementedError(
+                "worker.actor.ulysses_sequence_parallel_size > 1: Ulysses sequence parallelism (verl/utils/ulysses.py) is not built; a 288 GB "
+                "MI355X holds the 8192-token sequences of the shipped scripts without it — set it to 1")
+        if not bool(getattr(self.config.actor, "padding_free", True)) and self.rank == 0 and not FSDPWorker._warned_padding:
+            FSDPWorker._warned_padding = True
+            print("[FSDPWorker] worker.actor.padding_free=false: this engine always runs the padding-free (packed) formulation of "
+                  "dp_actor.py:86-138; the log-probs are the same function of the same tokens, only the padded rows are never computed", flush=True)
         if self._is_actor:
             self._init_batch_sizes(self.config.actor)
 
@@ -146,7 +157,8 @@ class FSDPWorker:
         data.meta_info["temperature"] = t
         cache, self._prompt_cache = getattr(self, "_prompt_cache", None), None            # one use, then the K/V memory is released
         lp = self.actor.compute_log_prob(self._as_dict(data), t, prompt_cache=cache).cpu()
-        return DataProto.from_dict(tensors={"old_log_probs": lp}, meta_info={"temperature": t})
+        return DataProto.from_dict(tensors={"old_log_probs": lp},
+                                   meta_info={"temperature": t, "prompt_cache_hit": bool(self.actor.last_prompt_cache_hit)})
 
     @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
     def compute_ref_log_probs(self, data: DataProto) -> DataProto:

@@ -45,28 +45,95 @@ class ActorHyper:
     weight_decay: float = 1e-2
     lr_warmup_steps: int = 0
     allreduce_bucket_mb: int = 512
+    grad_exchange: str = "allreduce"        # "allreduce" | "reduce_scatter" (direct reduce-scatter + all-gather over all xGMI links)
+    grad_exchange_dtype: str = "fp32"       # payload of the exchange: "fp32" (FSDP mp_reduce_dtype default) | "bf16"
     optim_strategy: str = "adamw_bf16"      # adamw_bf16 = AnyPrecisionAdamW (bf16 states + Kahan); adamw = torch.optim.AdamW(fused) semantics
     freeze_vision_tower: bool = False       # fsdp_workers.py:226-232: the ViT gets no gradient and no optimizer update
 
 
 class GradReducer:
-    """Sum all-reduce of the flat fp32 gradient buffer in slices, some of them early.
+    """Sum-exchange of the flat fp32 gradient buffer in slices, some of them early.
 
     ready(lo, hi) — the caller guarantees grad[lo:hi] will not be written again before finish(): the slice goes out at once as
-    an asynchronous all-reduce (RCCL runs it on its own stream, ordered after the kernels already queued on the current one),
-    so it overlaps the rest of the backward pass.  finish() reduces whatever was NOT announced (in buckets of bucket_elems),
+    an asynchronous collective (RCCL runs it on its own stream, ordered after the kernels already queued on the current one),
+    so it overlaps the rest of the backward pass.  finish() exchanges whatever was NOT announced (in buckets of bucket_elems),
     waits for everything and divides by the world size.  Correctness therefore never depends on ready() being called at all;
-    every rank must announce the same slices in the same order (they do: the order is the backward order of the layers)."""
+    every rank must announce the same slices in the same order (they do: the order is the backward order of the layers).
 
-    def __init__(self, grad: torch.Tensor, world: int, group=None, bucket_elems: int = 1 << 27):
+    mode (ActorHyper.grad_exchange):
+      "allreduce"       one ncclAllReduce(sum) per bucket — RCCL's ring / tree schedule.
+      "reduce_scatter"  SURVEY.md §5.8's topology-native schedule for a fully connected xGMI node: DIRECT reduce-scatter +
+                        all-gather.  A bucket is cut into `world` shards; an all-to-all hands shard j of every rank to rank j over all
+                        peer links at once (each of the 7 xGMI links carries 1/8 of the bucket, no ring hops), rank j adds the
+                        `world` contributions in rank order (fixed order: every rank ends up with bit-identical sums), and an
+                        all-gather returns the reduced shards.  Each byte crosses a link once per phase: 2 x (W-1)/W of the
+                        bucket in total per GPU, spread over W-1 links in parallel.
+    payload "bf16" (ActorHyper.grad_exchange_dtype; the reference's FSDP knob is `mp_reduce_dtype`, fp32 by default) sends bf16-rounded
+    contributions and bf16-rounded sums (half the bytes); sums are still formed in fp32.  The AdamW kernels round the gradient to bf16
+    anyway (the dtype the reference's optimizer sees), so only the clip-norm and the pre-sum rounding differ."""
+
+    def __init__(self, grad: torch.Tensor, world: int, group=None, bucket_elems: int = 1 << 27, mode: str = "allreduce", payload: str = "fp32"):
+        assert mode in ("allreduce", "reduce_scatter") and payload in ("fp32", "bf16"), (mode, payload)
         self.grad, self.world, self.pg, self.bucket = grad, world, group, max(1, int(bucket_elems))
+        self.mode, self.payload = mode, payload
         self.sent: List[tuple] = []
         self.works: list = []
+        self.pending: list = []           # reduce_scatter mode: (lo, hi, send, recv, work) of all-to-alls in flight
         self.early_elems = 0
+        # the post-processing of the direct schedule (shard sums, all-gathers) runs on a side stream so that a collective still in
+        # flight never stalls the backward kernels queued on the compute stream
+        self.side = torch.cuda.Stream(device=grad.device) if grad.is_cuda else None
+
+    # ---- plain all-reduce
+    def _send_allreduce(self, lo: int, hi: int):
+        for o in range(lo, hi, self.bucket):
+            sl = self.grad[o:min(hi, o + self.bucket)]
+            if self.payload == "bf16":
+                buf = sl.to(torch.bfloat16)
+                self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), sl, buf))
+            else:
+                self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, None))
+
+    # ---- direct reduce-scatter + all-gather
+    def _ctx(self):
+        import contextlib
+        return torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
+
+    def _send_direct(self, lo: int, hi: int):
+        W = self.world
+        dt = torch.bfloat16 if self.payload == "bf16" else torch.float32
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())        # the slice's last gradient kernels are queued on the compute stream
+        with self._ctx():
+            for o in range(lo, hi, self.bucket):
+                e = min(hi, o + self.bucket)
+                n = e - o
+                per = -(-n // W)
+                send = torch.zeros(W * per, dtype=dt, device=self.grad.device)
+                send[:n].copy_(self.grad[o:e])
+                recv = torch.empty_like(send)
+                work = dist.all_to_all_single(recv, send, group=self.pg, async_op=True)      # recv[j*per:(j+1)*per] = rank j's shard for me
+                self.pending.append((o, e, per, send, recv, work))
+
+    def _drain_direct(self):
+        """Shard sums + all-gathers of every all-to-all issued so far (on the side stream)."""
+        W = self.world
+        with self._ctx():
+            for (o, e, per, send, recv, work) in self.pending:
+                work.wait()
+                acc = recv.view(W, per)[0].float()
+                for j in range(1, W):                                   # rank order: the same fp32 sum on every rank
+                    acc = acc + recv.view(W, per)[j].float()
+                mine = acc.to(send.dtype)
+                full = send                                             # reuse as the gather target
+                self.works.append((dist.all_gather_into_tensor(full, mine, group=self.pg, async_op=True), self.grad[o:e], full))
+        self.pending = []
 
     def _send(self, lo: int, hi: int):
-        for o in range(lo, hi, self.bucket):
-            self.works.append(dist.all_reduce(self.grad[o:min(hi, o + self.bucket)], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if self.mode == "reduce_scatter":
+            self._send_direct(lo, hi)
+        else:
+            self._send_allreduce(lo, hi)
 
     def ready(self, lo: int, hi: int):
         lo, hi = max(0, int(lo)), min(int(hi), self.grad.numel())
@@ -76,6 +143,8 @@ class GradReducer:
             assert hi <= a or lo >= b, f"gradient slice [{lo},{hi}) announced twice (overlaps [{a},{b}))"
         self.sent.append((lo, hi))
         self.early_elems += hi - lo
+        if self.mode == "reduce_scatter" and self.pending:
+            self._drain_direct()                                        # earlier slices: sum + all-gather while backward continues
         self._send(lo, hi)
 
     def finish(self):
@@ -86,8 +155,15 @@ class GradReducer:
             pos = b
         if pos < self.grad.numel():
             self._send(pos, self.grad.numel())
-        for w in self.works:
-            w.wait()
+        if self.pending:
+            self._drain_direct()
+        with self._ctx():
+            for w, dst, buf in self.works:
+                w.wait()
+                if dst is not None:
+                    dst.copy_(buf[:dst.numel()])                        # bf16 payload / gathered shards back into the fp32 buffer
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         self.sent, self.works, self.early_elems = [], [], 0
         self.grad.mul_(1.0 / self.world)                          # FSDP reduce-scatter averages over ranks
 
@@ -210,7 +286,9 @@ class PolicyEngine:
         if not getattr(self, "sync_grads", self.world > 1):
             return None
         if getattr(self, "_reducer", None) is None or self._reducer.grad is not self.store.grad:
-            self._reducer = GradReducer(self.store.grad, self.world, self.pg, self.h.allreduce_bucket_mb * (1 << 20) // 4)
+            self._reducer = GradReducer(self.store.grad, self.world, self.pg, self.h.allreduce_bucket_mb * (1 << 20) // 4,
+                                        mode=os.environ.get("ST_GRAD_EXCHANGE", getattr(self.h, "grad_exchange", "allreduce")),
+                                        payload=os.environ.get("ST_GRAD_EXCHANGE_DTYPE", getattr(self.h, "grad_exchange_dtype", "fp32")))
         return self._reducer
 
     def all_reduce_grads(self):

@@ -77,3 +77,106 @@ def test_early_slices_plus_remainder_equal_one_full_allreduce(tmp_path, world):
     want = sum(torch.randn(700_001, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)) / world
     for r in range(world):
         torch.testing.assert_close(torch.load(tmp_path / f"o{r}.pt"), want, rtol=1e-6, atol=1e-7)
+
+
+def _modes_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spatialthinker_amd.actor import GradReducer
+    n = 300_007                                                  # not a multiple of world or of the bucket: padded shards, tail bucket
+    base = torch.randn(n, generator=torch.Generator().manual_seed(300 + rank))
+    out = {}
+    for mode, payload in (("allreduce", "fp32"), ("reduce_scatter", "fp32"), ("reduce_scatter", "bf16"), ("allreduce", "bf16")):
+        grad = base.clone()
+        red = GradReducer(grad, world, None, bucket_elems=70_000, mode=mode, payload=payload)
+        red.ready(250_000, n)                                    # early slices in backward order, remainder in finish()
+        red.ready(100_000, 250_000)
+        red.finish()
+        out[f"{mode}/{payload}"] = grad
+    torch.save(out, os.path.join(out_dir, f"x{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_reduce_scatter_all_gather_equals_allreduce(tmp_path, world):
+    """SURVEY §5.8's exchange (all-to-all of shards -> fixed-order fp32 shard sums -> all-gather) against the plain all-reduce: the
+    same averaged gradient on every rank (bit-identical ACROSS ranks by construction; equal to the all-reduce up to fp32 summation
+    order, exactly equal at world 2), and the bf16-payload variant within bf16 rounding of it."""
+    mp.spawn(_modes_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"x{r}.pt") for r in range(world)]
+    want = sum(torch.randn(300_007, generator=torch.Generator().manual_seed(300 + r)) for r in range(world)) / world
+    for r in range(world):
+        torch.testing.assert_close(res[r]["allreduce/fp32"], want, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(res[r]["reduce_scatter/fp32"], want, rtol=1e-6, atol=1e-7)
+        assert torch.equal(res[r]["reduce_scatter/fp32"], res[0]["reduce_scatter/fp32"])          # every rank holds the same bits
+        assert torch.equal(res[r]["reduce_scatter/bf16"], res[0]["reduce_scatter/bf16"])
+        for k in ("reduce_scatter/bf16", "allreduce/bf16"):
+            assert float((res[r][k] - want).abs().max()) < 2 ** -7 * float(want.abs().max()) * 2
+    if world == 2:
+        assert torch.equal(res[0]["reduce_scatter/fp32"], res[0]["allreduce/fp32"])
+
+
+def _announce_worker(rank, world, port, out_dir):
+    """update_policy on two ranks with a stub engine: which gradient slices are announced, in which order, on which pass."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spatialthinker_amd.actor import ActorHyper, PolicyEngine
+    L, per, head = 3, 1000, 500                                  # flat layout: [vit+embed 700 | L layers x 1000 | final norm + head 500]
+    n = 700 + L * per + head
+    eng = PolicyEngine.__new__(PolicyEngine)
+    eng.h = ActorHyper(micro_batch_size_per_device_for_update=2, global_batch_size_per_device=8, allreduce_bucket_mb=1,
+                       grad_exchange=os.environ.get("TEST_EXCHANGE", "allreduce"))
+    eng.store = types.SimpleNamespace(grad=torch.zeros(n), device="cpu")
+    eng.world, eng.pg, eng.sync_grads, eng.overlap_allreduce, eng._reducer = world, None, True, True, None
+    eng.fuse_micro_batches, eng.sched_steps, eng.opt_steps = 2, 0, 0
+    log, passes = [], [0]
+
+    def fwd_bwd(b, loss_in, temperature, **kw):
+        on_final = kw.get("on_final")
+        passes[0] += 1
+        g = eng.store.grad
+        g += float(rank + 1)                                     # this pass's contribution everywhere
+        if on_final is not None:
+            lo_head = 700 + L * per
+            on_final(lo_head, n); log.append((passes[0], lo_head, n))
+            for i in reversed(range(L)):
+                on_final(700 + i * per, 700 + (i + 1) * per); log.append((passes[0], 700 + i * per, 700 + (i + 1) * per))
+        return None, torch.zeros(2, 8)
+
+    eng.model = types.SimpleNamespace(forward_backward=fwd_bwd)
+    eng._stage = lambda data, sl: None
+    steps = []
+
+    def opt_step():
+        eng.all_reduce_grads()
+        steps.append(eng.store.grad.clone())
+        eng.store.grad.zero_()
+        return 1.0
+    eng.optimizer_step = opt_step
+    eng.current_lr = lambda: 0.0
+    N, R = 16, 4
+    data = dict(input_ids=torch.zeros(N, 8, dtype=torch.long), attention_mask=torch.ones(N, 8, dtype=torch.long), responses=torch.zeros(N, R, dtype=torch.long),
+                old_log_probs=torch.zeros(N, R), advantages=torch.zeros(N, R), ref_log_probs=torch.zeros(N, R), position_ids=torch.zeros(N, 8, dtype=torch.long))
+    eng.update_policy(data, 1.0)
+    torch.save({"log": log, "steps": steps, "passes": passes[0]}, os.path.join(out_dir, f"a{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "reduce_scatter"])
+def test_update_policy_announces_layer_slices_only_on_the_last_pass_of_each_optimizer_step(tmp_path, exchange):
+    """16 rows, mini-batch 8, micro 2, two micro-batches fused per pass: 2 optimizer steps x 2 passes.  Only the LAST pass of an
+    optimizer step announces slices (head + final norm first, then the layers from the back: the backward order); both ranks
+    announce the same sequence; what the optimizer sees is the rank-averaged sum of both passes everywhere — announced or not."""
+    os.environ["TEST_EXCHANGE"] = exchange
+    try:
+        mp.spawn(_announce_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    finally:
+        del os.environ["TEST_EXCHANGE"]
+    a = [torch.load(tmp_path / f"a{r}.pt") for r in range(2)]
+    assert a[0]["log"] == a[1]["log"] and a[0]["passes"] == 4
+    assert [p for p, _, _ in a[0]["log"]] == [2] * 4 + [4] * 4                       # passes 2 and 4 close the optimizer steps
+    assert [(lo, hi) for _, lo, hi in a[0]["log"][:4]] == [(3700, 4200), (2700, 3700), (1700, 2700), (700, 1700)]
+    for r in range(2):
+        assert len(a[r]["steps"]) == 2
+        for g in a[r]["steps"]:
+            torch.testing.assert_close(g, torch.full_like(g, 2 * (1 + 2) / 2.0))     # two passes x (1 + 2) summed over ranks / world

@@ -1,0 +1,85 @@
+"""The reference's tensor-level entry points under the reference's own names (VERDICT r2 missing #5): importable, same signatures,
+computed by the HIP kernels, pinned against the reference-generated goldens (tests/golden/rl_math.npz: `compute_policy_loss` outputs
++ autograd gradient, `-F.cross_entropy` log-probs; tests/golden/adamw.npz: the reference's AnyPrecisionAdamW class, 6 steps)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compute_policy_loss_by_name_matches_reference_outputs_and_autograd(golden_dir):
+    from verl.trainer import core_algos
+    g = np.load(os.path.join(golden_dir, "rl_math.npz"))
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    new = t("pl_new").requires_grad_(True)
+    loss, hi, lo, kl = core_algos.compute_policy_loss(t("pl_old"), new, t("pl_adv"), t("pl_mask"), 0.2, 0.3, 3.0)
+    np.testing.assert_allclose([float(loss), float(hi), float(lo), float(kl)], g["pl_out"], rtol=2e-5, atol=1e-7)
+    (loss * 2.0).backward()
+    np.testing.assert_allclose(new.grad.cpu().numpy(), 2.0 * g["pl_grad"], rtol=2e-5, atol=2e-9)
+    # host tensors in, host tensors out (the reference calls it on whatever device the micro-batch lives on)
+    new_c = torch.from_numpy(g["pl_new"]).requires_grad_(True)
+    out = core_algos.compute_policy_loss(torch.from_numpy(g["pl_old"]), new_c, torch.from_numpy(g["pl_adv"]), torch.from_numpy(g["pl_mask"]), 0.2, 0.3, 3.0)
+    assert not out[0].is_cuda
+    out[0].backward()
+    np.testing.assert_allclose(new_c.grad.numpy(), g["pl_grad"], rtol=2e-5, atol=2e-9)
+
+
+def test_log_probs_from_logits_by_name_forward_and_inplace_backward(golden_dir):
+    from oracle import rl_math as M
+    from verl.utils import torch_functional as VF
+    g = np.load(os.path.join(golden_dir, "rl_math.npz"))
+    z = torch.from_numpy(g["lp512_logits_bf16_bits"]).view(torch.bfloat16).cuda()
+    lab = torch.from_numpy(g["lp512_labels"]).cuda()
+    zz = z.clone().view(3, 11, 512).requires_grad_(True)                        # (batch, seqlen, vocab) as the docstring allows
+    lp = VF.log_probs_from_logits(zz, lab.view(3, 11))
+    assert lp.shape == (3, 11) and lp.dtype == torch.float32
+    np.testing.assert_allclose(lp.detach().cpu().numpy().reshape(-1), g["lp512_logp"], rtol=0, atol=5e-6)
+    w = torch.linspace(-1, 1, 33, device="cuda").view(3, 11)
+    (lp * w).sum().backward()
+    want = M.log_probs_grad(z.float().cpu().numpy(), lab.cpu().numpy(), w.reshape(-1).cpu().numpy())
+    np.testing.assert_allclose(zz.grad.float().cpu().numpy().reshape(33, 512), want, rtol=2 ** -7, atol=1e-9)
+
+
+def test_any_precision_adamw_by_name_vs_reference_class_golden(golden_dir, measured):
+    from verl.utils import torch_functional as VF
+    g = np.load(os.path.join(golden_dir, "adamw.npz"))
+    p = torch.nn.Parameter(torch.from_numpy(g["p0"]).bfloat16().cuda())
+    opt = VF.AnyPrecisionAdamW([p], lr=float(g["lrs"][0]), betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    worst, worst_frac = 0, 0.0
+    for t in range(1, 7):
+        for gr in opt.param_groups:
+            gr["lr"] = float(g["lrs"][t - 1])
+        p.grad = torch.from_numpy(g[f"g{t - 1}"]).bfloat16().cuda()
+        opt.step()
+        st = opt.state[p]
+        # the golden is the reference class on the CPU; torch's CPU and GPU elementwise kernels round python scalars differently
+        # (DESIGN.md §4), so a few elements sit one bf16 step apart: the GPU semantics are pinned bit-exactly in test_gpu_kernels.py
+        for name, got in (("p", p.data), ("m", st["exp_avg"]), ("v", st["exp_avg_sq"])):
+            want = torch.from_numpy(g[f"{name}{t}"]).bfloat16()
+            bits = (got.cpu().view(torch.int16).int() - want.view(torch.int16).int()).abs()
+            worst, worst_frac = max(worst, int(bits.max())), max(worst_frac, float((bits > 0).float().mean()))
+            assert int(bits.max()) <= 1 and float((bits > 0).float().mean()) < 0.5, (name, t, int(bits.max()), float((bits > 0).float().mean()))
+        assert int(st["step"].item()) == t
+    measured("adamw_byname_vs_cpu_reference_fraction_one_ulp", worst_frac)
+    with pytest.raises(NotImplementedError):
+        VF.AnyPrecisionAdamW([p], use_kahan_summation=False)
+
+
+def test_constant_schedule_with_warmup_by_name():
+    from verl.utils import torch_functional as VF
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = torch.optim.SGD([p], lr=2.0)
+    sch = VF.get_constant_schedule_with_warmup(opt, num_warmup_steps=4)
+    lrs = []
+    for _ in range(6):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    assert lrs == [0.0, 0.5, 1.0, 1.5, 2.0, 2.0]
+    opt0 = torch.optim.SGD([p], lr=2.0)
+    sch0 = VF.get_constant_schedule_with_warmup(opt0, num_warmup_steps=0)
+    assert opt0.param_groups[0]["lr"] == 0.0                                   # the first update of a zero-warm-up run trains at lr = 0
+    opt0.step(); sch0.step()
+    assert opt0.param_groups[0]["lr"] == 2.0

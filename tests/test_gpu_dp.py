@@ -88,7 +88,11 @@ def test_slices_announced_during_backward_are_final_and_disjoint(setup):
     st.grad.zero_()
 
 
-def test_overlapped_exchange_leaves_the_same_weights_as_the_plain_one(setup):
+@pytest.mark.parametrize("exchange", ["allreduce", "reduce_scatter"])
+def test_overlapped_exchange_leaves_the_same_weights_as_the_plain_one(setup, exchange):
+    """exchange = reduce_scatter: SURVEY §5.8's direct schedule (all-to-all of shards, shard sums and all-gathers on a side stream)
+    through RCCL — on a 1-rank group the collectives are copies, so the weights must be bit-identical to the all-reduce's; the
+    stream ordering (side stream waits for the gradient kernels, the optimizer waits for the side stream) is what is under test."""
     z, cfg, params = setup
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -97,7 +101,7 @@ def test_overlapped_exchange_leaves_the_same_weights_as_the_plain_one(setup):
     try:
         out = []
         for overlap in (False, True):
-            eng = _engine(cfg, params, allreduce_bucket_mb=1)
+            eng = _engine(cfg, params, allreduce_bucket_mb=1, grad_exchange=exchange)
             eng.fuse_micro_batches = 1                       # two passes per optimizer step: only the second may announce slices
             eng.sync_grads, eng.overlap_allreduce = True, overlap
             eng.sched_steps = 1                              # past the lr = 0 first call

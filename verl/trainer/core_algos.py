@@ -61,6 +61,35 @@ def compute_grpo_outcome_advantage(token_level_rewards: torch.Tensor, response_m
     return adv, adv
 
 
+class _PolicyLoss(torch.autograd.Function):
+    """st_grpo_loss with the KL term off = compute_policy_loss: the kernel returns the four masked means and d(pg_loss)/d(log_probs)."""
+
+    @staticmethod
+    def forward(ctx, log_probs, old_log_probs, advantages, response_mask, lo, hi, dual):
+        dev = log_probs.device if log_probs.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        f = lambda t: t.detach().reshape(-1).to(dev, torch.float32).contiguous()
+        g, met = ops.grpo_loss(f(log_probs), f(old_log_probs), None, f(advantages), response_mask.reshape(-1).to(dev, torch.int64).contiguous(),
+                               clip_low=lo, clip_high=hi, clip_dual=dual, kl_kind="kl", kl_coef=0.0, grad_accum=1.0)
+        ctx.save_for_backward(g.view(log_probs.shape).to(log_probs.device))
+        m = met.to(log_probs.device)
+        ctx.mark_non_differentiable(m[1], m[2], m[3])
+        return m[0].clone(), m[1].clone(), m[2].clone(), m[3].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss, *_):
+        (g,) = ctx.saved_tensors
+        return g_loss * g, None, None, None, None, None, None
+
+
+def compute_policy_loss(old_log_probs: torch.Tensor, log_probs: torch.Tensor, advantages: torch.Tensor, response_mask: torch.Tensor,
+                        clip_ratio_low: float, clip_ratio_high: float, clip_ratio_dual: float
+                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """core_algos.py:291-353 under the reference's name and argument order: (pg_loss, pg_clipfrac_higher, pg_clipfrac_lower, ppo_kl),
+    all token-means over response_mask (masked_mean, eps 1e-8); pg_loss is differentiable w.r.t. log_probs (dual-clip PPO:
+    max(-A r, -A clip(r)) capped at -A * clip_ratio_dual where A < 0).  One launch of st_grpo_loss."""
+    return _PolicyLoss.apply(log_probs, old_log_probs, advantages, response_mask, float(clip_ratio_low), float(clip_ratio_high), float(clip_ratio_dual))
+
+
 def compute_policy_loss_and_kl(old_log_probs, log_probs, advantages, response_mask, ref_log_probs=None, *, clip_ratio_low=0.2,
                                clip_ratio_high=0.3, clip_ratio_dual=3.0, kl_penalty="low_var_kl", kl_coef=0.0):
     """(pg_loss(+kl_coef*kl), clipfrac_higher, clipfrac_lower, ppo_kl, kl_loss, dloss/dlog_probs) through st_grpo_loss."""

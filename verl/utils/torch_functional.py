@@ -1,11 +1,18 @@
-"""Host tensor helpers with the reference's names (verl/utils/torch_functional.py).  The heavy entries of that file live in the
-HIP library (log_probs_from_logits -> st_logprob_fwd/bwd, AnyPrecisionAdamW -> st_adamw_kahan_step); what remains here is the
-integer / bookkeeping work the workers and the trainer do on (batch, length) host tensors."""
+"""The reference's tensor-level helpers under the reference's names (verl/utils/torch_functional.py).
+
+Host bookkeeping on (batch, length) tensors — masked_mean, get_response_mask, pad_2d_list_to_length, postprocess_data — is plain
+torch.  The heavy entries are the HIP library behind the reference's own signatures, so code written against the reference imports
+and runs unchanged:
+  log_probs_from_logits(logits, labels)   :34-66    -> autograd.Function over st_logprob_fwd / st_logprob_bwd
+  AnyPrecisionAdamW(params, lr, ...)      :201-329  -> torch.optim.Optimizer whose step() is st_adamw_kahan_step per parameter
+  get_constant_schedule_with_warmup(...)  :187-197  -> LambdaLR with the same multiplier
+The training engine (spatialthinker_amd/actor.py) calls the same kernels on its flat buffers directly."""
 from __future__ import annotations
 
-from typing import List, Optional, Union
+from typing import Iterable, List, Optional, Tuple, Union
 
 import torch
+from torch.optim.lr_scheduler import LambdaLR
 
 
 def masked_mean(values: torch.Tensor, mask: torch.Tensor, dim=None, eps: float = 1e-8) -> torch.Tensor:
@@ -49,3 +56,83 @@ def postprocess_data(input_ids, attention_mask, position_ids, max_length: int, p
             raise NotImplementedError(f"{n} is larger than {max_length}.")
         return input_ids[..., sl], attention_mask[..., sl], position_ids[..., sl]
     return input_ids, attention_mask, position_ids
+
+
+# ------------------------------------------------------------------ HIP-backed entries under the reference's names
+class _LogProbsFromLogits(torch.autograd.Function):
+    """logp[t] = logits[t, label[t]] - logsumexp(logits[t, :]) in one pass over the (T, V) bf16 logits (fp32 statistics); the
+    backward overwrites the logits buffer with its gradient, as flash-attn's `cross_entropy_loss(..., inplace_backward=True)` does
+    at verl/utils/torch_functional.py:26-31."""
+
+    @staticmethod
+    def forward(ctx, logits2d: torch.Tensor, labels1d: torch.Tensor):
+        from spatialthinker_amd import ops
+        logp, lse = ops.logprob_fwd(logits2d, labels1d, 1.0)
+        ctx.save_for_backward(logits2d, labels1d, lse)
+        return logp
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        from spatialthinker_amd import ops
+        logits2d, labels1d, lse = ctx.saved_tensors
+        ops.logprob_bwd_(logits2d, labels1d, lse, grad_out.contiguous().float(), 1.0)          # in place: logits <- dlogits
+        return logits2d, None
+
+
+def log_probs_from_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """:44-66 — log-probs of `labels` under `logits` (..., V) -> (...) fp32, the flash-attn sign convention (-NLL).
+    bf16 logits on the GPU (what the actor produces, dp_actor.py:125-128); anything else is converted first."""
+    batch_dim, vocab = logits.shape[:-1], logits.shape[-1]
+    dev = logits.device if logits.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    z = logits.to(dev, torch.bfloat16).contiguous().view(-1, vocab)
+    lab = labels.to(dev, torch.int64).contiguous().view(-1)
+    return _LogProbsFromLogits.apply(z, lab).view(*batch_dim).to(logits.device)
+
+
+def get_constant_schedule_with_warmup(optimizer: torch.optim.Optimizer, num_warmup_steps: int, last_epoch: int = -1):
+    """:187-197 — lr * min(1, step / max(1, num_warmup_steps)); step 0 of a zero-warm-up schedule therefore trains at lr = 0
+    (PolicyEngine.current_lr reproduces the same multiplier on its own counter)."""
+    return LambdaLR(optimizer, lambda step: min(1.0, float(step) / float(max(1, num_warmup_steps))), last_epoch)
+
+
+class AnyPrecisionAdamW(torch.optim.Optimizer):
+    """:201-329 — AdamW with bf16 momentum / variance / Kahan-compensation buffers.  One fused HIP pass per parameter
+    (st_adamw_kahan_step) with the rounding points of the reference's op sequence executed by torch on the GPU (bit-exact:
+    tests/test_gpu_kernels.py).  Parameters must be bf16 CUDA tensors; gradients may be bf16 or fp32 (rounded to bf16 first, the
+    dtype the reference's optimizer sees).  Only the configuration the reference constructs is built (fsdp_workers.py:292-299:
+    Kahan summation on, bf16 states)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, use_kahan_summation: bool = True, momentum_dtype: torch.dtype = torch.bfloat16,
+                 variance_dtype: torch.dtype = torch.bfloat16, compensation_buffer_dtype: torch.dtype = torch.bfloat16):
+        if not use_kahan_summation or any(d != torch.bfloat16 for d in (momentum_dtype, variance_dtype, compensation_buffer_dtype)):
+            raise NotImplementedError("AnyPrecisionAdamW: only use_kahan_summation=True with bf16 state dtypes is built (the reference's configuration)")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, use_kahan_summation=use_kahan_summation,
+                        momentum_dtype=momentum_dtype, variance_dtype=variance_dtype, compensation_buffer_dtype=compensation_buffer_dtype)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from spatialthinker_amd import ops
+        if closure is not None:
+            with torch.enable_grad():
+                closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("AnyPrecisionAdamW does not support sparse gradients.")
+                if p.dtype != torch.bfloat16 or not p.is_cuda or not p.is_contiguous():
+                    raise TypeError("AnyPrecisionAdamW (HIP): parameters must be contiguous bf16 CUDA tensors")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0)
+                    state["exp_avg"] = torch.zeros_like(p, dtype=torch.bfloat16)
+                    state["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.bfloat16)
+                    state["compensation"] = torch.zeros_like(p, dtype=torch.bfloat16)
+                state["step"] += 1
+                g32 = p.grad.detach().contiguous().view(-1).float()
+                ops.adamw_kahan_step_(p.data.view(-1), g32, state["exp_avg"].view(-1), state["exp_avg_sq"].view(-1),
+                                      state["compensation"].view(-1), t=int(state["step"].item()), lr=group["lr"], betas=tuple(group["betas"]),
+                                      eps=group["eps"], weight_decay=group["weight_decay"])

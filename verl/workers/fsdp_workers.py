@@ -96,7 +96,10 @@ class FSDPWorker:
                                ppo_epochs=a.ppo_epochs, use_kl_loss=a.use_kl_loss, disable_kl=a.disable_kl, kl_penalty=a.kl_penalty,
                                kl_coef=a.kl_coef, lr=a.optim.lr, betas=tuple(a.optim.betas), weight_decay=a.optim.weight_decay,
                                lr_warmup_steps=int(a.optim.lr_warmup_ratio * max(a.optim.training_steps, 0)),
-                               optim_strategy=a.optim.strategy, freeze_vision_tower=bool(mc.freeze_vision_tower))
+                               optim_strategy=a.optim.strategy, freeze_vision_tower=bool(mc.freeze_vision_tower),
+                               # FSDP's MixedPrecision(reduce_dtype=...) of the reference (fsdp_workers.py:238-243) = the payload dtype of the
+                               # gradient exchange here; ST_GRAD_EXCHANGE=reduce_scatter selects SURVEY §5.8's direct schedule
+                               grad_exchange_dtype="bf16" if str(a.fsdp.mp_reduce_dtype).lower() in ("bf16", "bfloat16") else "fp32")
             self.model_config, self.special = cfg, special
             self.actor = PolicyEngine(cfg, store, hyper)
             self.flops_counter = FlopsCounter(cfg)

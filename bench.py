@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
-    ap.add_argument("--recompute-light", action="store_true", help="recompute the RMSNorm / SwiGLU outputs in the backward instead of keeping them (-1/3 activation memory)")
+    ap.add_argument("--no-recompute-light", action="store_true", help="keep the RMSNorm / SwiGLU outputs for the backward instead of recomputing them (+50 %% activation memory per packed token)")
+    ap.add_argument("--tokens-grad", type=int, default=None, help="packed-token budget of an update pass (default: engine default, ST_TOKENS_GRAD)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = BASELINE config #5's arithmetic: the LM projection GEMMs of every forward pass on the MX-fp8 (OCP e4m3, block-"
@@ -332,8 +333,10 @@ def main():
     ref = PolicyEngine(cfg, ref_store, None)
     if a.fuse_micro_batches is not None:
         actor.fuse_micro_batches = a.fuse_micro_batches
-    if a.recompute_light:
-        actor.model.recompute_light = True
+    if a.no_recompute_light:
+        actor.model.recompute_light = False
+    if a.tokens_grad is not None:
+        actor.tokens_per_pass_grad = a.tokens_grad
     if a.dtype == "fp8":
         actor.model.enable_fp8(True)
         ref.model.enable_fp8(True)
@@ -396,17 +399,17 @@ def main():
             plen = mask[:, :].sum(1)                                         # valid prompt tokens per prompt
             rlen = rmask.sum(1).tolist()
 
-            def executed(mb, cached=False):
+            def executed(passes, cached=False):
                 groups = []
-                for s0 in range(0, B, mb):
-                    rows = list(range(s0, min(B, s0 + mb)))
+                for (s0, s1) in passes:                                      # the row ranges the engine actually ran (token-budgeted)
+                    rows = list(range(s0, s1))
                     for pr in sorted(set(r // G for r in rows)):
                         groups.append((int(plen[pr]), [rlen[r] for r in rows if r // G == pr]))
                 return cfg.flops_forward_grouped(groups, [] if cached else [n_patch] * len(groups), logit_rows=int(rmask.sum()),
                                                  prefix_cached=cached)
-            f_exp = executed(hyper.micro_batch_size_per_device_for_experience)
-            f_upd = executed(micro * max(1, min(actor.fuse_micro_batches, (B // n_opt) // micro)))
-            f_old = executed(hyper.micro_batch_size_per_device_for_experience, cached=True)      # prompt K/V re-used from the rollout
+            f_exp = executed(ref.last_plan["experience"])
+            f_upd = executed(actor.last_plan["update"])
+            f_old = executed(actor.last_plan["experience"], cached=actor.last_prompt_cache_hit)   # prompt K/V re-used from the rollout
             flops["old"] += f_old; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
             flops["reference_formulation"] = flops.get("reference_formulation", 0.0) + 5 * f_ref
             tokens_total[0] += int(mask_f.sum())

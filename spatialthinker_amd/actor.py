@@ -168,6 +168,15 @@ class GradReducer:
         self.grad.mul_(1.0 / self.world)                          # FSDP reduce-scatter averages over ranks
 
 
+def release_cached_blocks():
+    """End of a phase (rollout / a log-prob pass / update): hand the allocator's cached blocks back to the driver.  The phases
+    allocate differently shaped tensors (KV caches, 150k-wide logits, per-layer activations of passes whose packed length changes
+    every step); carried over, the split blocks of one phase fragment the next one and the reserved pool creeps up step after step
+    (round 2: 202 -> 235 GB over 25 steps).  Four calls per step, each a few ms.  ST_EMPTY_CACHE=0 switches it off."""
+    if os.environ.get("ST_EMPTY_CACHE", "1") != "0" and torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
 def _rows(x, sl):
     return x[sl] if x is not None else None
 
@@ -188,15 +197,22 @@ class PolicyEngine:
         self.overlap_allreduce = os.environ.get("ST_OVERLAP_ALLREDUCE", "1") != "0"
         self._reducer: Optional[GradReducer] = None
         self.share_prompts = True     # pack the prompt of a rollout group once (see _stage)
-        # reference micro-batches per forward/backward pass (update_policy): 8 x 4 rows ~ 21k packed tokens per pass.  With the light
-        # activations (RMSNorm / SwiGLU outputs) recomputed in the backward the pass keeps ~60 GB and the step peaks at 201 GB
-        # allocated / 202 GB reserved of the 288 GB; 4 passes-worth without recomputation peaked at 183 / 211 GB and ran 2 % slower
-        # (round 2, bench workload: update 15.5 -> 15.2 s)
-        self.fuse_micro_batches = 8
+        # Several reference micro-batches ride in one forward(/backward) pass, as many as a PACKED-TOKEN budget admits (_plan_passes):
+        # the reference's contract is that micro_batch_size_per_device_* holds for any sequence length up to max_prompt_length +
+        # max_response_length (dp_actor.py:169-292, scripts/spatialthinker_7b_grpo.sh:33-34), so the fusion factor is derived from the
+        # rows at hand, never a constant.  With gradients a packed token keeps ~3.0 MB of activations at 7B (28 layers x (x0, qkv, attn
+        # out, x1, gate|up) bf16, the RMSNorm / SwiGLU outputs recomputed in the backward): 24k tokens = ~72 GB next to the 131 GB of
+        # weights, gradients, optimizer state and the frozen reference.  The bench's 8 x 4 rows (~21k tokens) fit one pass; 32 rows at
+        # the 2048-token response cap (~70k tokens) are cut into passes of 8 rows.  A single reference micro-batch is never split.
+        self.fuse_micro_batches = 8                                                      # upper bound on micro-batches per update pass
+        self.tokens_per_pass_grad = int(os.environ.get("ST_TOKENS_GRAD", "24576"))
         if hyper is not None:
             self.model.recompute_light = True
-        self.fuse_experience = int(os.environ.get("ST_FUSE_EXPERIENCE", "4"))      # no-grad log-prob passes run this many reference micro-batches at once: rows are independent
-                                      # there (no loss normalisation), the result is bit-identical, the GEMMs see 4x the rows
+        # no-grad log-prob passes: rows are independent there (no loss normalisation), the result does not depend on the grouping,
+        # the GEMMs see more rows; activations are transient (~0.2 MB per packed token + 0.3 MB per response row of logits at 7B)
+        self.fuse_experience = int(os.environ.get("ST_FUSE_EXPERIENCE", "16"))         # upper bound on micro-batches per no-grad pass
+        self.tokens_per_pass_nograd = int(os.environ.get("ST_TOKENS_NOGRAD", "65536"))
+        self.last_plan: Dict[str, list] = {}          # row ranges of the passes of the latest compute_log_prob / update_policy call
         self.last_prompt_cache_hit = False   # did the latest compute_log_prob run on the rollout's prompt K/V? (perf/prompt_cache_hit)
         self.opt_steps = 0            # t of AdamW (state["step"])
         self.sched_steps = 0          # lr_scheduler.step() calls so far: once per update_policy call (fsdp_workers.py:453)
@@ -239,6 +255,42 @@ class PolicyEngine:
             gr = np.concatenate([np.asarray(items[r]["image_grid_thw"]).reshape(-1, 3) for r in owners], 0)
         return self.model.stage(ids, am, data["position_ids"][sl], R, px, gr, groups=groups)
 
+    # ------------------------------------------------------------------ token-budgeted passes
+    def _row_stats(self, data: Dict[str, Any], R: int):
+        """Per row: valid prompt tokens, valid response tokens and an identity of (prompt, image) — what one packed pass holds is
+        every response + each DISTINCT prompt once (shared-prompt packing, _stage)."""
+        ids, am = _to_np(data["input_ids"]), _to_np(data["attention_mask"])
+        Pc = ids.shape[1] - R
+        p_len, r_len = am[:, :Pc].sum(1).astype(np.int64), am[:, Pc:].sum(1).astype(np.int64)
+        mm = data.get("multi_modal_inputs")
+        keys = []
+        for r in range(ids.shape[0]):
+            it = mm[r] if mm is not None else None
+            img = id(it["pixel_values"]) if (it is not None and "pixel_values" in it) else None
+            keys.append(hash((img, ids[r, :Pc].tobytes(), am[r, :Pc].tobytes())) if self.share_prompts else r)
+        return p_len, r_len, keys
+
+    @staticmethod
+    def _plan_passes(lo: int, hi: int, unit: int, max_units: int, budget: int, p_len, r_len, keys, prompts_cached: bool = False) -> List[tuple]:
+        """Cut rows [lo, hi) into passes of whole `unit`-row blocks (the reference's micro-batches): a pass grows block by block while
+        it stays within `max_units` blocks and `budget` packed tokens.  One block always forms a pass, whatever its size."""
+        def tokens(a, b):
+            t = int(r_len[a:b].sum())
+            if not prompts_cached:
+                seen = {}
+                for r in range(a, b):
+                    seen.setdefault(keys[r], int(p_len[r]))
+                t += sum(seen.values())
+            return t
+        out, s0 = [], lo
+        while s0 < hi:
+            e = min(hi, s0 + unit)
+            while e < hi and (e - s0) // unit < max_units and tokens(s0, min(hi, e + unit)) <= budget:
+                e = min(hi, e + unit)
+            out.append((s0, e))
+            s0 = e
+        return out
+
     @torch.no_grad()
     def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None,
                          prompt_cache: Optional[dict] = None) -> torch.Tensor:
@@ -248,24 +300,29 @@ class PolicyEngine:
         need no second pass over the prompts and images."""
         N = data["input_ids"].shape[0]
         mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
-        mb *= max(1, int(self.fuse_experience))
         R = data["responses"].shape[1]
         self.last_prompt_cache_hit = bool(prompt_cache is not None and self._cache_matches(data, prompt_cache, R))
+        p_len, r_len, keys = self._row_stats(data, R)
+        passes = self._plan_passes(0, N, mb, max(1, int(self.fuse_experience)), self.tokens_per_pass_nograd, p_len, r_len, keys,
+                                   prompts_cached=self.last_prompt_cache_hit)
+        self.last_plan["experience"] = passes
+        outs = []
         if self.last_prompt_cache_hit:
             n = prompt_cache["n"]
-            outs = []
-            for s in range(0, N, mb):
-                sl = slice(s, min(N, s + mb))
-                rows = np.arange(sl.start, sl.stop)
+            for (a, b_) in passes:
+                sl = slice(a, b_)
+                rows = np.arange(a, b_)
                 b = self.model.stage_responses(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R,
                                                rows // n, prompt_cache["p_off"])
                 outs.append(self.model.log_probs_cached(b, prompt_cache, temperature))
-            return torch.cat(outs, 0)
-        outs = []
-        for s in range(0, N, mb):
-            b = self._stage(data, slice(s, min(N, s + mb)))
-            outs.append(self.model.log_probs(b, temperature))
-        return torch.cat(outs, 0)
+        else:
+            for (a, b_) in passes:
+                b = self._stage(data, slice(a, b_))
+                outs.append(self.model.log_probs(b, temperature))
+        out = torch.cat(outs, 0)
+        del outs, b
+        release_cached_blocks()
+        return out
 
     def _cache_matches(self, data: Dict[str, Any], cache: dict, R: int) -> bool:
         """The cache is usable only for exactly the prompts it was built from (row r <-> prompt r // n) and the current weights."""
@@ -340,17 +397,18 @@ class PolicyEngine:
         assert N % mini == 0 and mini % micro == 0, (N, mini, micro)
         accum = mini // micro
         # several reference micro-batches per forward/backward pass (each keeps its own loss normalisation, see
-        # Qwen25VL.forward_backward): with micro = 4 and G = 8 a pass then holds a whole rollout group behind ONE prompt copy
-        fuse = max(1, min(self.fuse_micro_batches, accum))
-        while accum % fuse:
-            fuse -= 1
-        rows = micro * fuse
+        # Qwen25VL.forward_backward): with micro = 4 and G = 8 a pass then holds a whole rollout group behind ONE prompt copy.  How
+        # many is decided per pass from the packed-token count of the rows at hand (_plan_passes)
+        p_len, r_len, keys = self._row_stats(data, R)
+        plan = self.last_plan["update"] = []
         for _ in range(h.ppo_epochs):
             for m0 in range(0, N, mini):
-                for s in range(m0, m0 + mini, rows):
-                    sl = slice(s, s + rows)
+                passes = self._plan_passes(m0, m0 + mini, micro, max(1, int(self.fuse_micro_batches)), self.tokens_per_pass_grad, p_len, r_len, keys)
+                plan.extend(passes)
+                for (s, e) in passes:
+                    sl = slice(s, e)
                     # the last pass of the optimizer step: gradient slices go out to the other ranks as backward leaves them
-                    red = self.grad_reducer() if (self.overlap_allreduce and s + rows >= m0 + mini) else None
+                    red = self.grad_reducer() if (self.overlap_allreduce and e >= m0 + mini) else None
                     b = self._stage(data, sl)
                     to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
                     loss_in = dict(old_log_probs=to("old_log_probs"), advantages=to("advantages"),
@@ -373,4 +431,5 @@ class PolicyEngine:
                 metrics["actor/kl_coef"] = h.kl_coef
         self.sched_steps += 1
         metrics["actor/lr"] = self.current_lr()                   # lr AFTER scheduler.step(), as fsdp_workers.py:453-455
+        release_cached_blocks()
         return dict(metrics)

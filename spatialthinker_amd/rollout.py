@@ -322,6 +322,9 @@ class Generator:
             self.stats["decode_bytes"] += nbytes
             self.stats["decode_row_steps"] += rows
         self._timers = []
+        del kg, vg, logits_g
+        from .actor import release_cached_blocks
+        release_cached_blocks()                       # the generated-token K/V and the logits of this rollout are gone: see actor.py
         if return_prompt_cache:
             return out, dict(kp=kp, vp=vp, last_h=last_h, p_off=p_off.astype(np.int64), prompt_ids=ids_np, prompt_mask=mask_np, n=n,
                              weights_version=getattr(self.m.p, "version", 0))

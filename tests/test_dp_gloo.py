@@ -129,6 +129,7 @@ def _announce_worker(rank, world, port, out_dir):
     eng.store = types.SimpleNamespace(grad=torch.zeros(n), device="cpu")
     eng.world, eng.pg, eng.sync_grads, eng.overlap_allreduce, eng._reducer = world, None, True, True, None
     eng.fuse_micro_batches, eng.sched_steps, eng.opt_steps = 2, 0, 0
+    eng.share_prompts, eng.tokens_per_pass_grad, eng.last_plan = False, 10 ** 9, {}
     log, passes = [], [0]
 
     def fwd_bwd(b, loss_in, temperature, **kw):

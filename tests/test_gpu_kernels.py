@@ -420,7 +420,8 @@ def test_attn_fwd(ops, measured, lens, n_q, n_kv, D, causal):
                              xf[:, (n_q + n_kv) * D:].reshape(T, n_kv, D), cu, causal).reshape(T, n_q * D)
     err = np.abs(out.float().cpu().numpy() - want.numpy()).max()
     measured(f"attn_fwd_D{D}_{'c' if causal else 'f'}_{sum(lens)}", err)
-    assert err < 2e-2, err                                           # P is rounded to bf16 before PV (as flash-attn does)
+    assert err < 1.05e-2, err                                        # measured <= 0.0080 over the cases (1.3x): P is rounded to bf16 before PV (as
+                                                                     # flash-attn does) and O(1) outputs land on the bf16 grid (half an ulp at 2..4 = 0.0078)
     # spiked key forces the online-softmax rescale branch on a late tile
     qkv2 = qkv.clone().float()
     if lens[0] > 70:
@@ -432,7 +433,7 @@ def test_attn_fwd(ops, measured, lens, n_q, n_kv, D, causal):
                               xf2[:, (n_q + n_kv) * D:].reshape(T, n_kv, D), cu, causal).reshape(T, n_q * D)
     err2 = np.abs(out2.float().cpu().numpy() - want2.numpy()).max()
     measured(f"attn_fwd_spiked_D{D}_{'c' if causal else 'f'}_{sum(lens)}", err2)
-    assert err2 < 2e-2, err2
+    assert err2 < 1.05e-2, err2                                      # measured <= 0.0080
 
 
 @pytest.mark.parametrize("lens,n_q,n_kv,D,causal", [
@@ -459,7 +460,7 @@ def test_attn_bwd(ops, measured, lens, n_q, n_kv, D, causal):
     for name, sl in (("dq", slice(0, n_q * D)), ("dk", slice(n_q * D, (n_q + n_kv) * D)), ("dv", slice((n_q + n_kv) * D, None))):
         err = np.abs(got[:, sl] - want[:, sl]).max() / (np.abs(want[:, sl]).max() + 1e-9)
         measured(f"attn_bwd_{name}_D{D}_{'c' if causal else 'f'}_{sum(lens)}", err)
-        assert err < 2e-2, (name, err)
+        assert err < 8.0e-3, (name, err)                            # measured <= 0.0061 of the gradient's max (1.3x)
 
 
 # ------------------------------------------------------------------ fused decode epilogues vs the unfused launch chain
@@ -561,11 +562,11 @@ def test_attn_seg_shared_prefix_fwd_bwd(ops, measured, groups):
     gr = leaf.grad
     e_f = float((out.float().cpu()[:T] - ref_out[:T]).abs().max())
     measured(f"attn_seg_fwd_{T}", e_f)
-    assert e_f < 2e-2, e_f
+    assert e_f < 1.02e-2, e_f                                         # measured <= 0.0078
     for name, got, want in (("dq", dq, gr[:, :n_q * D]), ("dk", dk, gr[:, n_q * D:(n_q + n_kv) * D]), ("dv", dv, gr[:, (n_q + n_kv) * D:])):
         err = float((got.float().cpu()[:T] - want[:T]).abs().max())
         measured(f"attn_seg_{name}_{T}_rel", err / float(want.abs().max()))
-        assert err < 0.02 * float(want.abs().max()) + 1e-2, (name, err, float(want.abs().max()))
+        assert err < 7.0e-3 * float(want.abs().max()), (name, err, float(want.abs().max()))      # measured <= 0.0054 (1.3x)
 
 
 @pytest.mark.parametrize("M_,I,K", [(517, 1216, 256), (300, 200, 128), (1024, 4096, 512)])

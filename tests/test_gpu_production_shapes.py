@@ -173,7 +173,8 @@ def test_decode_path_at_7b_widths_vs_fp32_oracle(ops, lm7b, measured, rows, wave
     # logits are O(1) (std 0.7, |max| ~ 3.5): one bf16 ulp at that size is 0.0156
     assert worst < 0.06, worst                                              # thresholds at <= 1.3x measured: DESIGN.md §4
     assert worst_margin < 0.08, worst_margin                                # a differing greedy token is always a near-tie of the fp32 logits
-    assert tok_agree / tok_checked > 0.9
+    # (exact agreement with the fp32 argmax is NOT asserted: the ramp-initialised head makes the top logits of a row near-ties a few
+    # 1e-3 apart, far below the bf16 noise — the margin above is the meaningful statement; the agreement rate is only recorded)
     del gen, taps, kc, vc
     torch.cuda.empty_cache()
 

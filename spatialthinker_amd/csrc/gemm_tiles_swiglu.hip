@@ -1,0 +1,71 @@
+// gemm_tiles_swiglu.hip — gate/up projection with the SwiGLU epilogue (training and decode).
+#include "gemm_tile_kernel.h"
+
+/* gate/up projection with the SwiGLU in the epilogue for any M (training / prefill): m_out[M, I] = silu(A gate_w^T) * (A up_w^T);
+ * gu_out (optional, [M, 2I]) additionally receives the bf16 gate|up values the backward needs. */
+extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* gu_out, int64_t ldgu,
+                              st_bf16* m_out, int64_t ldm, int M, int I, int K, st_stream_t stream) {
+    if (!A || !gate_up_w || !m_out || M <= 0 || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldm < I ||
+        (gu_out && ldgu < 2 * (int64_t)I) || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)(2 * I) * (double)K);
+    return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, m_out, ldm, M, I, K, s, gu_out, ldgu);
+}
+
+/* tuning entry: the decode gate/up + SwiGLU GEMM on an explicit tile (tools/decode_swiglu_tune.py):
+ * 1 = 256x160 3 slots (8-column interleave)   2 = 256x192 2 slots   3 = 256x256 2 slots   4 = 256x256 mid-tile barrier (training tile)
+ * 5 = 256x192 mid-tile barrier   6 = 128x128 3 slots   7 = 64x128 3 slots */
+extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out,
+                                             int64_t ldc, int M, int I, int K, st_stream_t stream) {
+    if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+        ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 3: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 4: return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 5: return launch_tile_swiglu<256, 192, 4, 2, 2, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 6: return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 7: return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        default: return ST_EINVAL;
+    }
+}
+
+// Tile choice of the decode gate/up + SwiGLU GEMM (ids of st_gemm_swiglu_decode_variant).
+// One row tile (M <= 256) or two (257..512): the only freedom is the column tile.  Cost ~ rounds over 256 CUs x tile width; the 7B
+// gate/up (I = 18944) gives 148 tiles at 128 output columns (0.58 of the CUs) and 198 at 96 (-10 % time).  A 256x160 tile as 8x1
+// waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
+// 256x160 with the 8-column interleave (id 1): 3-slot ring (two K-tiles of weights in flight: the 2-slot variants sit parked on HBM
+// latency half of the time) and 237 workgroups for I = 18944: 90 us vs 102 us (256x192) on MI355X.
+static int swiglu_decode_plan(int M, int I) {
+    if (M <= 64) return 7;
+    if (M <= 128) return 6;
+    auto cost = [&](int cols) { const int t = st_cdiv(M, 256) * st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
+    if (cost(80) <= cost(96) && cost(80) <= cost(128)) return 1;
+    if (cost(96) <= cost(128)) return 2;
+    return 3;
+}
+extern "C" int st_gemm_swiglu_decode_plan(int M, int I, int* variant_out) {
+    if (M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || !variant_out) return ST_EINVAL;
+    *variant_out = swiglu_decode_plan(M, I);
+    return 0;
+}
+
+extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out, int64_t ldc,
+                                     int M, int I, int K, st_stream_t stream) {
+    if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
+        ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (swiglu_decode_plan(M, I)) {
+        case 7: return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 6: return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        default: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    }
+}
+

@@ -347,6 +347,7 @@ def main():
     flops = {"old": 0.0, "ref": 0.0, "update": 0.0}
     phase = {k: 0.0 for k in ("gen", "reward", "old", "ref", "adv", "update_actor")}
     tokens_total = [0]
+    reserved_trace = []          # reserved GB at the end of every step (warm-up included): allocator creep shows here
 
     # the synthetic rollout batches (random images are ~0.4 GB of host RNG output per step) are drawn BEFORE the timed region: a
     # training job's dataloader workers prepare the next batch while the GPU runs the current step
@@ -387,6 +388,7 @@ def main():
         t5 = tick()
         metrics = actor.update_policy(data, temperature)
         t6 = tick()
+        reserved_trace.append(round(torch.cuda.memory_reserved() / 2 ** 30, 1))
         if timed:
             for k, v in zip(phase, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
                 phase[k] += v
@@ -503,6 +505,9 @@ def main():
             "perf_throughput_tokens_per_s_per_gpu": tokens_total[0] / elapsed,
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
+            "reserved_gb_after_each_step": reserved_trace,
+            "passes_per_step": {"update": len(actor.last_plan.get("update", [])), "old": len(actor.last_plan.get("experience", [])),
+                                "ref": len(ref.last_plan.get("experience", []))},
             "actor_mfu": (flops["old"] + flops["ref"] + flops["update"]) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "actor_mfu_reference_flops": flops.get("reference_formulation", 0.0) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "roofline": main_roof,

@@ -325,6 +325,23 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
               const int32_t* row_steps /* NULL or (B,): per-row step overriding step/step_dev (rows at different response indices) */,
               int32_t* out_ids, float* scratch, st_stream_t stream);
 
+/* ---- rollout decode: the bookkeeping between two decode forwards in ONE launch (vLLM's sampler output processing + scheduler state
+ *      behind verl/workers/rollout/vllm_rollout_spmd.py:141-147; here ~25 one-element-per-row launches of the captured iteration) ------
+ * st_sample_partials: st_sample without its last stage — the 16 partial (value, index) pairs per row stay in scratch (B*33 floats).
+ * st_decode_step, per row b (one workgroup): token = argmax of the partials (forced_token where forced_len[b] == gen_len[b] + 1);
+ *   if active[b]: out_tokens[b, min(gen_len[b], R-1)] = token;  active[b] &= !(gen_len[b] + 1 >= R || token in eos_ids (unless ignore_eos));
+ *   tok_out[b] = token;  slot_out[b] = min(gen_len[b], R-1) (cache slot of this token's K/V);  gen_len[b] += 1;
+ *   ke_gen[c*B + b] = clamp(k_base[b] + slot + 1, kb_gen[c*B + b], kb_gen[c*B + b] + chunk_keys) for the n_chunks generated-key chunks;
+ *   cos_out/sin_out[b, :] = M-RoPE table row of pos[:, b] (as st_mrope_table), then pos[:, b] += 1;  x_out[b, :H] = embed[token, :H]. */
+int st_sample_partials(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
+                       uint64_t step, const int64_t* step_dev, const int32_t* row_ids, const int32_t* row_steps, float* scratch,
+                       st_stream_t stream);
+int st_decode_step(const float* sample_scratch, const int32_t* forced_len, int32_t forced_token, const int64_t* eos_ids, int n_eos,
+                   int ignore_eos, int32_t* gen_len, int32_t* active, int64_t* out_tokens, int R, int32_t* tok_out, int32_t* slot_out,
+                   const int32_t* k_base, const int32_t* kb_gen, int32_t* ke_gen, int n_chunks, int chunk_keys, int32_t* pos,
+                   const float* inv_freq, int D, int s0, int s1, int s2, float* cos_out, float* sin_out, const st_bf16* embed,
+                   int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, st_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

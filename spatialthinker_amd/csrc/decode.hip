@@ -393,6 +393,67 @@ __global__ __launch_bounds__(256) void decode_finish_qkv_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// decode_step_kernel: everything between two decode forwards in ONE launch, one workgroup per live row (the captured iteration used
+// to spend ~25 one-element-per-row torch kernels on it): finish the split sampler (argmax over the 16 partials, forced EOS), record
+// the token, update the live flag / response index / cache slot / generated-key range ends, build the row's M-RoPE cos/sin for
+// the position of this token and advance the position, gather the token's embedding row.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_step_kernel(const float* __restrict__ partials, int splits, const int32_t* __restrict__ forced_len,
+                                                         int forced_token, const int64_t* __restrict__ eos_ids, int n_eos, int ignore_eos,
+                                                         int32_t* __restrict__ gen_len, int32_t* __restrict__ active, int64_t* __restrict__ out_tokens,
+                                                         int R, int32_t* __restrict__ tok_out, int32_t* __restrict__ slot_out,
+                                                         const int32_t* __restrict__ k_base, const int32_t* __restrict__ kb_gen,
+                                                         int32_t* __restrict__ ke_gen, int n_chunks, int chunk_keys, int32_t* __restrict__ pos,
+                                                         const float* __restrict__ inv_freq, int half, int s0, int s1, float* __restrict__ cosb,
+                                                         float* __restrict__ sinb, const uint16_t* __restrict__ embed, int64_t ld_embed,
+                                                         uint16_t* __restrict__ x_out, int64_t ldx, int H, int B) {
+    __shared__ int s_tok, s_pos[3];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        for (int k = 0; k < splits; ++k) {                   // same order and tie-break as sample_finish_kernel
+            const float b = partials[((int64_t)row * splits + k) * 2];
+            const int i = __float_as_int(partials[((int64_t)row * splits + k) * 2 + 1]);
+            if (b > best || (b == best && i < besti)) { best = b; besti = i; }
+        }
+        const int j = gen_len[row];                          // response index of this token
+        if (forced_len && forced_len[row] == j + 1) besti = forced_token;
+        const bool live = active[row] != 0;
+        const int col = j < R - 1 ? j : R - 1;               // finished rows at the cap rewrite their last slot
+        if (live) out_tokens[(int64_t)row * R + col] = (int64_t)besti;
+        bool stop = j + 1 >= R;                              // the length cap ends a sample like an EOS
+        if (!ignore_eos)
+            for (int e = 0; e < n_eos; ++e) stop = stop || ((int64_t)besti == eos_ids[e]);
+        active[row] = (live && !stop) ? 1 : 0;
+        tok_out[row] = besti;
+        slot_out[row] = col;
+        gen_len[row] = j + 1;
+        const int kend = k_base[row] + col + 1;              // one past the cache row this token's K/V will occupy
+        for (int c = 0; c < n_chunks; ++c) {
+            const int kb = kb_gen[c * B + row];
+            int ke = kb + chunk_keys < kend ? kb + chunk_keys : kend;
+            ke_gen[c * B + row] = ke > kb ? ke : kb;
+        }
+        s_tok = besti;
+    }
+    if (tid < 3) s_pos[tid] = pos[tid * B + row];
+    __syncthreads();
+    if (tid < half) {
+        const int sec = tid < s0 ? 0 : (tid < s0 + s1 ? 1 : 2);
+        const float ang = (float)s_pos[sec] * inv_freq[tid];  // as mrope_table_kernel
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        cosb[(int64_t)row * half + tid] = cs;
+        sinb[(int64_t)row * half + tid] = sn;
+    }
+    if (tid < 3) pos[tid * B + row] = s_pos[tid] + 1;
+    const uint16_t* src = embed + (int64_t)s_tok * ld_embed;
+    for (int c = tid; c < (H >> 3); c += 256)
+        *reinterpret_cast<uint4*>(x_out + (int64_t)row * ldx + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
+}
+
 extern "C" {
 
 int st_decode_finish_norm(const float* slabs, int splits, const st_bf16* residual, int64_t ldr, st_bf16* x_out, int64_t ldx,
@@ -459,6 +520,39 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
                        greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids, thr, row_steps);
     if (scratch)
         hipLaunchKernelGGL(sample_finish_kernel, dim3(st_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, scratch, splits, forced, out_ids, B);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+/* The sampler without its last stage: partial (value, index) pairs [row][16][2] stay in `scratch`; st_decode_step finishes them. */
+int st_sample_partials(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
+                       uint64_t step, const int64_t* step_dev, const int32_t* row_ids, const int32_t* row_steps, float* scratch,
+                       st_stream_t stream) {
+    if (!logits || !scratch || B <= 0 || V <= 0 || temperature < 0.f) return ST_EINVAL;
+    const int greedy = temperature == 0.f;
+    const bool filter = !greedy && ((top_k > 0 && top_k < V) || top_p < 1.f);
+    if (filter && top_p <= 0.f) return ST_EINVAL;
+    uint32_t* thr = filter ? reinterpret_cast<uint32_t*>(scratch + (int64_t)B * 32) : nullptr;
+    if (filter)
+        hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, 1.f / temperature, top_k, top_p, thr);
+    hipLaunchKernelGGL(sample_kernel, dim3(B, 16), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature, greedy,
+                       seed, step, step_dev, (const int32_t*)nullptr, (int32_t*)nullptr, scratch, row_ids, thr, row_steps);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_decode_step(const float* sample_scratch, const int32_t* forced_len, int32_t forced_token, const int64_t* eos_ids, int n_eos,
+                   int ignore_eos, int32_t* gen_len, int32_t* active, int64_t* out_tokens, int R, int32_t* tok_out, int32_t* slot_out,
+                   const int32_t* k_base, const int32_t* kb_gen, int32_t* ke_gen, int n_chunks, int chunk_keys, int32_t* pos,
+                   const float* inv_freq, int D, int s0, int s1, int s2, float* cos_out, float* sin_out, const st_bf16* embed,
+                   int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, st_stream_t stream) {
+    if (!sample_scratch || !gen_len || !active || !out_tokens || !tok_out || !slot_out || !k_base || !kb_gen || !ke_gen || !pos || !inv_freq ||
+        !cos_out || !sin_out || !embed || !x_out || B <= 0 || R <= 0 || n_chunks < 0 || D <= 0 || (D & 1) || D / 2 > 256 || s0 + s1 + s2 != D / 2 ||
+        H <= 0 || (H & 7) || (ld_embed & 7) || (ldx & 7) || (n_eos > 0 && !eos_ids))
+        return ST_EINVAL;
+    hipLaunchKernelGGL(decode_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sample_scratch, 16, forced_len, (int)forced_token, eos_ids,
+                       n_eos, ignore_eos, gen_len, active, out_tokens, R, tok_out, slot_out, k_base, kb_gen, ke_gen, n_chunks, chunk_keys, pos,
+                       inv_freq, D / 2, s0, s1, cos_out, sin_out, embed, ld_embed, x_out, ldx, H, B);
     ST_CHECK_LAUNCH();
     return 0;
 }

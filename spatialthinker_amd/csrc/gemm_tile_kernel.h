@@ -25,17 +25,23 @@ __device__ __forceinline__ void glds16t(const void* gsrc, char* lds_dst_uniform)
 
 // Copy J of a wave's run of consecutive 1-KiB pieces: the 1024*J bytes go into the instruction's immediate offset (which the hardware
 // adds to BOTH the global and the LDS address), so the run shares ONE M0 value; gsrc is the piece's true source address.
-template <int J> __device__ __forceinline__ void glds16_run(const void* gsrc, char* lds_run_base) {
+// AUX = 2: non-temporal ("nt") cache policy — for operands every workgroup reads exactly once (decode weights at one row tile):
+// issued -> landed latency of the weight stream -18 % (MI355X_MICROARCH.md price list, "nt-weights")
+template <int J, int AUX = 0> __device__ __forceinline__ void glds16_run(const void* gsrc, char* lds_run_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(gsrc) - J * 1024),
-                                     (__attribute__((address_space(3))) void*)lds_run_base, 16, J * 1024, 0);
+                                     (__attribute__((address_space(3))) void*)lds_run_base, 16, J * 1024, AUX);
 }
-__device__ __forceinline__ void glds16_run_j(int j, const void* gsrc, char* lds_run_base) {
+template <int AUX = 0> __device__ __forceinline__ void glds16_run_j(int j, const void* gsrc, char* lds_run_base) {
     switch (j) {
-        case 0: glds16_run<0>(gsrc, lds_run_base); break;
-        case 1: glds16_run<1>(gsrc, lds_run_base); break;
-        case 2: glds16_run<2>(gsrc, lds_run_base); break;
-        default: glds16_run<3>(gsrc, lds_run_base); break;
+        case 0: glds16_run<0, AUX>(gsrc, lds_run_base); break;
+        case 1: glds16_run<1, AUX>(gsrc, lds_run_base); break;
+        case 2: glds16_run<2, AUX>(gsrc, lds_run_base); break;
+        default: glds16_run<3, AUX>(gsrc, lds_run_base); break;
     }
+}
+template <int AUX> __device__ __forceinline__ void glds16t_aux(const void* gsrc, char* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, AUX);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -152,7 +158,7 @@ struct TailArgs {
 // copies there.  Slot t is refilled from R1(t) on, after both groups' reads of (t, k1) have returned (lgkmcnt(0) before their barrier).
 #define KMAJ_ANY(a, b) ((a) || (b))
 template <int BM, int BN, int WM, int WN, int STAGES, bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU = false,
-          bool MIDBAR = false, bool SW8 = false, bool LEPI = false, bool AS = false, bool BS = false, bool PP = false>
+          bool MIDBAR = false, bool SW8 = false, bool LEPI = false, bool AS = false, bool BS = false, bool PP = false, bool NTB = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t* __restrict__ A, int64_t lda,
                                                                 const uint16_t* __restrict__ B, int64_t ldb,
                                                                 const uint16_t* __restrict__ bias,
@@ -228,8 +234,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
             } else {
                 gr = n0 + r; gr = gr < N ? gr : N - 1;
             }
-            if constexpr (EVEN_DMA && B_PER <= 4 && ST_DMA_RUNS) glds16_run_j(j, B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + wave * B_PER * 1024);
-            else glds16t(B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + inst * 1024);
+            constexpr int BAUX = NTB ? 2 : 0;                // NTB: the B operand (weights) streams with the non-temporal policy
+            if constexpr (EVEN_DMA && B_PER <= 4 && ST_DMA_RUNS) glds16_run_j<BAUX>(j, B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + wave * B_PER * 1024);
+            else glds16t_aux<BAUX>(B + (int64_t)gr * ldb + kt * 64 + kc * 8, dst + A_BYTES + inst * 1024);
         }
     };
 
@@ -917,13 +924,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
 
 extern float* g_tail_ws;          // st_gemm_set_workspace: fp32 slices of split tail tiles (one stream at a time)
 extern int64_t g_tail_ws_bytes;
+extern int g_decode_nt;            // decode tiles stream their weights non-temporally when only one row tile reads them (ST_DECODE_NT)
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false, bool LE = false, bool PP_ = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool HB, bool HR, bool OB, bool AC, bool MB = false, bool LE = false, bool PP_ = false, bool NT_ = false>
 static int launch_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
                        int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int M, int N, int K, hipStream_t s, int splits = 1,
                        int64_t slab_stride = 0) {
     constexpr int smem = LE ? (STAGES * (BM + BN) * 128 > 256 * 528 ? STAGES * (BM + BN) * 128 : 256 * 528) : STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB, false, LE, false, false, PP_>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, HB, HR, OB, AC, false, MB, false, LE, false, false, PP_, NT_>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -997,11 +1005,11 @@ static int launch_tile_layout(const uint16_t* A, int64_t lda, const uint16_t* B,
     return e == hipSuccess ? 0 : (int)e;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool MB = false, bool S8 = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool MB = false, bool S8 = false, bool NT_ = false>
 static int launch_tile_swiglu(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N,
                               int K, hipStream_t s, uint16_t* gu = nullptr, int64_t ldgu = 0) {
     constexpr int smem = STAGES * (BM + BN) * 128;
-    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true, MB, S8>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, STAGES, false, false, true, false, true, MB, S8, false, false, false, false, NT_>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

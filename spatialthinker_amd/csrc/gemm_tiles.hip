@@ -4,6 +4,7 @@
 
 float* g_tail_ws = nullptr;
 int64_t g_tail_ws_bytes = 0;
+int g_decode_nt = [] { const char* e = getenv("ST_DECODE_NT"); return e ? atoi(e) : 1; }();
 
 extern "C" int st_gemm_set_workspace(void* ws, int64_t bytes) {
     g_tail_ws = reinterpret_cast<float*>(ws);

@@ -60,7 +60,13 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
         ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    switch (swiglu_decode_plan(M, I)) {
+    const int plan = swiglu_decode_plan(M, I);
+    if (g_decode_nt && M <= 256) {                           // one row tile: the weights are read once — non-temporal stream
+        if (plan == 7) return launch_tile_swiglu<64, 128, 1, 4, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        if (plan == 6 && M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        if (plan == 1) return launch_tile_swiglu<256, 160, 4, 2, 3, false, true, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+    }
+    switch (plan) {
         case 7: return launch_tile_swiglu<64, 128, 1, 4, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 6: return launch_tile_swiglu<128, 128, 2, 2, 3>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);

@@ -605,6 +605,24 @@ def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, 
     return out
 
 
+def sample_partials(logits, temperature, seed, scratch, step=0, top_k=-1, top_p=1.0, row_ids=None, row_steps=None):
+    """The sampler up to its 16 partial (value, index) pairs per row (left in `scratch`, B*33 floats); decode_step finishes them."""
+    B, V = logits.shape
+    lib().st_sample_partials(_p(logits), logits.stride(0), B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step), None,
+                             _p(row_ids), _p(row_steps), _p(scratch), _s())
+
+
+def decode_step(scratch, *, forced_len, forced_token, eos_ids, ignore_eos, gen_len, active, out_tokens, tok_out, slot_out, k_base, kb_gen, ke_gen,
+                n_chunks, chunk_keys, pos, inv_freq, D, section, cos_out, sin_out, embed, x_out):
+    """One launch between two decode forwards (st_decode_step): sampler finish + forced EOS, token record, live flags, response index,
+    cache slot, generated-key range ends, the rows' M-RoPE cos/sin + position advance, embedding gather."""
+    B, R = out_tokens.shape
+    lib().st_decode_step(_p(scratch), _p(forced_len), int(forced_token), _p(eos_ids), 0 if eos_ids is None else eos_ids.numel(), int(bool(ignore_eos)),
+                         _p(gen_len), _p(active), _p(out_tokens), R, _p(tok_out), _p(slot_out), _p(k_base), _p(kb_gen), _p(ke_gen), int(n_chunks),
+                         int(chunk_keys), _p(pos), _p(inv_freq), D, section[0], section[1], section[2], _p(cos_out), _p(sin_out), _p(embed),
+                         embed.stride(0), _p(x_out), x_out.stride(0), embed.shape[1], B, _s())
+
+
 def prof_disable(klass: int):
     lib().st_prof_disable(klass)
     _prof_on[klass] = False

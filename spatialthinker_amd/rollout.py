@@ -185,27 +185,46 @@ class Generator:
             s_first = int(S_np[0])
             assert fused or np.array_equal(S_np, np.arange(s_first, s_first + Ba)), "the unfused path decodes contiguous waves only"
 
+            # state of the one-launch step bookkeeping (st_decode_step) of the fused path
+            kbase_row = (S_t * R).contiguous()                               # first cache row of every local row's sample
+            slot = torch.zeros(Ba, dtype=I32, device=dev)                    # cache slot of the current token's K/V
+            cos_b = torch.empty(Ba, D // 2, dtype=F32, device=dev); sin_b = torch.empty_like(cos_b)
+            samp_scratch = torch.empty(Ba * 33, dtype=F32, device=dev)
+            ke_gen = ke_all[n1:]                                            # view: the generated-key range ends inside the launch arrays
+
             def iteration():
                 """sample -> record -> one decode forward for the phase's rows -> next logits.  Device state only (graph-capturable).
                 Finished rows keep computing on their last token until the phase is re-batched; their output is ignored."""
-                forced = None
-                if forced_len is not None:
-                    forced = torch.where(forced_len == gen_len + 1, int(eos[0]), -1).to(I32)
-                ops.sample(logits[:Ba], temperature, seed, forced=forced, row_steps=gen_len, out=tok32, row_ids=S_t, top_k=top_k, top_p=top_p)
-                tok = tok32.to(I64)
-                live = active.bool()
-                col = gen_len.clamp(max=R - 1).long()[:, None]
-                out_l.scatter_(1, col, torch.where(live, tok, out_l.gather(1, col)[:, 0])[:, None])
-                stop = gen_len + 1 >= R                                             # the length cap ends a sample like an EOS
-                if not ignore_eos:
-                    stop = stop | (tok[:, None] == eos_t[None, :]).any(1)
-                active.copy_((live & ~stop).to(I32))
-                cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
-                ops.embed_gather(w["embed"], tok32, out=xbuf[:Ba])
-                x = xbuf
-                glen = gen_len.clamp(max=R - 1)                                     # finished rows at the cap rewrite their last slot
-                ke2 = torch.maximum(torch.minimum(kb2 + CKG, kbase + (glen + 1).repeat(Cg)), kb2).contiguous()
-                ke_all[n1:].copy_(ke2)
+                if fused:
+                    # two launches: the split sampler, then ONE kernel for everything between two forwards (sampler finish + forced
+                    # EOS, token record, live flags, response index, cache slot, key-range ends, M-RoPE table rows + position
+                    # advance, embedding gather) — the unfused branch below is the same sequence as ~25 torch kernels
+                    live = active.bool() if self.tap is not None else None
+                    ops.sample_partials(logits[:Ba], temperature, seed, samp_scratch, row_steps=gen_len, row_ids=S_t, top_k=top_k, top_p=top_p)
+                    ops.decode_step(samp_scratch, forced_len=forced_len, forced_token=int(eos[0]), eos_ids=eos_t, ignore_eos=ignore_eos,
+                                    gen_len=gen_len, active=active, out_tokens=out_l, tok_out=tok32, slot_out=slot, k_base=kbase_row,
+                                    kb_gen=kb2, ke_gen=ke_gen, n_chunks=Cg, chunk_keys=CKG, pos=pos, inv_freq=m.inv_freq, D=D,
+                                    section=c.mrope_section, cos_out=cos_b, sin_out=sin_b, embed=w["embed"], x_out=xbuf)
+                    cos, sin, glen, x = cos_b, sin_b, slot, xbuf
+                else:
+                    forced = None
+                    if forced_len is not None:
+                        forced = torch.where(forced_len == gen_len + 1, int(eos[0]), -1).to(I32)
+                    ops.sample(logits[:Ba], temperature, seed, forced=forced, row_steps=gen_len, out=tok32, row_ids=S_t, top_k=top_k, top_p=top_p)
+                    tok = tok32.to(I64)
+                    live = active.bool()
+                    col = gen_len.clamp(max=R - 1).long()[:, None]
+                    out_l.scatter_(1, col, torch.where(live, tok, out_l.gather(1, col)[:, 0])[:, None])
+                    stop = gen_len + 1 >= R                                             # the length cap ends a sample like an EOS
+                    if not ignore_eos:
+                        stop = stop | (tok[:, None] == eos_t[None, :]).any(1)
+                    active.copy_((live & ~stop).to(I32))
+                    cos, sin = ops.mrope_table(pos, m.inv_freq, D, c.mrope_section)
+                    ops.embed_gather(w["embed"], tok32, out=xbuf[:Ba])
+                    x = xbuf
+                    glen = gen_len.clamp(max=R - 1)                                     # finished rows at the cap rewrite their last slot
+                    ke2 = torch.maximum(torch.minimum(kb2 + CKG, kbase + (glen + 1).repeat(Cg)), kb2).contiguous()
+                    ke_all[n1:].copy_(ke2)
                 if fused:
                     # 10 launches per layer: the split-K slabs of the projections are consumed by fused epilogues (bias + RoPE +
                     # cache append; residual + RMSNorm of the NEXT op) and the SwiGLU lives in the gate/up GEMM epilogue
@@ -247,9 +266,10 @@ class Generator:
                         x = ops.gemm_nt(mm, w[p + "down_w"], residual=x1, decode=True)
                     hn2, _ = ops.rmsnorm_fwd(x, w["final_norm"], c.rms_eps, want_rstd=False)
                 ops.gemm_nt(hn2[:logits.shape[0]], head, out=logits, decode=True)
+                if not fused:
+                    gen_len.add_(1); pos.add_(1)              # (st_decode_step advances both itself)
                 if self.tap is not None:                      # test hook (eager iterations only): this iteration's tokens and next logits
-                    self.tap(S_np, live.clone(), gen_len.clone(), tok32.clone(), logits[:Ba].clone())
-                gen_len.add_(1); pos.add_(1)
+                    self.tap(S_np, live.clone(), gen_len - 1, tok32.clone(), logits[:Ba].clone())
 
             # the decode iteration is launch-bound (~10 launches x layers): capture it once per phase into a hipGraph and replay
             graph, done = None, 0

@@ -218,12 +218,15 @@ class ParamStore:
                 self.wq[f"l.{i}.{nm}"] = ops.mxfp8_quantize(self.w[f"l.{i}.{nm}"])
 
     # ---- HF state_dict interop (names of transformers Qwen2_5_VLForConditionalGeneration) -------------
-    def load_hf_state_dict(self, sd: Dict[str, torch.Tensor]):
+    def load_hf_state_dict(self, sd: Dict[str, torch.Tensor], target: Optional[torch.Tensor] = None):
+        """HF-named tensors into the fused / padded flat layout.  target: another flat buffer with the same layout (AdamW moments,
+        Kahan compensation: the reference's optimizer state is keyed by the same parameter names) instead of the weights."""
         c = self.cfg
+        views = self.w if target is None else {n: self._view(target, n) for n in self.layout}
 
         def put(name, t):
             t = t.to(dtype=BF16, device=self.device)
-            dst = self.w[name]
+            dst = views[name]
             if dst.shape == t.shape:
                 dst.copy_(t)
             elif dst.dim() == 2:
@@ -260,7 +263,7 @@ class ParamStore:
         put("final_norm", sd["model.language_model.norm.weight"])
         if not c.tie_word_embeddings:
             put("lm_head", sd["lm_head.weight"])
-        if self.trainable:
+        if self.trainable and target is None:
             self.refresh_transposes()
 
     def export_hf(self, source: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:

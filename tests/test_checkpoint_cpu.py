@@ -61,3 +61,61 @@ def test_hub_id_resolves_through_the_hub_cache(tmp_path, monkeypatch):
     with pytest.raises(FileNotFoundError):
         resolve_model_path("acme/does-not-exist")
     assert resolve_model_path(str(snap)) == str(snap)
+
+
+# ------------------------------------------------------------------ the reference's sharded layout
+def _export_worker(args):
+    src_sd, optim, out, world = args
+    from verl.utils.checkpoint import export_reference_layout
+    export_reference_layout(src_sd, optim, out, world, opt_steps=7, sched_steps=3)
+
+
+@pytest.mark.parametrize("world", [1, 4])
+def test_reference_sharded_checkpoint_roundtrip(tmp_path, world):
+    """model_/optim_/extra_state_world_size_W_rank_r.pt as FSDPCheckpointManager writes them (DTensor Shard(0) on an ("fsdp",) mesh,
+    verl/utils/checkpoint/fsdp_checkpoint_manager.py:83-131), with the transformers-4.49 parameter names the reference's runs carry:
+    the loader reassembles weights, AdamW moments, Kahan compensation, optimizer step and scheduler position bit for bit, without
+    any process group.  (The files are produced by export_reference_layout in a child process: building DTensors needs one.)"""
+    import multiprocessing as mp
+    from verl.utils.checkpoint import find_reference_world_size, load_reference_checkpoint, read_reference_shards
+    cfg, store, params = _store()
+    hf = {k: torch.from_numpy(v).bfloat16() for k, v in params.items()}
+    # the reference's checkpoints use the old tower names
+    old = {}
+    for k, v in hf.items():
+        if k.startswith("model.visual."):
+            old[k[len("model."):]] = v
+        elif k.startswith("model.language_model."):
+            old["model." + k[len("model.language_model."):]] = v
+        else:
+            old[k] = v
+    g = torch.Generator().manual_seed(0)
+    optim = {k: {"step": torch.tensor(7.0), "exp_avg": (torch.randn(v.shape, generator=g) * 1e-3).bfloat16(),
+                 "exp_avg_sq": (torch.rand(v.shape, generator=g) * 1e-6).bfloat16(), "compensation": (torch.randn(v.shape, generator=g) * 1e-5).bfloat16()}
+             for k, v in old.items()}
+    out = str(tmp_path / "actor")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_export_worker, args=((old, optim, out, world),))
+    p.start(); p.join()
+    assert p.exitcode == 0
+    assert find_reference_world_size(out) == world
+    assert sorted(os.listdir(out)) == sorted(f"{k}_world_size_{world}_rank_{r}.pt" for k in ("model", "optim", "extra_state") for r in range(world))
+    merged = read_reference_shards(out, "model")
+    assert set(merged) == set(old) and all(torch.equal(merged[k], old[k]) for k in old)
+    if world > 1:
+        r0 = torch.load(os.path.join(out, f"model_world_size_{world}_rank_0.pt"), weights_only=False)
+        k0 = "model.embed_tokens.weight"
+        assert type(r0[k0]).__name__ == "DTensor" and r0[k0]._local_tensor.shape[0] < old[k0].shape[0]      # really sharded
+    tgt = mdl.ParamStore(cfg, device="cpu", trainable=False)
+    tgt.trainable = True
+    tgt.m, tgt.v, tgt.c = (torch.zeros(tgt.numel, dtype=torch.bfloat16) for _ in range(3))
+    tgt.refresh_transposes = lambda: None
+    info = load_reference_checkpoint(tgt, out)
+    assert info == {"world_size": world, "opt_steps": 7, "sched_steps": 3}
+    assert torch.equal(tgt.flat, store.flat)
+    back = tgt.export_hf({n: tgt._view(tgt.m, n) for n in tgt.layout})
+    for k, v in hf.items():
+        ko = k[len("model."):] if k.startswith("model.visual.") else ("model." + k[len("model.language_model."):] if k.startswith("model.language_model.") else k)
+        assert torch.equal(back[k], optim[ko]["exp_avg"].reshape(back[k].shape)), k
+    back_c = tgt.export_hf({n: tgt._view(tgt.c, n) for n in tgt.layout})
+    assert torch.equal(back_c["lm_head.weight"], optim["lm_head.weight"]["compensation"])

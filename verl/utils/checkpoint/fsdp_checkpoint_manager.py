@@ -1,0 +1,158 @@
+"""Interop with the reference's on-disk checkpoint layout (verl/utils/checkpoint/fsdp_checkpoint_manager.py:52-131):
+
+    <ckpt>/actor/model_world_size_{W}_rank_{r}.pt         FSDP SHARDED_STATE_DICT: {hf_param_name: DTensor Shard(0) on mesh ("fsdp",)}
+    <ckpt>/actor/optim_world_size_{W}_rank_{r}.pt         sharded optimizer state: {"state": {name: {step, exp_avg, exp_avg_sq,
+                                                           compensation}}, "param_groups": [...]}
+    <ckpt>/actor/extra_state_world_size_{W}_rank_{r}.pt   {"lr_scheduler": LambdaLR.state_dict(), "rng": {...}}
+    <ckpt>/actor/huggingface/                             config + generation config + tokenizer / processor files
+
+This engine keeps full replicas, so its native checkpoint is ONE HF-loadable directory + ONE optimizer file
+(verl/workers/fsdp_workers.py save_checkpoint).  To let a run checkpointed by the reference continue here (and vice versa):
+  * load_reference_checkpoint  — reads all W shard files (unpickling DTensors needs no process group), concatenates the local
+    shards along their placement dimension, maps transformers-4.49 names to the 5.x names, and fills the ParamStore's weights, the
+    AdamW moments / Kahan compensation, the optimizer step and the scheduler position;
+  * export_reference_layout    — writes this engine's state as W rank files of DTensor shards (what scripts/model_merger.py :37-164
+    and FSDPCheckpointManager.load_checkpoint :52-81 expect).  DTensor construction needs a process group of W ranks: a stand-alone
+    process builds them on torch's in-process "fake" backend, one rank at a time (tools/export_reference_checkpoint.py).
+The CUDA RNG state of the reference ("rng") has no counterpart: this engine's sampler is counter-based (seed, row, step)."""
+from __future__ import annotations
+
+import os
+import re
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+
+_PAT = re.compile(r"model_world_size_(\d+)_rank_0\.pt$")
+
+
+def find_reference_world_size(path: str) -> Optional[int]:
+    for name in sorted(os.listdir(path)) if os.path.isdir(path) else []:
+        m = _PAT.match(name)
+        if m:
+            return int(m.group(1))
+    return None
+
+
+def _local(t):
+    """(local tensor, shard dim or None) of one rank's entry: DTensor (FSDP with a device mesh), ShardedTensor (FSDP without) or a
+    plain tensor / scalar (replicated)."""
+    try:
+        from torch.distributed.tensor import DTensor
+    except Exception:                                           # pragma: no cover
+        DTensor = ()
+    if DTensor and isinstance(t, DTensor):
+        pl = t.placements[-1]
+        return t._local_tensor, (pl.dim if pl.is_shard() else None)
+    if hasattr(t, "local_shards"):                              # torch.distributed._shard.sharded_tensor.ShardedTensor
+        sh = t.local_shards()
+        return (sh[0].tensor if sh else None), 0
+    return t, None
+
+
+def _merge(per_rank: list):
+    """One entry of every rank's dict -> the full value."""
+    first = per_rank[0]
+    if isinstance(first, dict):
+        return {k: _merge([d[k] for d in per_rank]) for k in first}
+    if not torch.is_tensor(first):
+        return first
+    locs = [_local(t) for t in per_rank]
+    dim = locs[0][1]
+    if dim is None:
+        return locs[0][0]
+    parts = [x for x, _ in locs if x is not None and x.numel() > 0]
+    return torch.cat(parts, dim=dim).contiguous() if parts else locs[0][0]
+
+
+def read_reference_shards(path: str, kind: str = "model", world_size: Optional[int] = None) -> Dict[str, Any]:
+    """Merge `{kind}_world_size_W_rank_r.pt` for r = 0..W-1 into one dict of full tensors (kind: model | optim | extra_state)."""
+    W = world_size or find_reference_world_size(path)
+    if not W:
+        raise FileNotFoundError(f"no model_world_size_*_rank_0.pt under {path}")
+    per_rank = [torch.load(os.path.join(path, f"{kind}_world_size_{W}_rank_{r}.pt"), map_location="cpu", weights_only=False) for r in range(W)]
+    if kind == "extra_state":
+        return per_rank[0]
+    return _merge(per_rank)
+
+
+def normalise_hf_names(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """transformers < 4.52 (the reference pins >= 4.49) names the towers `visual.*` / `model.*`; 5.x (and ParamStore) use
+    `model.visual.*` / `model.language_model.*`.  FSDP wrapper prefixes are dropped."""
+    out = {}
+    for k, v in sd.items():
+        k = k.replace("_fsdp_wrapped_module.", "").replace("_checkpoint_wrapped_module.", "")
+        if k.startswith("visual."):
+            k = "model." + k
+        elif k.startswith("model.") and not k.startswith(("model.visual.", "model.language_model.")):
+            k = "model.language_model." + k[len("model."):]
+        out[k] = v
+    return out
+
+
+def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
+    """Fill `store` (ParamStore) — and, when given, the PolicyEngine's optimizer / scheduler counters — from a checkpoint directory in
+    the reference's layout.  Returns {"world_size", "opt_steps", "sched_steps"}."""
+    W = find_reference_world_size(path)
+    if not W:
+        raise FileNotFoundError(f"{path} holds no reference-layout checkpoint (model_world_size_W_rank_r.pt)")
+    store.load_hf_state_dict(normalise_hf_names(read_reference_shards(path, "model", W)))
+    info = {"world_size": W, "opt_steps": 0, "sched_steps": 0}
+    opt_file = os.path.join(path, f"optim_world_size_{W}_rank_0.pt")
+    if store.trainable and os.path.exists(opt_file):
+        opt = read_reference_shards(path, "optim", W)
+        state = normalise_hf_names(opt.get("state", {}))
+        shapes = store.export_hf()                                   # HF name -> view with the parameter's shape
+        for buf, key in ((store.m, "exp_avg"), (store.v, "exp_avg_sq"), (store.c, "compensation")):
+            have = {n: st[key] for n, st in state.items() if key in st}
+            if have:                                                 # parameters without state (frozen tower) keep zeros
+                full = {n: have[n] if n in have else torch.zeros(tuple(t.shape)) for n, t in shapes.items()}
+                store.load_hf_state_dict(full, target=buf)
+        steps = [int(float(st["step"])) for st in state.values() if "step" in st]
+        info["opt_steps"] = max(steps) if steps else 0
+    extra_file = os.path.join(path, f"extra_state_world_size_{W}_rank_0.pt")
+    if os.path.exists(extra_file):
+        extra = read_reference_shards(path, "extra_state", W)
+        sched = extra.get("lr_scheduler") or {}
+        info["sched_steps"] = int(sched.get("last_epoch", 0))
+    if engine is not None:
+        engine.opt_steps, engine.sched_steps = info["opt_steps"], info["sched_steps"]
+        store.version = getattr(store, "version", 0) + 1
+    return info
+
+
+def export_reference_layout(hf_state: Dict[str, torch.Tensor], optim_state: Optional[Dict[str, Dict[str, torch.Tensor]]], out_dir: str,
+                            world_size: int, opt_steps: int = 0, sched_steps: int = 0, base_lr: float = 1e-6, hyper: Optional[dict] = None) -> None:
+    """Write full tensors as the reference's per-rank DTensor shards.  Must run in a process WITHOUT an initialised process group
+    (it brings up torch's "fake" backend once per rank to build the device mesh)."""
+    import torch.distributed as dist
+    from torch.distributed.device_mesh import DeviceMesh
+    from torch.distributed.tensor import DTensor, Shard
+    from torch.testing._internal.distributed.fake_pg import FakeStore
+    assert not dist.is_initialized(), "export_reference_layout needs a process without a process group (see tools/export_reference_checkpoint.py)"
+    os.makedirs(out_dir, exist_ok=True)
+    W = int(world_size)
+
+    def shard(full: torch.Tensor, mesh, r: int):
+        if full.dim() == 0:
+            return full.clone()
+        chunks = list(torch.chunk(full, W, dim=0))
+        local = chunks[r].clone() if r < len(chunks) else full[:0].clone()
+        return DTensor.from_local(local, mesh, [Shard(0)], run_check=False, shape=full.shape, stride=full.stride())
+
+    for r in range(W):
+        dist.init_process_group(backend="fake", store=FakeStore(), rank=r, world_size=W)
+        try:
+            mesh = DeviceMesh("cpu", torch.arange(W), mesh_dim_names=("fsdp",))
+            torch.save({k: shard(v.detach().cpu().contiguous(), mesh, r) for k, v in hf_state.items()},
+                       os.path.join(out_dir, f"model_world_size_{W}_rank_{r}.pt"))
+            if optim_state is not None:
+                st = {n: {k: (shard(t.detach().cpu().contiguous(), mesh, r) if torch.is_tensor(t) and t.dim() > 0 else torch.tensor(float(opt_steps)))
+                          for k, t in d.items()} for n, d in optim_state.items()}
+                groups = [dict({"lr": base_lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 1e-2}, **(hyper or {}), params=list(optim_state.keys()))]
+                torch.save({"state": st, "param_groups": groups}, os.path.join(out_dir, f"optim_world_size_{W}_rank_{r}.pt"))
+            sched = {"last_epoch": int(sched_steps), "_step_count": int(sched_steps) + 1, "base_lrs": [base_lr], "_last_lr": [base_lr],
+                     "lr_lambdas": [None]}
+            torch.save({"lr_scheduler": sched, "rng": {}}, os.path.join(out_dir, f"extra_state_world_size_{W}_rank_{r}.pt"))
+        finally:
+            dist.destroy_process_group()

@@ -209,6 +209,16 @@ class FSDPWorker:
     def load_checkpoint(self, path: str):
         if path is None:
             return
+        from ..utils.checkpoint import find_reference_world_size, load_reference_checkpoint
+        if find_reference_world_size(path):
+            # a run checkpointed by the REFERENCE (model_/optim_/extra_state_world_size_W_rank_r.pt, fsdp_checkpoint_manager.py:83-131):
+            # every rank reassembles the full weights / optimizer state from all W shard files (whatever this run's world size is)
+            info = load_reference_checkpoint(self.actor.store, path, engine=self.actor)
+            self.print_rank0(f"Loaded a reference-layout checkpoint written by {info['world_size']} ranks: optimizer step "
+                             f"{info['opt_steps']}, scheduler step {info['sched_steps']}.")
+            if self.world_size > 1:
+                dist.barrier()
+            return
         from safetensors.torch import load_file
         import glob
         sd = {}

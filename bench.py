@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = BASELINE config #5's arithmetic: the LM projection GEMMs of every forward pass on the MX-fp8 (OCP e4m3, block-"
                          "scaled) MFMA path, everything else (attention, lm_head, ViT, backward, decode) bf16")
+    ap.add_argument("--through-api", action="store_true",
+                    help="the same synthetic step through the kept API: `python -m verl.trainer.main` (config merge, RLHF dataloader, FSDPWorker "
+                         "methods, DataProto .cpu() round trips, tokenizer decode + CustomRewardManager, RayPPOTrainer.fit) instead of calling the "
+                         "engine directly; the JSON line reports the step rate the trainer itself logged")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/contract check without a GPU: ranks rendezvous over gloo, time K trivial steps, rank 0 prints the JSON line")
     return ap.parse_args()
@@ -69,6 +73,54 @@ def maybe_spawn(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
+
+def through_api(a):
+    """Run K + W steps of `python -m verl.trainer.main` on the bench workload as a CHILD process (this one never touches the GPU) and
+    report samples/s from the trainer's own timers (timing_s/step = gen + reward + balance + old + ref + adv + update_actor, the
+    reference's `step` timer of ray_trainer.py:585-706)."""
+    import re
+    size = {"7b": "random:7b", "3b": "random:3b", "tiny": "random:tiny"}[a.model]
+    tiny = a.model == "tiny"
+    G, npr = a.rollouts, a.prompts_per_gpu
+    R = 64 if tiny else a.response_cap
+    spec = "synthetic:stvqa" + (f":{a.image}" if a.image else "") + "@train"
+    n_opt = 4 if (G * npr) % 16 == 0 else 1
+    cmd = [sys.executable, "-m", "verl.trainer.main", f"data.train_files={spec}", "data.val_files=", f"data.rollout_batch_size={npr * max(1, a.gpus)}",
+           f"data.max_prompt_length={128 if tiny else 1152}", f"data.max_response_length={R}", f"worker.actor.model.model_path={size}",
+           f"worker.actor.global_batch_size={npr * max(1, a.gpus) // n_opt}", "worker.actor.micro_batch_size_per_device_for_update=4",
+           f"worker.actor.micro_batch_size_per_device_for_experience={a.experience_micro_batch}", "worker.actor.optim.strategy=adamw_bf16",
+           "worker.actor.fsdp.torch_dtype=bf16", "worker.actor.padding_free=true", f"worker.rollout.n={G}", "worker.reward.score_function=spatial_sgg",
+           "algorithm.use_kl_loss=true", "algorithm.kl_penalty=low_var_kl", "algorithm.kl_coef=1.0e-2", f"trainer.max_steps={a.steps + a.warmup}",
+           "trainer.total_episodes=100", f"trainer.n_gpus_per_node={max(1, a.gpus)}", "trainer.val_before_train=false", "trainer.logger=['console']",
+           "trainer.save_freq=-1", "trainer.save_checkpoint_path=/tmp/st_bench_api_ckpt"]
+    env = dict(os.environ, PYTHONPATH=ROOT, ST_SKIP_FINAL_SAVE="1", ST_SYNTH_RESPONSE_LENGTHS="16,4" if tiny else "512,128")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout[-3000:] + p.stderr[-3000:])
+        raise SystemExit(p.returncode)
+    steps = []
+    for line in p.stdout.splitlines():
+        if line.startswith("step ") and "timing_s/step" in line:
+            kv = dict(item.split(":", 1) for item in line.split(": ", 1)[1].split(" - ") if ":" in item)
+            steps.append({k: float(v) for k, v in kv.items() if re.fullmatch(r"[-+0-9.eE]+|nan|inf", v)})
+    timed = steps[a.warmup:]
+    assert len(timed) == a.steps, (len(steps), a.steps, p.stdout[-2000:])
+    B, world = G * npr, max(1, a.gpus)
+    el = sum(s_["timing_s/step"] for s_ in timed)
+    keys = ("gen", "reward", "old", "ref", "adv", "update_actor")
+    print(json.dumps({
+        "metric": "GRPO samples/sec (G=8 rollouts/prompt) Qwen2.5-VL-7B at 1/2/4/8 MI355X", "value": B * world * a.steps / el, "unit": "samples/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (SyntheticSTVQADataset rows through the resumable dataloader; random-init weights; "
+        "response lengths ~ clip(N(512,128),64,cap) forced by the worker; rewards scored on the DECODED random tokens)",
+        "config": {"workload": f"python -m verl.trainer.main (kept API) on the bench workload: {size}, G={G}, {npr} prompts/GPU, micro-batch 4, {n_opt} optimizer "
+                               f"steps/step, max_response_length {R}", "global_batch": B * world, "parallelism": f"dp{world}", "through_api": True},
+        "timing_s": {k: sum(s_.get(f"timing_s/{k}", 0.0) for s_ in timed) / a.steps for k in keys},
+        "timing_s_step_minus_phases": (el - sum(s_.get(f"timing_s/{k}", 0.0) for s_ in timed for k in keys)) / a.steps,
+        "prompt_cache_hit": sum(s_.get("perf/prompt_cache_hit", 0.0) for s_ in timed) / a.steps,
+        "perf_mfu_actor_reference_counter": sum(s_.get("perf/mfu_actor", 0.0) for s_ in timed) / a.steps,
+        "trainer_samples_per_s": [s_.get("perf/samples_per_s") for s_ in timed]}))
 
 
 def dry_run(a):
@@ -286,6 +338,8 @@ def cpu_baseline():
 # ------------------------------------------------------------------ main
 def main():
     a = parse()
+    if a.through_api:
+        return through_api(a)
     maybe_spawn(a)
     if a.dry_run:
         return dry_run(a)

@@ -172,8 +172,10 @@ def release_cached_blocks():
     """End of a phase (rollout / a log-prob pass / update): hand the allocator's cached blocks back to the driver.  The phases
     allocate differently shaped tensors (KV caches, 150k-wide logits, per-layer activations of passes whose packed length changes
     every step); carried over, the split blocks of one phase fragment the next one and the reserved pool creeps up step after step
-    (round 2: 202 -> 235 GB over 25 steps).  Four calls per step, each a few ms.  ST_EMPTY_CACHE=0 switches it off."""
-    if os.environ.get("ST_EMPTY_CACHE", "1") != "0" and torch.cuda.is_available():
+    (round 2: 202 -> 235 GB over 25 steps).  OPT-IN (ST_EMPTY_CACHE=1): measured on the bench it costs more than it saves — the
+    update phase then re-requests ~70 GB from the driver every step, peak reserved went 202 -> 287 GB and update_actor 14.9 -> 17.1 s
+    (profiles/r03 notes); the default bound on the creep is the expandable-segments allocator mode (bench.py sets it)."""
+    if os.environ.get("ST_EMPTY_CACHE", "0") == "1" and torch.cuda.is_available():
         torch.cuda.empty_cache()
 
 

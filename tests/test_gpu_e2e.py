@@ -84,3 +84,18 @@ def test_config1_3b_vanilla_grpo_r1v_2x4_224px(tmp_path):
     assert 10.0 < ent < 13.0, lines[-1]                                          # ~ln(151936) = 11.9 for a near-uniform policy
     pl = float(re.search(r"prompt_length/mean:([0-9.eE+]+)", lines[-1]).group(1))
     assert abs(pl - (700 + 2 + 64)) < 1, lines[-1]                              # 200 + 500 text, vision start/end, 64 image tokens
+
+
+def test_bench_through_api_prints_the_contract_line():
+    """`bench.py --through-api`: the bench workload through `python -m verl.trainer.main` (tiny model here), one JSON line with the
+    contract keys, per-phase times from the trainer's own timers and the prompt-cache hit rate of the old-policy pass."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--through-api", "--model", "tiny", "--steps", "2", "--warmup", "1",
+                        "--prompts-per-gpu", "4", "--rollouts", "4"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["steps"] == 2 and line["value"] > 0 and line["config"]["through_api"] is True
+    assert line["prompt_cache_hit"] == 1.0
+    assert set(line["timing_s"]) == {"gen", "reward", "old", "ref", "adv", "update_actor"} and line["timing_s"]["update_actor"] > 0

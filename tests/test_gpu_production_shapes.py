@@ -94,11 +94,13 @@ def test_decode_path_at_7b_widths_vs_fp32_oracle(ops, lm7b, measured, rows, wave
     nb = rows // n
     rs = np.random.RandomState(rows)
     ids, mask, pos = _prompts(rs, nb)
-    R = 8
+    R = 10
     B = nb * n
-    # half of the rows stop early (forced EOS at 2..4 tokens): the survivors are re-batched; with wave = 256 < rows the survivors of
-    # two waves are pooled at DIFFERENT generated lengths (per-row steps, cache slots and RoPE positions)
-    lens = np.where(rs.rand(B) < 0.5, rs.randint(2, 5, B), R).astype(np.int64)
+    # more than half of the rows stop early (forced EOS): the survivors are re-batched.  With wave = 256 < rows the first wave's early
+    # rows stop after 2..3 tokens and the second wave's after 5..6, so the pooled survivors of the two waves sit at DIFFERENT
+    # generated lengths (per-row steps, cache slots and RoPE positions)
+    early = np.where(np.arange(B) < wave, rs.randint(2, 4, B), rs.randint(5, 7, B))
+    lens = np.where(rs.rand(B) < 0.6, early, R).astype(np.int64)
     gen = Generator(eng)
     gen.max_decode_batch = wave
     taps = []
@@ -171,8 +173,8 @@ def test_decode_path_at_7b_widths_vs_fp32_oracle(ops, lm7b, measured, rows, wave
     measured(f"decode7b_rows{rows}_worst_argmax_margin", worst_margin)
     measured(f"decode7b_rows{rows}_greedy_agreement", tok_agree / tok_checked)
     # logits are O(1) (std 0.7, |max| ~ 3.5): one bf16 ulp at that size is 0.0156
-    assert worst < 0.06, worst                                              # thresholds at <= 1.3x measured: DESIGN.md §4
-    assert worst_margin < 0.08, worst_margin                                # a differing greedy token is always a near-tie of the fp32 logits
+    assert worst < 0.043, worst                                             # measured 0.027 / 0.028 / 0.033 at 64 / 200 / 512 rows (1.3x): DESIGN.md §4
+    assert worst_margin < 0.0106, worst_margin                              # measured <= 0.0081: a differing greedy token is always a near-tie of the fp32 logits
     # (exact agreement with the fp32 argmax is NOT asserted: the ramp-initialised head makes the top logits of a row near-ties a few
     # 1e-3 apart, far below the bf16 noise — the margin above is the meaningful statement; the agreement rate is only recorded)
     del gen, taps, kc, vc
@@ -213,14 +215,14 @@ def test_decode_shaped_gemms_at_7b_shapes_vs_fp32(ops, measured, M_):
             # gate / up may land one bf16 ulp apart from the fp32 product's rounding: compare at the output's own scale
             err = float((got.float() - ref).abs().max() / ref.abs().max())
             measured(f"decode_gemm_swiglu_M{M_}_rel", err)
-            assert err < 2 ** -6, (name, err)
+            assert err < 9.1e-3, (name, err)                     # measured <= 0.0070 (1.3x)
         else:
             res = _randn_bf16((M_, N), 1.0, 5) if N <= 4608 else None
             got = ops.gemm_nt(a, w, bias=bias, residual=res, decode=True)
             ref = want + bias.float() + (res.float() if res is not None else 0.0)
             err = float((got.float() - ref).abs().max() / scale)
             worst = max(worst, err)
-            assert err < 2 ** -7, (name, err)
+            assert err < 5.9e-3, (name, err)                     # measured <= 0.0045 (1.3x)
         if N == 3584:                                   # the slab GEMM + fused finish (residual + RMSNorm) used by the decode loop
             slabs, sp = ops.gemm_nt_decode_slabs(a, w)
             res = _randn_bf16((M_, N), 1.0, 7)
@@ -242,7 +244,7 @@ def test_decode_shaped_gemms_at_7b_shapes_vs_fp32(ops, measured, M_):
 T_BENCH = 10496                                          # packed tokens of a fused update pass at the bench workload (tools/gemm_shapes.py)
 
 
-def _check_bf16(got, ref, scale, what, tol=2 ** -7):
+def _check_bf16(got, ref, scale, what, tol=4.9e-3):          # measured <= 0.0037 of the output's max at T = 10496 (1.3x)
     err = float((got.float() - ref).abs().max() / scale)
     assert err < tol, (what, err)
     return err
@@ -272,7 +274,7 @@ def test_training_gemms_at_bench_rows_vs_fp32(ops, measured):
     g_, u_ = gu[:, :I].float(), gu[:, I:].float()
     mref = ((g_ * torch.sigmoid(g_)).bfloat16().float() * u_)
     e4 = float((m.float() - mref).abs().max() / mref.abs().max())
-    assert e4 < 2 ** -7, e4
+    assert e4 < 3.5e-3, e4                                                  # measured 0.0027
     del want, gu, g_, u_, mref
     # ---- down projection + residual (K = 18944)
     wd = _randn_bf16((H, I), 0.05, 17)
@@ -289,7 +291,7 @@ def test_training_gemms_at_bench_rows_vs_fp32(ops, measured):
     ops.gemm_tn(dy, x, acc, accumulate=True)
     want = dy.float().t() @ x.float()
     e7 = float((acc - 0.5 - want).abs().max() / want.abs().max())
-    assert e7 < 2e-5, e7
+    assert e7 < 6.4e-6, e7                                                  # measured 4.7e-6: fp32 summation order only
     del want, acc, dy
     # ---- dW of the down projection (M = 3584, N = 18944, contraction over the 10496 tokens)
     dx = _randn_bf16((T, H), 0.1, 19)
@@ -297,7 +299,7 @@ def test_training_gemms_at_bench_rows_vs_fp32(ops, measured):
     ops.gemm_tn(dx, m, acc, accumulate=False)
     want = dx.float().t() @ m.float()
     e8 = float((acc - want).abs().max() / want.abs().max())
-    assert e8 < 2e-5, e8
+    assert e8 < 6.4e-6, e8                                                  # measured 4.9e-6
     for k_, v_ in (("qkv_bias", e1), ("o_residual", e2), ("gate_up", e3), ("swiglu_m", e4), ("down_residual", e5), ("dx_gate_up", e6),
                    ("dw_gate_up_f32", e7), ("dw_down_f32", e8)):
         measured(f"train_gemm_T{T}_{k_}_rel", v_)
@@ -352,11 +354,11 @@ def test_attention_at_bench_packing_vs_dense_fp32(ops, measured):
     ref_out, ref_g = _dense_ref(qkv, segs, scale, do)
     e_f = float((out.float()[:T] - ref_out[:T]).abs().max())
     measured("attn_bench_varlen_fwd_abs", e_f)
-    assert e_f < 2e-2, e_f
+    assert e_f < 1.32e-2, e_f                                               # measured 0.0101 (1.3x): O(1) outputs on the bf16 grid
     for name, sl in (("dq", slice(0, NQ * D)), ("dk", slice(NQ * D, (NQ + NKV) * D)), ("dv", slice((NQ + NKV) * D, W))):
         e_ = float((dqkv.float()[:T, sl] - ref_g[:T, sl]).abs().max() / ref_g[:T, sl].abs().max())
         measured(f"attn_bench_varlen_{name}_rel", e_)
-        assert e_ < 3e-2, (name, e_)
+        assert e_ < 5.2e-3, (name, e_)                                      # measured <= 0.0040 of the gradient's max (1.3x)
     del ref_out, ref_g, dqkv, out
     torch.cuda.empty_cache()
     # ---- (ii) one rollout group behind a shared prompt
@@ -380,9 +382,9 @@ def test_attention_at_bench_packing_vs_dense_fp32(ops, measured):
     ref_out, ref_g = _dense_ref(qkv, [s_[:4] for s_ in segs5], scale, do)
     e_f = float((out.float()[:T] - ref_out[:T]).abs().max())
     measured("attn_bench_seg_fwd_abs", e_f)
-    assert e_f < 2e-2, e_f
+    assert e_f < 1.06e-2, e_f                                               # measured 0.0081
     for name, got, sl in (("dq", dq, slice(0, NQ * D)), ("dk", dk, slice(NQ * D, (NQ + NKV) * D)), ("dv", dv, slice((NQ + NKV) * D, W))):
         e_ = float((got.float()[:T] - ref_g[:T, sl]).abs().max() / ref_g[:T, sl].abs().max())
         measured(f"attn_bench_seg_{name}_rel", e_)
-        assert e_ < 3e-2, (name, e_)
+        assert e_ < 5.2e-3, (name, e_)                                      # measured <= 0.0040 of the gradient's max (1.3x)
     torch.cuda.empty_cache()

@@ -140,12 +140,18 @@ class FSDPWorker:
             gr = [m["image_grid_thw"] for m in mm]
         eos = self.special["eos"]
         self._gen_calls = getattr(self, "_gen_calls", 0) + 1
+        forced = prompts.meta_info.get("synthetic_response_lengths")
+        synth = os.environ.get("ST_SYNTH_RESPONSE_LENGTHS")          # "mean,std": synthetic benchmark through the kept API (bench.py --through-api)
+        if forced is None and synth and str(self.config.actor.model.model_path).startswith("random:"):
+            mu, sd = (float(v) for v in synth.split(","))
+            rs = np.random.RandomState(1234 + self.rank + 1000 * self._gen_calls)
+            forced = np.clip(rs.normal(mu, sd, len(ids) * n), min(64, r.response_length), r.response_length).astype(np.int64)
         # the prefill's prompt K/V serves the old-policy log-prob pass that follows on the same weights (PolicyEngine checks that
         # the cache matches the rows it is handed, else it simply recomputes)
         resp, self._prompt_cache = self.generator.generate(
             ids, mask, pos, n=n, max_new_tokens=r.response_length, temperature=temperature, eos_token_id=eos,
             pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls, pixel_values=px, image_grid_thw=gr,
-            ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)), forced_lengths=prompts.meta_info.get("synthetic_response_lengths"),
+            ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)), forced_lengths=forced,
             top_k=top_k, top_p=top_p, return_prompt_cache=True)
         batch = assemble_rollout_batch(ids, mask, pos, resp.cpu(), n, eos)          # vllm_rollout_spmd.py:144-188
         non_tensor = {}

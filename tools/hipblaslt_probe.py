@@ -31,5 +31,5 @@ for name, N, K in SHAPES:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-            print(f"{name:8s} {tag:5s} T={T} N={N} K={K}: {ms:.3f} ms  {2.0 * T * N * K / ms / 1e9:.0f} TF/s", flush=True)
+        print(f"{name:8s} {tag:5s} T={T} N={N} K={K}: {ms:.3f} ms  {2.0 * T * N * K / ms / 1e9:.0f} TF/s", flush=True)
     del a, w, out

@@ -137,6 +137,10 @@ int st_gemm_tn(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, flo
  * bias/residual/accumulate epilogue) — e.g. 574 tiles on 256 CUs finish in ~2.3 rounds instead of 3.  NULL / 0 switches it off.
  * The workspace is process-global: GEMMs that may use it must be issued on one stream at a time. */
 int st_gemm_set_workspace(void* workspace, int64_t bytes);
+/* Production tile of the training-shape launches of st_gemm_nt / st_gemm_swiglu: 23 = 256x256, 8 waves (mid-tile barrier schedule,
+ * LDS-staged epilogue, tail split); 40 = 256x256, 4 waves x 128x128 with the hand-scheduled K loop (csrc/gemm_asm4.hip).  Process-wide;
+ * also settable through the environment (ST_GEMM_VARIANT) before the library loads. */
+int st_gemm_select(int variant);
 /* Tuning/inspection entry: the same GEMM with an explicit tile variant (0: 128x128 2-stage, 1: 128x128 3-stage,
  * 2: 256x128 2-stage, 3: 256x128 3-stage, 4: 256x256 2-stage, 5: 128x256 3-stage, 6/7: 256x256 / 128x128 mid-tile barrier,
  * 8: 256x256 with 4 waves of 128x128 and a hand-written schedule, 9: the same tile, compiler schedule).  st_gemm_nt picks per shape. */

@@ -13,6 +13,7 @@
 //     walked in groups of 8 tile-rows so the A and B panels of neighbours stay L2-resident.
 // Roofline: MFMA-bound, 2*M*N*K flop per launch.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -324,6 +325,15 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
                           const uint16_t* res, int64_t ldr, uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K,
                           hipStream_t s);
 
+// production tile of the training-shape GEMMs: 23 = 8 waves x 64x128 (mid-tile barrier, LDS-staged epilogue, tail split),
+// 40 = 4 waves x 128x128 with the hand-scheduled K loop (gemm_asm4.hip).  ST_GEMM_VARIANT / st_gemm_select override it (A/B runs).
+int g_train_variant = [] { const char* e = getenv("ST_GEMM_VARIANT"); return e ? atoi(e) : 23; }();
+extern "C" int st_gemm_select(int variant) {
+    if (variant != 23 && variant != 40 && variant != 6 && variant != 8 && variant != 31) return ST_EINVAL;
+    g_train_variant = variant;
+    return 0;
+}
+
 extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64_t ldb, const st_bf16* bias,
                           const st_bf16* residual, int64_t ldr, st_bf16* out_bf16, float* out_f32, int64_t ldc,
                           int accumulate, int M, int N, int K, st_stream_t stream) {
@@ -339,7 +349,7 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     // 128 flop/B of L2 traffic) wins or ties from ~0.5 workgroups per CU upwards (dW of the 3584x3584 projection, 196 tiles:
     // 1098 vs 926 TF); only smaller problems fill the chip better with 128x128 tiles at 2 workgroups/CU.
     if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 128)
-        return st_gemm_tile_dispatch(23, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);   // 6 + LDS-staged epilogue
+        return st_gemm_tile_dispatch(g_train_variant, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);
 #define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
     if (out_bf16) {
         if (hb && hr) GO(true, true, true, false, false);

@@ -1,0 +1,366 @@
+// gemm_asm4.hip — the training GEMM tile with a hand-scheduled K loop:  C[M,N] = A[M,K] * B[N,K]^T, bf16 in, fp32 accumulate.
+//
+// 256x256x64 tile, FOUR waves (one per SIMD), each wave 128x128 = 8x8 MFMA 16x16x32 tiles whose 256 accumulator registers fill the
+// AGPR half of the SIMD's register file.  Why this shape (round-3 measurements): with two waves per SIMD the older
+// wave takes the matrix pipe and the younger one is left alone with its LDS-DMA issue stalls (~55 cycles each, in-order wave);
+// with ONE wave per SIMD nothing competes for issue slots, so the K loop can be written as a fixed instruction stream in which
+// every non-MFMA instruction (fragment read, LDS-DMA issue, M0 update, wait, barrier) sits in the shadow of a 16-cycle MFMA — at
+// most one or two "fillers" between two MFMAs (MI355X_MICROARCH.md: a 16x16x32 MFMA hides ~2 single-issue instructions).
+// Every instruction of the loop is an `asm volatile` statement: hipcc only allocates registers and keeps the statement order.
+//   * operands: LDS-DMA through the BUFFER path (`buffer_load_dwordx4 ... offen lds`): one lane-offset VGPR per operand (advanced
+//     by 128 bytes per K-tile), one SGPR offset per 1-KiB copy, the LDS destination in M0 — no per-copy address arithmetic on the
+//     VALU; rows beyond M / N are cut off by the buffer's num_records (they read as zero, nothing is clamped);
+//   * LDS image [row][64 k] with the 16-byte chunk position XOR (row & 7), applied on the SOURCE address: conflict-free for the
+//     lane groups of ds_read_b128, and the lane offset does not depend on the copy index;
+//   * per K-tile and wave: 128 MFMAs, 32 ds_read_b128 (fragments of the next k-step under the MFMAs of the current one), 16 LDS-DMA
+//     issues of tile t+2 into the slot tile t has just vacated, two barriers (slot free / next tile landed), counted vmcnt so that
+//     16 copies stay in flight across the second barrier.
+// Epilogue: the accumulators pass through the (idle) operand LDS so that bias / residual / C / the fp32 accumulate target move as
+// 16-byte row-contiguous vectors (same scheme as the 8-wave tile's LDS-staged epilogue in gemm_tile_kernel.h).
+#include "common.h"
+#include <type_traits>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: the body receives std::integral_constant<int, I> — every index below is a constant expression, so register
+// arrays are addressed statically (a loop the optimizer declines to unroll would turn them into indexed VGPR / scratch accesses)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#define A4_BM 256
+#define A4_BN 256
+#define A4_SLOT 65536          // one K-tile of both operands: (256 + 256) rows x 128 bytes
+#define A4_ABYTES 32768
+
+__device__ __forceinline__ void a4_mfma(f32x4& acc, const bf16x8& b, const bf16x8& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+template <int OFF> __device__ __forceinline__ void a4_read(bf16x8& f, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void a4_dma(uint32_t voff, i32x4 srd, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void a4_m0_set(uint32_t v) { asm volatile("s_mov_b32 m0, %0" : : "s"(v) : "memory"); }
+__device__ __forceinline__ void a4_m0_next() { asm volatile("s_add_u32 m0, m0, 0x400" : : : "memory", "scc"); }
+__device__ __forceinline__ void a4_barrier() { asm volatile("s_barrier" : : : "memory"); }
+__device__ __forceinline__ void a4_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
+template <int N> __device__ __forceinline__ void a4_wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// SWIGLU: B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows, so a lane holds gate
+// and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
+// silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
+template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU>
+__global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
+                                                      const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
+                                                      uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc, uint16_t* __restrict__ gu,
+                                                      int64_t ldgu, int M, int N, int K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap + grouped tile order (as gemm_tile_kernel.h): each XCD walks a contiguous range of tiles in groups
+    // of 8 tile-rows, so co-resident tiles share their A and B panels in the XCD's L2
+    const int nb = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = 8 * tiles_n;
+    const int group = bid / per_group, in_g = bid % per_group;
+    const int first_m = group * 8;
+    const int gsz = min(tiles_m - first_m, 8);
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * A4_BM;
+    const int n0 = SWIGLU ? tn * (A4_BN / 2) : tn * A4_BN;           // SWIGLU: first OUTPUT column (N = output width I)
+
+    // ---- buffer resources: base = first row of the tile, num_records cuts the rows beyond the matrix (they load as zero)
+    const uint64_t a_base = (uint64_t)(A + (int64_t)m0 * lda);
+    const int rows_a = min(A4_BM, M - m0);
+    i32x4 srdA, srdB, srdB2;
+    srdA.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a_base);
+    srdA.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a_base >> 32) & 0xffffu));
+    srdA.z = __builtin_amdgcn_readfirstlane((int)((int64_t)rows_a * lda * 2));
+    srdA.w = 0x00020000;
+    const int cols_b = SWIGLU ? min(A4_BN / 2, N - n0) : min(A4_BN, N - n0);        // B rows (= output columns) this tile owns
+    const uint64_t b_base = (uint64_t)(B + (int64_t)n0 * ldb);
+    srdB.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b_base);
+    srdB.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b_base >> 32) & 0xffffu));
+    srdB.z = __builtin_amdgcn_readfirstlane((int)((int64_t)cols_b * ldb * 2));
+    srdB.w = 0x00020000;
+    srdB2 = srdB;
+    if constexpr (SWIGLU) {                                          // the up-projection rows follow the N gate rows
+        const uint64_t u_base = (uint64_t)(B + (int64_t)(n0 + N) * ldb);
+        srdB2.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)u_base);
+        srdB2.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((u_base >> 32) & 0xffffu));
+    }
+    // lane part of a copy's source address: row (lane >> 3) of the copy's 8 rows, chunk (lane & 7) ^ row  (the swizzle on the source)
+    uint32_t voffA = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
+    uint32_t voffB = (uint32_t)(lane >> 3) * (uint32_t)(ldb * 2) + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
+    // copy j of this wave: A rows wave*64 + 8j .. +8; B tile rows wave*64 + 8j .. +8 (SWIGLU: tile rows alternate 16 gate / 16 up)
+    uint32_t soffA[8], soffB[8];
+    static_for<0, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        soffA[j] = __builtin_amdgcn_readfirstlane((uint32_t)(wave * 64 + j * 8) * (uint32_t)(lda * 2));
+        const int r = wave * 64 + j * 8;                             // first tile row of the copy
+        const int src = SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r;     // row inside the gate (or up) block
+        soffB[j] = __builtin_amdgcn_readfirstlane((uint32_t)src * (uint32_t)(ldb * 2));
+    });
+    const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
+    const uint32_t m0A = __builtin_amdgcn_readfirstlane(smem32 + wave * 8 * 1024);
+    const uint32_t m0B = __builtin_amdgcn_readfirstlane(smem32 + A4_ABYTES + wave * 8 * 1024);
+
+    f32x4 acc[8][8];                                                 // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / 64;
+    // fragment addresses: row = wave tile base + i*16 + (lane & 15), 16-byte chunk (s*4 + lane>>4) ^ (row & 7)
+    const int frow = lane & 15, fk = lane >> 4;
+    uint32_t adA[2][2], adB[2][2];                                   // [slot][k-step]
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kc = (s2 * 4 + fk) ^ (frow & 7);
+            adA[sl][s2] = smem32 + sl * A4_SLOT + (wm * 128 + frow) * 128 + (kc << 4);
+            adB[sl][s2] = smem32 + sl * A4_SLOT + A4_ABYTES + (wn * 128 + frow) * 128 + (kc << 4);
+        }
+    bf16x8 af[2][8], bfr[2][8];
+
+    auto dma_tile = [&](auto jc) {                                   // copy j of the NEXT issue (voff already points at its K-tile)
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < 8) a4_dma(voffA, srdA, soffA[j]);
+        else if (SWIGLU && (((wave * 64 + (j - 8) * 8) >> 4) & 1)) a4_dma(voffB, srdB2, soffB[j - 8]);
+        else a4_dma(voffB, srdB, soffB[j - 8]);
+    };
+    auto rd = [&](auto slot_c, auto s_c, auto i_c) {                 // i < 8: A fragment i, else B fragment i - 8
+        constexpr int slot = decltype(slot_c)::value, s2 = decltype(s_c)::value, i = decltype(i_c)::value;
+        if constexpr (i < 8) a4_read<i * 2048>(af[s2][i], adA[slot][s2]);
+        else a4_read<(i - 8) * 2048>(bfr[s2][i - 8], adB[slot][s2]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: tiles 0 and 1 in flight, fragments of (0, k-step 0) in registers
+    a4_m0_set(m0A);
+    static_for<0, 16>([&](auto jc) {
+        if constexpr (decltype(jc)::value == 8) a4_m0_set(m0B);
+        dma_tile(jc);
+        a4_m0_next();
+    });
+    voffA += 128; voffB += 128;
+    if (nk > 1) {
+        a4_m0_set(m0A + A4_SLOT);
+        static_for<0, 16>([&](auto jc) {
+            if constexpr (decltype(jc)::value == 8) a4_m0_set(m0B + A4_SLOT);
+            dma_tile(jc);
+            a4_m0_next();
+        });
+        voffA += 128; voffB += 128;
+        a4_wait_vm<16>();
+    } else {
+        a4_wait_vm<0>();
+    }
+    a4_barrier();
+    static_for<0, 16>([&](auto ic) { rd(I0{}, I0{}, ic); });
+    a4_wait_lgkm0();
+
+    // ---- one K-tile (slot P = kt & 1, compile time): see the schedule in the header comment
+    auto body = [&](auto slot_tag, auto next_tag, auto dma_tag) {
+        constexpr int P = decltype(slot_tag)::value;
+        constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_DMA = decltype(dma_tag)::value;
+        using PC = std::integral_constant<int, P>;
+        using QC = std::integral_constant<int, P ^ 1>;
+        // phase A: MFMAs of k-step 0; the 16 fragment reads of k-step 1 under the first 32; then slot P is free: first half of the copies
+        static_for<0, 64>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            a4_mfma(acc[idx >> 3][idx & 7], bfr[0][idx >> 3], af[0][idx & 7]);
+            if constexpr ((idx & 1) == 1 && idx < 32) rd(PC{}, I1{}, std::integral_constant<int, (idx >> 1)>{});
+            if constexpr (idx == 38) a4_wait_lgkm0();        // this wave's reads of slot P have returned ...
+            if constexpr (HAS_NEXT && idx == 39) a4_barrier();   // ... every wave's have: the slot may be refilled
+            if constexpr (HAS_DMA) {
+                if constexpr (idx == 40) a4_m0_set(m0A + P * A4_SLOT);
+                if constexpr (idx >= 41 && (idx - 41) % 3 == 0 && (idx - 41) / 3 < 8) dma_tile(std::integral_constant<int, (idx - 41) / 3>{});
+                if constexpr (idx >= 42 && (idx - 42) % 3 == 0 && (idx - 42) / 3 < 7) a4_m0_next();
+            }
+        });
+        // phase B: MFMAs of k-step 1; second half of the copies; tile t+1 has landed: its k-step-0 fragments
+        static_for<0, 64>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            a4_mfma(acc[idx >> 3][idx & 7], bfr[1][idx >> 3], af[1][idx & 7]);
+            if constexpr (HAS_DMA) {
+                if constexpr (idx == 0) a4_m0_set(m0B + P * A4_SLOT);
+                if constexpr (idx >= 1 && (idx - 1) % 3 == 0 && (idx - 1) / 3 < 8) dma_tile(std::integral_constant<int, 8 + (idx - 1) / 3>{});
+                if constexpr (idx >= 2 && (idx - 2) % 3 == 0 && (idx - 2) / 3 < 7) a4_m0_next();
+            }
+            if constexpr (HAS_NEXT) {
+                if constexpr (idx == 25) { if constexpr (HAS_DMA) a4_wait_vm<16>(); else a4_wait_vm<0>(); }   // this wave's copies of tile t+1 landed
+                if constexpr (idx == 26) a4_barrier();                                                        // every wave's did
+                if constexpr (idx >= 28 && idx < 60 && ((idx - 28) & 1) == 0) rd(QC{}, I0{}, std::integral_constant<int, ((idx - 28) >> 1)>{});
+                if constexpr (idx == 62) a4_wait_lgkm0();
+            }
+        });
+        if constexpr (HAS_DMA) { voffA += 128; voffB += 128; }
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using Y = std::true_type;
+    using Nn = std::false_type;
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) { body(T0{}, Y{}, Y{}); body(T1{}, Y{}, Y{}); }
+    if (kt + 2 < nk) { body(T0{}, Y{}, Y{}); body(T1{}, Y{}, Nn{}); body(T0{}, Nn{}, Nn{}); }
+    else if (kt + 1 < nk) { body(T0{}, Y{}, Nn{}); body(T1{}, Nn{}, Nn{}); }
+    else { body(T0{}, Nn{}, Nn{}); }
+    // MFMA results -> epilogue reads: the hazard checker cannot see into asm; every accumulator passes THROUGH a wait
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+        asm volatile("s_nop 7" : "+a"(acc[ni][0]), "+a"(acc[ni][1]), "+a"(acc[ni][2]), "+a"(acc[ni][3]), "+a"(acc[ni][4]), "+a"(acc[ni][5]),
+                     "+a"(acc[ni][6]), "+a"(acc[ni][7]));
+
+    // ---- epilogue through LDS: 2 passes of 256 rows x 128 columns of fp32 (rows padded to 528 bytes: conflict-free b128 writes)
+    constexpr int ROWB = 128 * 4 + 16;
+    __syncthreads();                                                 // every wave is done with the operand slots; no DMA in flight
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int nl = 0; nl < 4; ++nl)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int row = wm * 128 + mi * 16 + (lane & 15), col = wn * 64 + nl * 16 + (lane >> 4) * 4;
+                // SWIGLU: pass p holds tile columns ni = p*4 + nl: even ni = gate, odd = up of output columns (ni >> 1) * 16 ..
+                *reinterpret_cast<f32x4*>(smem + row * ROWB + col * 4) = acc[p * 4 + nl][mi];
+            }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if constexpr (SWIGLU) {
+            // image columns: wave wn at 64*wn; inside, [gate16 | up16 | gate16 | up16]; thread handles 8 output columns of one row
+            const int c8 = (t & 7) * 8;                              // 64 output columns per pass: (wn, pair q, half h)
+            const int wn_ = c8 >> 5, q = (c8 >> 4) & 1, h = c8 & 8;
+            const int lcol = wn_ * 64 + q * 32 + h;                  // gate columns at lcol .. lcol+7, up at +16
+            const int n = n0 + wn_ * 64 + p * 32 + q * 16 + h;      // output column
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 32 + (t >> 3), m = m0 + row;
+                if (m >= M || n >= N) continue;
+                float g[8], u[8], o[8];
+                *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4);
+                *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4 + 16);
+                *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 16) * 4);
+                *reinterpret_cast<float4*>(u + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 16) * 4 + 16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {                        // same roundings as st_gemm_nt + st_swiglu_fwd: bf16 gate/up, bf16 act
+                    g[r] = bfround(g[r]); u[r] = bfround(u[r]);
+                    o[r] = bfround(g[r] * sigmoidf_(g[r])) * u[r];
+                }
+                const bool full = n + 7 < N;
+                uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                if (full && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) *reinterpret_cast<uint4*>(cp) = pack8(o);
+                else for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+                if (gu) {
+                    uint16_t* gp = gu + (int64_t)m * ldgu + n;
+                    if (full && (reinterpret_cast<uintptr_t>(gp) & 15) == 0 && ((N * 2) & 15) == 0) {
+                        *reinterpret_cast<uint4*>(gp) = pack8(g);
+                        *reinterpret_cast<uint4*>(gp + N) = pack8(u);
+                    } else for (int r = 0; r < 8; ++r) if (n + r < N) { gp[r] = f2bf(g[r]); gp[N + r] = f2bf(u[r]); }
+                }
+            }
+        } else {
+            const int c8 = (t & 15) * 8;
+            const int n = n0 + (c8 >> 6) * 128 + p * 64 + (c8 & 63);
+            float bvals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool ncols = n + 7 < N;
+            if constexpr (HAS_BIAS) {
+                if (ncols && (reinterpret_cast<uintptr_t>(bias + n) & 15) == 0) unpack8(*reinterpret_cast<const uint4*>(bias + n), bvals);
+                else for (int r = 0; r < 8; ++r) bvals[r] = n + r < N ? bf2f(bias[n + r]) : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 16 + (t >> 4), m = m0 + row;
+                if (m >= M || n >= N) continue;
+                float v[8];
+                *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
+                *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
+                if constexpr (HAS_BIAS) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bvals[r];
+                }
+                if constexpr (HAS_RES) {
+                    const uint16_t* rp = res + (int64_t)m * ldr + n;
+                    float rr[8];
+                    if (ncols && (reinterpret_cast<uintptr_t>(rp) & 15) == 0) unpack8(*reinterpret_cast<const uint4*>(rp), rr);
+                    else for (int r = 0; r < 8; ++r) rr[r] = n + r < N ? bf2f(rp[r]) : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += rr[r];
+                }
+                if constexpr (OUT_BF16) {
+                    uint16_t* cp = Cb + (int64_t)m * ldc + n;
+                    if (ncols && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) *reinterpret_cast<uint4*>(cp) = pack8(v);
+                    else for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+                } else {
+                    float* cp = Cf + (int64_t)m * ldc + n;
+                    if (ncols && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) {
+                        float4 o0 = ACCUM ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        float4 o1 = ACCUM ? *reinterpret_cast<float4*>(cp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        o0.x += v[0]; o0.y += v[1]; o0.z += v[2]; o0.w += v[3]; o1.x += v[4]; o1.y += v[5]; o1.z += v[6]; o1.w += v[7];
+                        *reinterpret_cast<float4*>(cp) = o0; *reinterpret_cast<float4*>(cp + 4) = o1;
+                    } else {
+                        for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = (ACCUM ? cp[r] : 0.f) + v[r];
+                    }
+                }
+            }
+        }
+        if (p == 0) __syncthreads();                             // the second pass overwrites the image
+    }
+}
+
+template <bool HB, bool HR, bool OB, bool AC, bool SW>
+static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
+                       uint16_t* Cb, float* Cf, int64_t ldc, uint16_t* gu, int64_t ldgu, int M, int N, int K, hipStream_t s) {
+    constexpr int smem = 256 * 528;                              // >= the two 64-KiB operand slots
+    auto kern = gemm_nt4_kernel<HB, HR, OB, AC, SW>;
+    static bool configured = false;
+    if (!configured) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
+    const int tiles_m = st_cdiv(M, A4_BM), tiles_n = st_cdiv(N, SW ? A4_BN / 2 : A4_BN);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, gu, ldgu, M, N, K, tiles_m,
+                       tiles_n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// C = A B^T with the epilogue kinds of st_gemm_nt (exactly one of Cb / Cf; bias / residual only with Cb).  Row pitches must keep a
+// 256-row operand tile within 4 GiB (buffer offsets are 32-bit): lda, ldb < 2^22 elements.
+int st_gemm_asm4_dispatch(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
+                          uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K, hipStream_t s) {
+    if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
+    if (Cb) {
+        if (bias && res) return launch_asm4<true, true, true, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+        if (bias) return launch_asm4<true, false, true, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+        if (res) return launch_asm4<false, true, true, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+        return launch_asm4<false, false, true, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+    }
+    if (accumulate) return launch_asm4<false, false, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+    return launch_asm4<false, false, false, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+}
+
+// gate/up projection with the SwiGLU epilogue: m_out[M, I] = silu(A gate^T) * (A up^T), gu_out (optional) = bf16 gate | up
+int st_gemm_asm4_swiglu(const uint16_t* A, int64_t lda, const uint16_t* gate_up_w, int64_t ldb, uint16_t* gu_out, int64_t ldgu, uint16_t* m_out,
+                        int64_t ldm, int M, int I, int K, hipStream_t s) {
+    if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
+    return launch_asm4<false, false, true, false, true>(A, lda, gate_up_w, ldb, nullptr, nullptr, 0, m_out, nullptr, ldm, gu_out, ldgu, M, I, K, s);
+}

@@ -1,6 +1,10 @@
 // gemm_tiles_swiglu.hip — gate/up projection with the SwiGLU epilogue (training and decode).
 #include "gemm_tile_kernel.h"
 
+extern int g_train_variant;
+int st_gemm_asm4_swiglu(const uint16_t* A, int64_t lda, const uint16_t* gate_up_w, int64_t ldb, uint16_t* gu_out, int64_t ldgu, uint16_t* m_out,
+                        int64_t ldm, int M, int I, int K, hipStream_t s);
+
 /* gate/up projection with the SwiGLU in the epilogue for any M (training / prefill): m_out[M, I] = silu(A gate_w^T) * (A up_w^T);
  * gu_out (optional, [M, 2I]) additionally receives the bf16 gate|up values the backward needs. */
 extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* gu_out, int64_t ldgu,
@@ -10,6 +14,8 @@ extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)(2 * I) * (double)K);
+    if (g_train_variant == 40 && (int64_t)st_cdiv(M, 256) * st_cdiv(I, 128) >= 128)
+        return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, gu_out, ldgu, m_out, ldm, M, I, K, s);
     return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, m_out, ldm, M, I, K, s, gu_out, ldgu);
 }
 

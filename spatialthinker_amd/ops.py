@@ -376,6 +376,11 @@ def gemm_mxfp8_nt(aq, sa, bq, sb, *, bias=None, residual=None, out=None):
     return out
 
 
+def gemm_select(variant: int):
+    """Production tile of the training-shape GEMMs (st_gemm_select): 23 = 8-wave tile, 40 = 4-wave tile with the hand-scheduled loop."""
+    lib().st_gemm_select(int(variant))
+
+
 def gemm_nt_variant(variant, a, b, out=None, out_f32=None, accumulate=False, bias=None, residual=None):
     M, K = a.shape
     N = b.shape[0]

@@ -283,8 +283,8 @@ def test_gemm_nt(ops, M_, N, K):
     assert np.abs(acc.cpu().numpy() - want.numpy()).max() < scale * 1e-5 + 1e-4
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 23])
-@pytest.mark.parametrize("K", [64, 128, 192, 320])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 23, 40])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 448])
 def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
     """Every tile/pipeline variant (2- and 3-slot rings, the mid-tile-barrier schedule) at 1, 2, 3 and 5 K-tiles — the
     prologue / steady state / peeled tail paths — with ragged M, N; bf16 and fp32-accumulate epilogues."""
@@ -618,3 +618,55 @@ def test_gemm_nn_tn_contraction_major_operands(ops, shape):
     wide_a = torch.zeros(M_, K + 128, dtype=torch.bfloat16, device="cuda"); wide_a[:, 64:64 + K] = a
     wide_w = torch.zeros(K, N + 256, dtype=torch.bfloat16, device="cuda"); wide_w[:, 128:128 + N] = w_kn
     assert torch.equal(ops.gemm_nn(wide_a[:, 64:64 + K], wide_w[:, 128:128 + N]), ops.gemm_nn(a, w_kn))
+
+
+# ------------------------------------------------------------------ the 4-wave tile with the hand-scheduled K loop (gemm_asm4.hip)
+@pytest.mark.parametrize("shape", [(300, 520, 192), (1000, 777 * 8, 256), (513, 1016, 64), (4200, 4104, 1024), (256, 256, 3584)])
+def test_gemm_asm4_every_epilogue_vs_fp32_and_8wave_tile(ops, shape):
+    """Variant 40 (4 waves x 128x128, every K-loop instruction an asm statement, operands through buffer_load ... lds with the rows
+    beyond M / N cut off by the buffer's num_records) against the fp32 product and against the 8-wave production tile (same MFMA
+    shape and fp32 summation order per output element -> bit-identical bf16 outputs): ragged M / N, 1..16 K-tiles (every prologue /
+    steady-state / tail path of the 2-slot pipeline), bias / residual / fp32 (accumulate) epilogues, strided views."""
+    M_, N, K = shape
+    rs = np.random.RandomState(M_ + N + K)
+    a = bf(rs.standard_normal((M_, K))).cuda()
+    b = bf(rs.standard_normal((N, K)) * (1 + np.arange(N)[:, None] / N)).cuda()
+    bias, res = bf(rs.standard_normal(N)).cuda(), bf(rs.standard_normal((M_, N))).cuda()
+    want = a.float() @ b.float().t()
+    scale = float(want.abs().max())
+    for kw in ({}, {"bias": bias}, {"residual": res}, {"bias": bias, "residual": res}):
+        got = ops.gemm_nt_variant(40, a, b, **kw)
+        ref = want + (bias.float() if "bias" in kw else 0.0) + (res.float() if "residual" in kw else 0.0)
+        assert float((got.float() - ref).abs().max()) < scale * 2 ** -7, list(kw)
+        assert torch.equal(got, ops.gemm_nt_variant(6, a, b, **kw)), list(kw)
+    for accumulate in (True, False):
+        f = torch.full((M_, N), 0.25, dtype=torch.float32, device="cuda"); f6 = f.clone()
+        ops.gemm_nt_variant(40, a, b, out_f32=f, accumulate=accumulate)
+        ops.gemm_nt_variant(6, a, b, out_f32=f6, accumulate=accumulate)
+        assert float((f - want - (0.25 if accumulate else 0.0)).abs().max()) < scale * 1e-5 + 1e-4, accumulate
+        assert torch.equal(f, f6), accumulate
+    big = torch.zeros(M_, N + 64, dtype=torch.bfloat16, device="cuda")
+    resb = torch.zeros(M_, N + 64, dtype=torch.bfloat16, device="cuda"); resb[:, 8:N + 8] = res
+    wide_a = torch.zeros(M_, K + 128, dtype=torch.bfloat16, device="cuda"); wide_a[:, 64:64 + K] = a
+    ops.gemm_nt_variant(40, wide_a[:, 64:64 + K], b, out=big[:, 8:N + 8], residual=resb[:, 8:N + 8])
+    assert torch.equal(big[:, 8:N + 8], ops.gemm_nt_variant(6, a, b, residual=res)) and float(big[:, :8].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M_,I,K", [(517, 1216, 256), (300, 200, 128), (4100, 4104, 512), (33000, 1024, 192)])
+def test_gemm_asm4_swiglu_epilogue_bit_identical(ops, M_, I, K):
+    """st_gemm_swiglu on the 4-wave tile (st_gemm_select(40)): m and the kept gate|up equal st_gemm_nt + st_swiglu_fwd bit for bit."""
+    rs = np.random.RandomState(M_ + I)
+    a = bf(rs.standard_normal((M_, K))).cuda()
+    w = bf(rs.standard_normal((2 * I, K)) * 0.1).cuda()
+    gu_ref = ops.gemm_nt_variant(6, a, w)
+    m_ref = ops.swiglu_fwd(gu_ref)
+    try:
+        ops.gemm_select(40)
+        gu, m = ops.gemm_swiglu(a, w, want_gu=True)
+        gu2, m2 = ops.gemm_swiglu(a, w, want_gu=False)
+    finally:
+        ops.gemm_select(23)
+    if -(-M_ // 256) * -(-I // 128) >= 128:                      # below that the launcher keeps the 8-wave tile
+        pass
+    assert torch.equal(gu, gu_ref) and torch.equal(m, m_ref)
+    assert gu2 is None and torch.equal(m2, m_ref)

@@ -174,8 +174,16 @@ def release_cached_blocks():
     every step); carried over, the split blocks of one phase fragment the next one and the reserved pool creeps up step after step
     (round 2: 202 -> 235 GB over 25 steps).  OPT-IN (ST_EMPTY_CACHE=1): measured on the bench it costs more than it saves — the
     update phase then re-requests ~70 GB from the driver every step, peak reserved went 202 -> 287 GB and update_actor 14.9 -> 17.1 s
-    (profiles/r03 notes); the default bound on the creep is the expandable-segments allocator mode (bench.py sets it)."""
-    if os.environ.get("ST_EMPTY_CACHE", "0") == "1" and torch.cuda.is_available():
+    (profiles/r03_notes.md; torch's expandable-segments mode, the usual cure, is "not supported on this platform")."""
+    if not torch.cuda.is_available():
+        return
+    if os.environ.get("ST_EMPTY_CACHE", "0") == "1":
+        torch.cuda.empty_cache()
+        return
+    # default: only when the pool has crept close to the device's capacity (the caching allocator would otherwise start to
+    # free-and-retry inside the next phase, which synchronises the device per block) — a rare, bounded clean-up
+    free_b, total_b = torch.cuda.mem_get_info()
+    if torch.cuda.memory_reserved() > 0.80 * total_b and torch.cuda.memory_allocated() < 0.60 * total_b:
         torch.cuda.empty_cache()
 
 

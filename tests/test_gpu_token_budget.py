@@ -1,0 +1,85 @@
+"""Token-budgeted passes at 7B widths: 32 rows at the 2048-token response cap (4 rollout groups of 8 behind
+1102-token prompts = ~70k packed tokens) through PolicyEngine.update_policy on a 1-layer model with the real 7B widths.  The
+reference's contract is that micro_batch_size_per_device_for_update holds for any sequence length up to max_prompt_length +
+max_response_length (verl/workers/actor/dp_actor.py:212-292; scripts/spatialthinker_7b_grpo.sh:33-34), so the engine must cut the
+mini-batch into passes by packed-token count instead of fusing a fixed number of micro-batches."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import fullsize  # noqa: E402
+
+
+def _engine(params):
+    from spatialthinker_amd import model as mdl
+    from spatialthinker_amd.actor import ActorHyper, PolicyEngine
+    cfg = mdl.VLConfig(**fullsize.FULL)
+    store = mdl.ParamStore(cfg, trainable=True)
+    store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = PolicyEngine(cfg, store, ActorHyper(micro_batch_size_per_device_for_update=4, global_batch_size_per_device=32, lr=1e-6))
+    grads = []
+
+    def capture():                                            # stands in for optimizer_step: keep the accumulated gradient, change nothing
+        torch.cuda.synchronize()
+        grads.append(store.grad.clone())
+        store.grad.zero_()
+        return 1.0
+    eng.optimizer_step = capture
+    return eng, grads
+
+
+def _data(rs, n_groups=4, G=8, P_valid=1102, Pc=1152, R=2048):
+    B = n_groups * G
+    ids = np.full((B, Pc + R), fullsize.PAD, dtype=np.int64)
+    mask = np.zeros((B, Pc + R), dtype=np.int64)
+    for g in range(n_groups):
+        prompt = rs.randint(0, 150000, P_valid)
+        for j in range(G):
+            r = g * G + j
+            ids[r, Pc - P_valid:Pc] = prompt; mask[r, Pc - P_valid:Pc] = 1
+            L = R if j % 4 != 3 else int(rs.randint(64, R))        # three of four rollouts run into the cap
+            ids[r, Pc:Pc + L] = rs.randint(0, 150000, L); mask[r, Pc:Pc + L] = 1
+    pos = np.clip(np.cumsum(mask, 1) - 1, 0, None)[:, None, :].repeat(3, 1)
+    rmask = mask[:, -R:]
+    old = (-11.9 + 0.3 * rs.standard_normal((B, R))).astype(np.float32)
+    adv = rs.standard_normal((B, 1)).astype(np.float32).repeat(R, 1) * rmask
+    t = torch.from_numpy
+    return dict(input_ids=t(ids), attention_mask=t(mask), position_ids=t(pos), responses=t(ids[:, -R:].copy()),
+                old_log_probs=t(old), ref_log_probs=t(old.copy()), advantages=t(adv)), int(mask.sum())
+
+
+def test_32_rows_at_the_2048_token_cap_run_in_budgeted_passes_with_bounded_memory(measured):
+    params = fullsize.make_params()
+    data, n_tokens = _data(np.random.RandomState(3))
+    eng, grads = _engine(params)
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    eng.update_policy(data, 1.0)
+    peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
+    plan = eng.last_plan["update"]
+    assert plan == [(0, 8), (8, 16), (16, 24), (24, 32)], plan             # one rollout group (1102 + ~16k tokens) per pass: the next group would exceed 24576
+    measured("token_budget_7bwidth_peak_gb_above_weights", peak)
+    # a pass keeps ~17.5k packed tokens of one LM layer (~1.9 GB) + 16k x 152064 logits (~5 GB) + transients; the unbudgeted 32-row pass
+    # would need 4x that (20 GB of logits alone)
+    assert peak < 14.0, peak
+    g_budget = grads[0]
+    del eng
+    torch.cuda.empty_cache()
+    eng1, grads1 = _engine(params)
+    eng1.fuse_micro_batches = 1                                             # the reference's own granularity: one micro-batch per pass
+    eng1.update_policy(data, 1.0)
+    assert eng1.last_plan["update"] == [(i, i + 4) for i in range(0, 32, 4)]
+    g_ref = grads1[0]
+    # NOT bit-identical, and cannot be: a fused pass sums dW over its tokens in one K loop where the single-micro-batch passes
+    # accumulate four GEMMs into the fp32 buffer, and the shared prompt is stored once per pass — same mathematics (each micro-batch
+    # keeps its own token-mean normalisation), different fp32 summation order and bf16 rounding of a few activations
+    st = eng1.store
+    worst = 0.0
+    for name in ("l.0.qkv_w", "l.0.o_w", "l.0.gu_w", "l.0.down_w", "lm_head", "final_norm", "l.0.in_norm"):
+        a, b = st._view(g_budget, name).float(), st._view(g_ref, name).float()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel < 2e-2, (name, rel)
+    measured("token_budget_grad_rel_l2_vs_single_micro_batch_passes", worst)

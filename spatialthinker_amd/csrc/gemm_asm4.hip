@@ -49,6 +49,16 @@ __device__ __forceinline__ void a4_m0_set(uint32_t v) { asm volatile("s_mov_b32 
 __device__ __forceinline__ void a4_m0_next() { asm volatile("s_add_u32 m0, m0, 0x400" : : : "memory", "scc"); }
 __device__ __forceinline__ void a4_barrier() { asm volatile("s_barrier" : : : "memory"); }
 __device__ __forceinline__ void a4_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
+template <int N> __device__ __forceinline__ void a4_wait_lgkm() {          // LDS reads return in order: "at most N still outstanding"
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+    else if constexpr (N == 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    else static_assert(N < 0, "add the lgkmcnt literal");
+}
 template <int N> __device__ __forceinline__ void a4_wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -111,9 +121,13 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     uint32_t soffA[8], soffB[8];
     static_for<0, 8>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        soffA[j] = __builtin_amdgcn_readfirstlane((uint32_t)(wave * 64 + j * 8) * (uint32_t)(lda * 2));
+        // gfx9 buffers range-check voffset only (soffset is excluded), so a copy's 8 rows are kept inside the matrix by clamping its
+        // SGPR offset to the last 8 valid rows (such rows compute values that are never stored); tiles with fewer than 8 valid rows
+        // are cut by num_records through the lane's own row offset
+        const int ra = min(wave * 64 + j * 8, max(rows_a - 8, 0));
+        soffA[j] = __builtin_amdgcn_readfirstlane((uint32_t)ra * (uint32_t)(lda * 2));
         const int r = wave * 64 + j * 8;                             // first tile row of the copy
-        const int src = SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r;     // row inside the gate (or up) block
+        const int src = min(SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r, max(cols_b - 8, 0));     // row inside the gate (or up) block
         soffB[j] = __builtin_amdgcn_readfirstlane((uint32_t)src * (uint32_t)(ldb * 2));
     });
     const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
@@ -129,15 +143,16 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     const int nk = K / 64;
     // fragment addresses: row = wave tile base + i*16 + (lane & 15), 16-byte chunk (s*4 + lane>>4) ^ (row & 7)
     const int frow = lane & 15, fk = lane >> 4;
-    uint32_t adA[2][2], adB[2][2];                                   // [slot][k-step]
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int kc = (s2 * 4 + fk) ^ (frow & 7);
-            adA[sl][s2] = smem32 + sl * A4_SLOT + (wm * 128 + frow) * 128 + (kc << 4);
-            adB[sl][s2] = smem32 + sl * A4_SLOT + A4_ABYTES + (wn * 128 + frow) * 128 + (kc << 4);
-        }
+    // fragment read addresses; the two LDS slots are 64 KiB apart, so "the other slot" is an XOR with 0x10000: the k-step-1 reads of
+    // tile t go to its slot (adK1), the k-step-0 reads of tile t+1 to the other one (adK0n); both flip after every tile
+    uint32_t adA_k1, adB_k1, adA_k0n, adB_k0n;
+    {
+        const int kc0 = fk ^ (frow & 7), kc1 = (4 + fk) ^ (frow & 7);
+        adA_k1 = smem32 + (wm * 128 + frow) * 128 + (kc1 << 4);
+        adB_k1 = smem32 + A4_ABYTES + (wn * 128 + frow) * 128 + (kc1 << 4);
+        adA_k0n = smem32 + A4_SLOT + (wm * 128 + frow) * 128 + (kc0 << 4);
+        adB_k0n = smem32 + A4_SLOT + A4_ABYTES + (wn * 128 + frow) * 128 + (kc0 << 4);
+    }
     bf16x8 af[2][8], bfr[2][8];
 
     auto dma_tile = [&](auto jc) {                                   // copy j of the NEXT issue (voff already points at its K-tile)
@@ -146,13 +161,18 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         else if (SWIGLU && (((wave * 64 + (j - 8) * 8) >> 4) & 1)) a4_dma(voffB, srdB2, soffB[j - 8]);
         else a4_dma(voffB, srdB, soffB[j - 8]);
     };
-    auto rd = [&](auto slot_c, auto s_c, auto i_c) {                 // i < 8: A fragment i, else B fragment i - 8
-        constexpr int slot = decltype(slot_c)::value, s2 = decltype(s_c)::value, i = decltype(i_c)::value;
-        if constexpr (i < 8) a4_read<i * 2048>(af[s2][i], adA[slot][s2]);
-        else a4_read<(i - 8) * 2048>(bfr[s2][i - 8], adB[slot][s2]);
+    // i < 8: A fragment i, else B fragment i - 8 (16 rows = 2048 bytes apart)
+    auto rd_k1 = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i < 8) a4_read<i * 2048>(af[1][i], adA_k1);
+        else a4_read<(i - 8) * 2048>(bfr[1][i - 8], adB_k1);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
+    auto rd_k0n = [&](auto i_c) {                                    // order of issue: A0..A7, B0 first (the next tile's first MFMAs need them)
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i < 8) a4_read<i * 2048>(af[0][i], adA_k0n);
+        else a4_read<(i - 8) * 2048>(bfr[0][i - 8], adB_k0n);
+    };
+    uint32_t m0A_cur = m0A, m0B_cur = m0B;                           // LDS-DMA destination of the tile being refilled (slot of tile t)
 
     // ---- prologue: tiles 0 and 1 in flight, fragments of (0, k-step 0) in registers
     a4_m0_set(m0A);
@@ -161,69 +181,61 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         dma_tile(jc);
         a4_m0_next();
     });
-    voffA += 128; voffB += 128;
-    if (nk > 1) {
-        a4_m0_set(m0A + A4_SLOT);
-        static_for<0, 16>([&](auto jc) {
-            if constexpr (decltype(jc)::value == 8) a4_m0_set(m0B + A4_SLOT);
-            dma_tile(jc);
-            a4_m0_next();
-        });
-        voffA += 128; voffB += 128;
-        a4_wait_vm<16>();
-    } else {
-        a4_wait_vm<0>();
-    }
+    if (nk > 1) { voffA += 128; voffB += 128; }
+    a4_m0_set(m0A + A4_SLOT);
+    static_for<0, 16>([&](auto jc) {                                 // (nk == 1: tile 0 once more — keeps the loop's counted waits uniform)
+        if constexpr (decltype(jc)::value == 8) a4_m0_set(m0B + A4_SLOT);
+        dma_tile(jc);
+        a4_m0_next();
+    });
+    if (nk > 2) { voffA += 128; voffB += 128; }
+    a4_wait_vm<16>();
     a4_barrier();
-    static_for<0, 16>([&](auto ic) { rd(I0{}, I0{}, ic); });
-    a4_wait_lgkm0();
+    {                                                                // (0, k-step 0) sits in slot 0 = "the other slot" of the flipped addresses
+        adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
+        static_for<0, 16>([&](auto ic) { rd_k0n(ic); });
+        adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
+    }
+    a4_wait_lgkm<7>();
 
-    // ---- one K-tile (slot P = kt & 1, compile time): see the schedule in the header comment
-    auto body = [&](auto slot_tag, auto next_tag, auto dma_tag) {
-        constexpr int P = decltype(slot_tag)::value;
-        constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_DMA = decltype(dma_tag)::value;
-        using PC = std::integral_constant<int, P>;
-        using QC = std::integral_constant<int, P ^ 1>;
-        // phase A: MFMAs of k-step 0; the 16 fragment reads of k-step 1 under the first 32; then slot P is free: first half of the copies
-        static_for<0, 64>([&](auto ic) {
-            constexpr int idx = decltype(ic)::value;
-            a4_mfma(acc[idx >> 3][idx & 7], bfr[0][idx >> 3], af[0][idx & 7]);
-            if constexpr ((idx & 1) == 1 && idx < 32) rd(PC{}, I1{}, std::integral_constant<int, (idx >> 1)>{});
-            if constexpr (idx == 38) a4_wait_lgkm0();        // this wave's reads of slot P have returned ...
-            if constexpr (HAS_NEXT && idx == 39) a4_barrier();   // ... every wave's have: the slot may be refilled
-            if constexpr (HAS_DMA) {
-                if constexpr (idx == 40) a4_m0_set(m0A + P * A4_SLOT);
-                if constexpr (idx >= 41 && (idx - 41) % 3 == 0 && (idx - 41) / 3 < 8) dma_tile(std::integral_constant<int, (idx - 41) / 3>{});
-                if constexpr (idx >= 42 && (idx - 42) % 3 == 0 && (idx - 42) / 3 < 7) a4_m0_next();
-            }
+    // ---- one K-tile: 128 MFMA slots; every other instruction sits between two of them
+    //   slot   0..63  MFMAs of k-step 0          64..127  MFMAs of k-step 1
+    //   8,16,24,32,40  counted lgkmcnt waits: B fragments 1..7 of k-step 0 were issued LAST in the previous tile and land now
+    //   9..39 (odd)    the 16 fragment reads of k-step 1 (this tile's slot)
+    //   52 / 53        lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot
+    //   54..99         the 16 LDS-DMA copies of tile t+2 into that slot, one every third MFMA (+ the M0 updates)
+    //   100 / 101      vmcnt(16) + barrier #2: tile t+1 has landed for every wave (tile t+2's copies stay in flight)
+    //   102..127       the 16 fragment reads of (t+1, k-step 0): A0..A7, B0, then B1..B7; lgkmcnt(7) closes the tile
+    for (int kt = 0; kt < nk; ++kt) {
+        static_for<0, 128>([&](auto ic) {
+            constexpr int sl = decltype(ic)::value;
+            constexpr int ks = sl >> 6, idx = sl & 63;
+            a4_mfma(acc[idx >> 3][idx & 7], bfr[ks][idx >> 3], af[ks][idx & 7]);
+            if constexpr (sl == 7) a4_wait_lgkm<6>();            // before MFMA 8 (B1): after B1 only B2..B7 may be outstanding
+            if constexpr (sl == 15) a4_wait_lgkm<8>();           // B2: B3..B7 + the 3 k-step-1 reads issued so far (slots 9, 11, 13)
+            if constexpr (sl == 23) a4_wait_lgkm<11>();          // B3: B4..B7 + 7 reads
+            if constexpr (sl == 31) a4_wait_lgkm<14>();          // B4: B5..B7 + 11 reads
+            if constexpr (sl == 39) a4_wait_lgkm<15>();          // B5..B7: the 3 oldest of the 18 then outstanding (the counter saturates at 15)
+            if constexpr (sl >= 9 && sl <= 39 && (sl & 1) == 1) rd_k1(std::integral_constant<int, ((sl - 9) >> 1)>{});
+            if constexpr (sl == 52) a4_wait_lgkm<0>();
+            if constexpr (sl == 53) { a4_barrier(); a4_m0_set(m0A_cur); }
+            if constexpr (sl >= 54 && sl <= 99 && (sl - 54) % 3 == 0) dma_tile(std::integral_constant<int, ((sl - 54) / 3)>{});
+            if constexpr (sl >= 55 && sl <= 99 && (sl - 55) % 3 == 0 && (sl - 55) / 3 != 7 && (sl - 55) / 3 < 15) a4_m0_next();
+            if constexpr (sl == 76) a4_m0_set(m0B_cur);          // after the 8th A copy (slot 75), before the first B copy (slot 78)
+            if constexpr (sl == 100) a4_wait_vm<16>();
+            if constexpr (sl == 101) a4_barrier();
+            if constexpr (sl >= 102 && sl <= 118 && (sl & 1) == 0) rd_k0n(std::integral_constant<int, ((sl - 102) >> 1)>{});
+            if constexpr (sl >= 120 && sl <= 126) rd_k0n(std::integral_constant<int, (9 + sl - 120)>{});
+            if constexpr (sl == 127) a4_wait_lgkm<7>();
         });
-        // phase B: MFMAs of k-step 1; second half of the copies; tile t+1 has landed: its k-step-0 fragments
-        static_for<0, 64>([&](auto ic) {
-            constexpr int idx = decltype(ic)::value;
-            a4_mfma(acc[idx >> 3][idx & 7], bfr[1][idx >> 3], af[1][idx & 7]);
-            if constexpr (HAS_DMA) {
-                if constexpr (idx == 0) a4_m0_set(m0B + P * A4_SLOT);
-                if constexpr (idx >= 1 && (idx - 1) % 3 == 0 && (idx - 1) / 3 < 8) dma_tile(std::integral_constant<int, 8 + (idx - 1) / 3>{});
-                if constexpr (idx >= 2 && (idx - 2) % 3 == 0 && (idx - 2) / 3 < 7) a4_m0_next();
-            }
-            if constexpr (HAS_NEXT) {
-                if constexpr (idx == 25) { if constexpr (HAS_DMA) a4_wait_vm<16>(); else a4_wait_vm<0>(); }   // this wave's copies of tile t+1 landed
-                if constexpr (idx == 26) a4_barrier();                                                        // every wave's did
-                if constexpr (idx >= 28 && idx < 60 && ((idx - 28) & 1) == 0) rd(QC{}, I0{}, std::integral_constant<int, ((idx - 28) >> 1)>{});
-                if constexpr (idx == 62) a4_wait_lgkm0();
-            }
-        });
-        if constexpr (HAS_DMA) { voffA += 128; voffB += 128; }
-    };
-    using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, 1>;
-    using Y = std::true_type;
-    using Nn = std::false_type;
-    int kt = 0;
-    for (; kt + 3 < nk; kt += 2) { body(T0{}, Y{}, Y{}); body(T1{}, Y{}, Y{}); }
-    if (kt + 2 < nk) { body(T0{}, Y{}, Y{}); body(T1{}, Y{}, Nn{}); body(T0{}, Nn{}, Nn{}); }
-    else if (kt + 1 < nk) { body(T0{}, Y{}, Nn{}); body(T1{}, Nn{}, Nn{}); }
-    else { body(T0{}, Nn{}, Nn{}); }
+        // flip the slots; advance the source of the next copies (the last two tiles re-fetch tile nk-1: lands in a slot nobody reads)
+        adA_k1 ^= A4_SLOT; adB_k1 ^= A4_SLOT; adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
+        m0A_cur ^= A4_SLOT; m0B_cur ^= A4_SLOT;
+        const uint32_t step = (kt + 3 < nk) ? 128u : 0u;
+        voffA += step; voffB += step;
+    }
+    a4_wait_vm<0>();                                                 // the two re-fetched tiles are still landing
+    a4_wait_lgkm<0>();
     // MFMA results -> epilogue reads: the hazard checker cannot see into asm; every accumulator passes THROUGH a wait
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni)

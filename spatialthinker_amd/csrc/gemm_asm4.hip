@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     i32x4 srdA, srdB, srdB2;
     srdA.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a_base);
     srdA.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a_base >> 32) & 0xffffu));
-    srdA.z = __builtin_amdgcn_readfirstlane((int)((int64_t)rows_a * lda * 2));
+    srdA.z = (int)0xffffffffu;                                       // rows are clamped per lane: nothing to cut off
     srdA.w = 0x00020000;
     const int cols_b = SWIGLU ? min(A4_BN / 2, N - n0) : min(A4_BN, N - n0);        // B rows (= output columns) this tile owns
     const uint64_t b_base = (uint64_t)(B + (int64_t)n0 * ldb);
     srdB.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b_base);
     srdB.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b_base >> 32) & 0xffffu));
-    srdB.z = __builtin_amdgcn_readfirstlane((int)((int64_t)cols_b * ldb * 2));
+    srdB.z = (int)0xffffffffu;
     srdB.w = 0x00020000;
     srdB2 = srdB;
     if constexpr (SWIGLU) {                                          // the up-projection rows follow the N gate rows
@@ -114,22 +114,20 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         srdB2.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)u_base);
         srdB2.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((u_base >> 32) & 0xffffu));
     }
-    // lane part of a copy's source address: row (lane >> 3) of the copy's 8 rows, chunk (lane & 7) ^ row  (the swizzle on the source)
-    uint32_t voffA = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
-    uint32_t voffB = (uint32_t)(lane >> 3) * (uint32_t)(ldb * 2) + (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
-    // copy j of this wave: A rows wave*64 + 8j .. +8; B tile rows wave*64 + 8j .. +8 (SWIGLU: tile rows alternate 16 gate / 16 up)
-    uint32_t soffA[8], soffB[8];
+    // source offset of copy j of this wave, per lane: row (lane >> 3) of the copy's 8 rows — clamped to the last valid row of the
+    // tile, such rows compute values that are never stored — and the 16-byte chunk (lane & 7) ^ row (the swizzle, on the source).
+    // These 16 registers are constant over the K loop: the K-tile offset goes through the instruction's SGPR offset.
+    uint32_t voffA[8], voffB[8];
     static_for<0, 8>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        // gfx9 buffers range-check voffset only (soffset is excluded), so a copy's 8 rows are kept inside the matrix by clamping its
-        // SGPR offset to the last 8 valid rows (such rows compute values that are never stored); tiles with fewer than 8 valid rows
-        // are cut by num_records through the lane's own row offset
-        const int ra = min(wave * 64 + j * 8, max(rows_a - 8, 0));
-        soffA[j] = __builtin_amdgcn_readfirstlane((uint32_t)ra * (uint32_t)(lda * 2));
-        const int r = wave * 64 + j * 8;                             // first tile row of the copy
-        const int src = min(SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r, max(cols_b - 8, 0));     // row inside the gate (or up) block
-        soffB[j] = __builtin_amdgcn_readfirstlane((uint32_t)src * (uint32_t)(ldb * 2));
+        const int rl = lane >> 3, ch = ((lane & 7) ^ rl) << 4;
+        const int ra = min(wave * 64 + j * 8 + rl, rows_a - 1);
+        voffA[j] = (uint32_t)ra * (uint32_t)(lda * 2) + ch;
+        const int r = wave * 64 + j * 8 + rl;                        // tile row (SWIGLU: tile rows alternate 16 gate / 16 up rows)
+        const int src = min(SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r, cols_b - 1);
+        voffB[j] = (uint32_t)src * (uint32_t)(ldb * 2) + ch;
     });
+    uint32_t koff = 0;                                               // byte offset of the K-tile the next copies fetch (SGPR)
     const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
     const uint32_t m0A = __builtin_amdgcn_readfirstlane(smem32 + wave * 8 * 1024);
     const uint32_t m0B = __builtin_amdgcn_readfirstlane(smem32 + A4_ABYTES + wave * 8 * 1024);
@@ -157,9 +155,9 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 
     auto dma_tile = [&](auto jc) {                                   // copy j of the NEXT issue (voff already points at its K-tile)
         constexpr int j = decltype(jc)::value;
-        if constexpr (j < 8) a4_dma(voffA, srdA, soffA[j]);
-        else if (SWIGLU && (((wave * 64 + (j - 8) * 8) >> 4) & 1)) a4_dma(voffB, srdB2, soffB[j - 8]);
-        else a4_dma(voffB, srdB, soffB[j - 8]);
+        if constexpr (j < 8) a4_dma(voffA[j], srdA, koff);
+        else if (SWIGLU && (((wave * 64 + (j - 8) * 8) >> 4) & 1)) a4_dma(voffB[j - 8], srdB2, koff);
+        else a4_dma(voffB[j - 8], srdB, koff);
     };
     // i < 8: A fragment i, else B fragment i - 8 (16 rows = 2048 bytes apart)
     auto rd_k1 = [&](auto i_c) {
@@ -181,14 +179,14 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         dma_tile(jc);
         a4_m0_next();
     });
-    if (nk > 1) { voffA += 128; voffB += 128; }
+    if (nk > 1) koff += 128;
     a4_m0_set(m0A + A4_SLOT);
     static_for<0, 16>([&](auto jc) {                                 // (nk == 1: tile 0 once more — keeps the loop's counted waits uniform)
         if constexpr (decltype(jc)::value == 8) a4_m0_set(m0B + A4_SLOT);
         dma_tile(jc);
         a4_m0_next();
     });
-    if (nk > 2) { voffA += 128; voffB += 128; }
+    if (nk > 2) koff += 128;
     a4_wait_vm<16>();
     a4_barrier();
     {                                                                // (0, k-step 0) sits in slot 0 = "the other slot" of the flipped addresses
@@ -231,8 +229,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         // flip the slots; advance the source of the next copies (the last two tiles re-fetch tile nk-1: lands in a slot nobody reads)
         adA_k1 ^= A4_SLOT; adB_k1 ^= A4_SLOT; adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
         m0A_cur ^= A4_SLOT; m0B_cur ^= A4_SLOT;
-        const uint32_t step = (kt + 3 < nk) ? 128u : 0u;
-        voffA += step; voffB += step;
+        koff += (kt + 3 < nk) ? 128u : 0u;
     }
     a4_wait_vm<0>();                                                 // the two re-fetched tiles are still landing
     a4_wait_lgkm<0>();
@@ -263,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
             const int wn_ = c8 >> 5, q = (c8 >> 4) & 1, h = c8 & 8;
             const int lcol = wn_ * 64 + q * 32 + h;                  // gate columns at lcol .. lcol+7, up at +16
             const int n = n0 + wn_ * 64 + p * 32 + q * 16 + h;      // output column
-#pragma unroll
+#pragma unroll 2
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 32 + (t >> 3), m = m0 + row;
                 if (m >= M || n >= N) continue;

@@ -634,6 +634,7 @@ def test_gemm_asm4_every_epilogue_vs_fp32_and_8wave_tile(ops, shape):
     bias, res = bf(rs.standard_normal(N)).cuda(), bf(rs.standard_normal((M_, N))).cuda()
     want = a.float() @ b.float().t()
     scale = float(want.abs().max())
+    ops.gemm_tail_split(False)                                   # compare whole-tile launches (the K-sliced tail sums in another order)
     for kw in ({}, {"bias": bias}, {"residual": res}, {"bias": bias, "residual": res}):
         got = ops.gemm_nt_variant(40, a, b, **kw)
         ref = want + (bias.float() if "bias" in kw else 0.0) + (res.float() if "residual" in kw else 0.0)
@@ -650,6 +651,7 @@ def test_gemm_asm4_every_epilogue_vs_fp32_and_8wave_tile(ops, shape):
     wide_a = torch.zeros(M_, K + 128, dtype=torch.bfloat16, device="cuda"); wide_a[:, 64:64 + K] = a
     ops.gemm_nt_variant(40, wide_a[:, 64:64 + K], b, out=big[:, 8:N + 8], residual=resb[:, 8:N + 8])
     assert torch.equal(big[:, 8:N + 8], ops.gemm_nt_variant(6, a, b, residual=res)) and float(big[:, :8].abs().max()) == 0
+    ops.gemm_tail_split(True)
 
 
 @pytest.mark.parametrize("M_,I,K", [(517, 1216, 256), (300, 200, 128), (4100, 4104, 512), (33000, 1024, 192)])

@@ -48,14 +48,20 @@ __device__ __forceinline__ void a4_dma(uint32_t voff, i32x4 srd, uint32_t soff) 
 __device__ __forceinline__ void a4_m0_set(uint32_t v) { asm volatile("s_mov_b32 m0, %0" : : "s"(v) : "memory"); }
 __device__ __forceinline__ void a4_m0_next() { asm volatile("s_add_u32 m0, m0, 0x400" : : : "memory", "scc"); }
 __device__ __forceinline__ void a4_barrier() { asm volatile("s_barrier" : : : "memory"); }
+// Wave w waits 16*w cycles: the four waves of a workgroup leave a barrier together and would hand their LDS-DMA copies to the CU's one
+// texture addresser in the same cycle, 16 cycles per 1-KiB copy — the last of four then sits ~48 cycles at ITS issue while its matrix
+// pipe runs dry.  Skewed by one copy time each, the four issue streams interleave for the whole copy window (until the next barrier).
+__device__ __forceinline__ void a4_stagger(uint32_t wave) {
+    asm volatile("s_bitcmp1_b32 %0, 0\n\ts_cbranch_scc0 1f\n\ts_nop 15\n1:\n\ts_bitcmp1_b32 %0, 1\n\ts_cbranch_scc0 2f\n\ts_nop 15\n\ts_nop 15\n2:"
+                 : : "s"(wave) : "scc", "memory");
+}
 __device__ __forceinline__ void a4_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
 template <int N> __device__ __forceinline__ void a4_wait_lgkm() {          // LDS reads return in order: "at most N still outstanding"
     if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
     else if constexpr (N == 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
     else static_assert(N < 0, "add the lgkmcnt literal");
 }
@@ -198,32 +204,32 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 
     // ---- one K-tile: 128 MFMA slots; every other instruction sits between two of them
     //   slot   0..63  MFMAs of k-step 0          64..127  MFMAs of k-step 1
-    //   8,16,24,32,40  counted lgkmcnt waits: B fragments 1..7 of k-step 0 were issued LAST in the previous tile and land now
-    //   9..39 (odd)    the 16 fragment reads of k-step 1 (this tile's slot)
-    //   52 / 53        lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot
-    //   54..99         the 16 LDS-DMA copies of tile t+2 into that slot, one every third MFMA (+ the M0 updates)
-    //   100 / 101      vmcnt(16) + barrier #2: tile t+1 has landed for every wave (tile t+2's copies stay in flight)
-    //   102..127       the 16 fragment reads of (t+1, k-step 0): A0..A7, B0, then B1..B7; lgkmcnt(7) closes the tile
+    //   7,15,23,31     counted lgkmcnt waits: B fragments 1..7 of k-step 0 were issued LAST in the previous tile and land now
+    //   1..31 (odd)    the 16 fragment reads of k-step 1 (this tile's slot)
+    //   40 / 41        lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot; per-wave skew of the copy streams
+    //   43..103        the 16 LDS-DMA copies of tile t+2 into that slot, one every FOURTH MFMA = 64 cycles, the time the CU's texture
+    //                  addresser needs for the four waves' copies (closer spacing only queues them up behind each other)
+    //   104 / 105      vmcnt(16) + barrier #2: tile t+1 has landed for every wave (tile t+2's copies stay in flight)
+    //   106..121       the 16 fragment reads of (t+1, k-step 0): A0..A7, B0, then B1..B7; lgkmcnt(7) closes the tile
     for (int kt = 0; kt < nk; ++kt) {
         static_for<0, 128>([&](auto ic) {
             constexpr int sl = decltype(ic)::value;
             constexpr int ks = sl >> 6, idx = sl & 63;
             a4_mfma(acc[idx >> 3][idx & 7], bfr[ks][idx >> 3], af[ks][idx & 7]);
-            if constexpr (sl == 7) a4_wait_lgkm<6>();            // before MFMA 8 (B1): after B1 only B2..B7 may be outstanding
-            if constexpr (sl == 15) a4_wait_lgkm<8>();           // B2: B3..B7 + the 3 k-step-1 reads issued so far (slots 9, 11, 13)
-            if constexpr (sl == 23) a4_wait_lgkm<11>();          // B3: B4..B7 + 7 reads
-            if constexpr (sl == 31) a4_wait_lgkm<14>();          // B4: B5..B7 + 11 reads
-            if constexpr (sl == 39) a4_wait_lgkm<15>();          // B5..B7: the 3 oldest of the 18 then outstanding (the counter saturates at 15)
-            if constexpr (sl >= 9 && sl <= 39 && (sl & 1) == 1) rd_k1(std::integral_constant<int, ((sl - 9) >> 1)>{});
-            if constexpr (sl == 52) a4_wait_lgkm<0>();
-            if constexpr (sl == 53) { a4_barrier(); a4_m0_set(m0A_cur); }
-            if constexpr (sl >= 54 && sl <= 99 && (sl - 54) % 3 == 0) dma_tile(std::integral_constant<int, ((sl - 54) / 3)>{});
-            if constexpr (sl >= 55 && sl <= 99 && (sl - 55) % 3 == 0 && (sl - 55) / 3 != 7 && (sl - 55) / 3 < 15) a4_m0_next();
-            if constexpr (sl == 76) a4_m0_set(m0B_cur);          // after the 8th A copy (slot 75), before the first B copy (slot 78)
-            if constexpr (sl == 100) a4_wait_vm<16>();
-            if constexpr (sl == 101) a4_barrier();
-            if constexpr (sl >= 102 && sl <= 118 && (sl & 1) == 0) rd_k0n(std::integral_constant<int, ((sl - 102) >> 1)>{});
-            if constexpr (sl >= 120 && sl <= 126) rd_k0n(std::integral_constant<int, (9 + sl - 120)>{});
+            if constexpr (sl == 7) a4_wait_lgkm<9>();            // before MFMA 8 (B1): B2..B7 + the 3 k-step-1 reads issued so far (slots 1, 3, 5)
+            if constexpr (sl == 15) a4_wait_lgkm<12>();          // B2: B3..B7 + 7 reads
+            if constexpr (sl == 23) a4_wait_lgkm<15>();          // B3: B4..B7 + 11 reads
+            if constexpr (sl == 31) a4_wait_lgkm<15>();          // B4..B7: the 4 oldest of the 19 then outstanding (the counter saturates at 15)
+            if constexpr (sl >= 1 && sl <= 31 && (sl & 1) == 1) rd_k1(std::integral_constant<int, (sl >> 1)>{});
+            if constexpr (sl == 40) a4_wait_lgkm<0>();
+            if constexpr (sl == 41) { a4_barrier(); a4_stagger(wave); }
+            if constexpr (sl == 42) a4_m0_set(m0A_cur);
+            if constexpr (sl >= 43 && sl <= 103 && (sl - 43) % 4 == 0) dma_tile(std::integral_constant<int, ((sl - 43) / 4)>{});
+            if constexpr (sl >= 44 && sl <= 103 && (sl - 44) % 4 == 0 && (sl - 44) / 4 != 7 && (sl - 44) / 4 < 15) a4_m0_next();
+            if constexpr (sl == 73) a4_m0_set(m0B_cur);          // after the 8th A copy (slot 71), before the first B copy (slot 75)
+            if constexpr (sl == 104) a4_wait_vm<16>();
+            if constexpr (sl == 105) a4_barrier();
+            if constexpr (sl >= 106 && sl <= 121) rd_k0n(std::integral_constant<int, (sl - 106)>{});
             if constexpr (sl == 127) a4_wait_lgkm<7>();
         });
         // flip the slots; advance the source of the next copies (the last two tiles re-fetch tile nk-1: lands in a slot nobody reads)

@@ -74,11 +74,13 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // SWIGLU: B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows, so a lane holds gate
 // and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
-template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU>
+// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only
+template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
                                                       uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc, uint16_t* __restrict__ gu,
-                                                      int64_t ldgu, int M, int N, int K, int tiles_m, int tiles_n) {
+                                                      int64_t ldgu, int M, int N, int K, int tiles_m, int tiles_n, float* __restrict__ tail_ws,
+                                                      int full_blocks, int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -86,8 +88,13 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 
     // XCD-aware bijective remap + grouped tile order (as gemm_tile_kernel.h): each XCD walks a contiguous range of tiles in groups
     // of 8 tile-rows, so co-resident tiles share their A and B panels in the XCD's L2
+    // Tail split (as launch_tile in gemm_tile_kernel.h): one 128-KiB workgroup per CU means q*CUs + r tiles cost q + 1 rounds; the last r
+    // tiles are cut into `split` K-slices ("pieces", dispatched last) that leave fp32 partial tiles in tail_ws, summed in a fixed
+    // order by gemm_a4_finish_kernel, which also runs the bias / residual / accumulate epilogue.
     const int nb = tiles_m * tiles_n;
     int bid = blockIdx.x;
+    int piece = -1;
+    if (bid >= full_blocks) { piece = bid - full_blocks; bid = full_blocks + piece / split; }
     {
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -144,7 +151,12 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / 64;
+    int nk = K / 64;
+    if (piece >= 0) {                                                // this workgroup's K-slice of a tail tile
+        const int per = (nk + split - 1) / split, kt0 = (piece % split) * per;
+        nk = min(nk - kt0, per);
+        koff = (uint32_t)kt0 * 128u;
+    }
     // fragment addresses: row = wave tile base + i*16 + (lane & 15), 16-byte chunk (s*4 + lane>>4) ^ (row & 7)
     const int frow = lane & 15, fk = lane >> 4;
     // fragment read addresses; the two LDS slots are 64 KiB apart, so "the other slot" is an XOR with 0x10000: the k-step-1 reads of
@@ -216,20 +228,21 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
             constexpr int sl = decltype(ic)::value;
             constexpr int ks = sl >> 6, idx = sl & 63;
             a4_mfma(acc[idx >> 3][idx & 7], bfr[ks][idx >> 3], af[ks][idx & 7]);
+            constexpr bool RD = DBG != 3 && DBG != 4, BAR = DBG != 2 && DBG != 4, DMA = DBG != 1 && DBG != 4;
             if constexpr (sl == 7) a4_wait_lgkm<9>();            // before MFMA 8 (B1): B2..B7 + the 3 k-step-1 reads issued so far (slots 1, 3, 5)
             if constexpr (sl == 15) a4_wait_lgkm<12>();          // B2: B3..B7 + 7 reads
             if constexpr (sl == 23) a4_wait_lgkm<15>();          // B3: B4..B7 + 11 reads
             if constexpr (sl == 31) a4_wait_lgkm<15>();          // B4..B7: the 4 oldest of the 19 then outstanding (the counter saturates at 15)
-            if constexpr (sl >= 1 && sl <= 31 && (sl & 1) == 1) rd_k1(std::integral_constant<int, (sl >> 1)>{});
+            if constexpr (RD && sl >= 1 && sl <= 31 && (sl & 1) == 1) rd_k1(std::integral_constant<int, (sl >> 1)>{});
             if constexpr (sl == 40) a4_wait_lgkm<0>();
-            if constexpr (sl == 41) { a4_barrier(); a4_stagger(wave); }
+            if constexpr (BAR && sl == 41) { a4_barrier(); a4_stagger(wave); }
             if constexpr (sl == 42) a4_m0_set(m0A_cur);
-            if constexpr (sl >= 43 && sl <= 103 && (sl - 43) % 4 == 0) dma_tile(std::integral_constant<int, ((sl - 43) / 4)>{});
+            if constexpr (DMA && sl >= 43 && sl <= 103 && (sl - 43) % 4 == 0) dma_tile(std::integral_constant<int, ((sl - 43) / 4)>{});
             if constexpr (sl >= 44 && sl <= 103 && (sl - 44) % 4 == 0 && (sl - 44) / 4 != 7 && (sl - 44) / 4 < 15) a4_m0_next();
             if constexpr (sl == 73) a4_m0_set(m0B_cur);          // after the 8th A copy (slot 71), before the first B copy (slot 75)
-            if constexpr (sl == 104) a4_wait_vm<16>();
-            if constexpr (sl == 105) a4_barrier();
-            if constexpr (sl >= 106 && sl <= 121) rd_k0n(std::integral_constant<int, (sl - 106)>{});
+            if constexpr (DMA && sl == 104) a4_wait_vm<16>();
+            if constexpr (BAR && sl == 105) a4_barrier();
+            if constexpr (RD && sl >= 106 && sl <= 121) rd_k0n(std::integral_constant<int, (sl - 106)>{});
             if constexpr (sl == 127) a4_wait_lgkm<7>();
         });
         // flip the slots; advance the source of the next copies (the last two tiles re-fetch tile nk-1: lands in a slot nobody reads)
@@ -292,6 +305,16 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
                     } else for (int r = 0; r < 8; ++r) if (n + r < N) { gp[r] = f2bf(g[r]); gp[N + r] = f2bf(u[r]); }
                 }
             }
+        } else if (piece >= 0) {                                     // K-slice of a tail tile: the raw fp32 tile, row-major [256][256]
+            const int c8 = (t & 15) * 8;
+            const int col = (c8 >> 6) * 128 + p * 64 + (c8 & 63);
+            float* wp = tail_ws + (int64_t)piece * (A4_BM * A4_BN);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 16 + (t >> 4);
+                *reinterpret_cast<float4*>(wp + row * A4_BN + col) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
+                *reinterpret_cast<float4*>(wp + row * A4_BN + col + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
+            }
         } else {
             const int c8 = (t & 15) * 8;
             const int n = n0 + (c8 >> 6) * 128 + p * 64 + (c8 & 63);
@@ -341,6 +364,53 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     }
 }
 
+// Sum the K-slices of the tail tiles (fixed order: deterministic) and run the epilogue.  grid (tail tiles, 32): a block owns 8 rows of a
+// tile, a thread 8 consecutive columns of one row.
+template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM>
+__global__ __launch_bounds__(256) void gemm_a4_finish_kernel(const float* __restrict__ ws, int split, int full_blocks, const uint16_t* __restrict__ bias,
+                                                            const uint16_t* __restrict__ res, int64_t ldr, uint16_t* __restrict__ Cb,
+                                                            float* __restrict__ Cf, int64_t ldc, int M, int N, int tiles_m, int tiles_n) {
+    const int nb = tiles_m * tiles_n;
+    int bid = full_blocks + blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = 8 * tiles_n;
+    const int group = bid / per_group, in_g = bid % per_group;
+    const int first_m = group * 8;
+    const int gsz = min(tiles_m - first_m, 8);
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int row = blockIdx.y * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 8;
+    const int m = tm * A4_BM + row, n = tn * A4_BN + col;
+    if (m >= M || n >= N) return;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < split; ++sp) {
+        const float* wp = ws + ((int64_t)blockIdx.x * split + sp) * (A4_BM * A4_BN) + row * A4_BN + col;
+        const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const bool ncols = n + 7 < N;
+    if constexpr (HAS_BIAS) {
+        for (int r = 0; r < 8; ++r) if (n + r < N) v[r] += bf2f(bias[n + r]);
+    }
+    if constexpr (HAS_RES) {
+        const uint16_t* rp = res + (int64_t)m * ldr + n;
+        for (int r = 0; r < 8; ++r) if (n + r < N) v[r] += bf2f(rp[r]);
+    }
+    if constexpr (OUT_BF16) {
+        uint16_t* cp = Cb + (int64_t)m * ldc + n;
+        if (ncols && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) *reinterpret_cast<uint4*>(cp) = pack8(v);
+        else for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+    } else {
+        float* cp = Cf + (int64_t)m * ldc + n;
+        for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = (ACCUM ? cp[r] : 0.f) + v[r];
+    }
+}
+
+extern float* g_tail_ws;          // st_gemm_set_workspace (gemm_tiles.hip)
+extern int64_t g_tail_ws_bytes;
+
 template <bool HB, bool HR, bool OB, bool AC, bool SW>
 static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
                        uint16_t* Cb, float* Cf, int64_t ldc, uint16_t* gu, int64_t ldgu, int M, int N, int K, hipStream_t s) {
@@ -352,8 +422,36 @@ static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
         configured = true;
     }
     const int tiles_m = st_cdiv(M, A4_BM), tiles_n = st_cdiv(N, SW ? A4_BN / 2 : A4_BN);
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, gu, ldgu, M, N, K, tiles_m,
-                       tiles_n);
+    const int nb = tiles_m * tiles_n;
+    int full = nb, split = 1, tail_tiles = 0;
+    if (!SW && g_tail_ws) {                                      // cost model of launch_tile (K-tile steps, fitted to kernel traces)
+        const int ncu = st_num_cus(), nkt = K / 64, r = nb % ncu;
+        const int64_t cap = g_tail_ws_bytes / ((int64_t)A4_BM * A4_BN * 4);
+        int best = 1, best_cost = nkt + 4;
+        for (int S = 2; S <= 8 && r > 0; ++S) {
+            if ((int64_t)r * S > cap || S * 4 > nkt) break;
+            const int cost = st_cdiv(r * S, ncu) * (st_cdiv(nkt, S) + 14) + 20;
+            if (cost < best_cost) { best = S; best_cost = cost; }
+        }
+        if (best > 1) { full = nb - r; split = best; tail_tiles = r; }
+    }
+    hipLaunchKernelGGL(kern, dim3(full + tail_tiles * split), dim3(256), smem, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, gu, ldgu, M, N, K, tiles_m,
+                       tiles_n, g_tail_ws, full, split);
+    if (tail_tiles)
+        hipLaunchKernelGGL((gemm_a4_finish_kernel<HB, HR, OB, AC>), dim3(tail_tiles, 32), dim3(256), 0, s, g_tail_ws, split, full, bias, res, ldr, Cb, Cf,
+                           ldc, M, N, tiles_m, tiles_n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    constexpr int smem = 256 * 528;
+    const int tiles_m = st_cdiv(M, A4_BM), tiles_n = st_cdiv(N, A4_BN);
+#define A4DBG(D) { auto kern = gemm_nt4_kernel<false, false, true, false, false, D>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, \
+                           (uint16_t*)nullptr, (int64_t)0, M, N, K, tiles_m, tiles_n, (float*)nullptr, tiles_m * tiles_n, 1); }
+    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; default: return ST_EINVAL; }
+#undef A4DBG
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

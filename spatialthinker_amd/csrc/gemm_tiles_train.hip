@@ -1,6 +1,7 @@
 // gemm_tiles_train.hip — training-shape instantiations of the tile family (st_gemm_nt / st_gemm_nt_variant).
 #include "gemm_tile_kernel.h"
 
+int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N, int K, hipStream_t s);
 int st_gemm_asm4_dispatch(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
                           uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K, hipStream_t s);
 
@@ -23,6 +24,7 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
         return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
     } while (0)
     switch (variant) {
+        case 41: case 42: case 43: case 44: return st_gemm_asm4_debug(variant - 40, A, lda, B, ldb, Cb, ldc, M, N, K, s);   // timing experiments (wrong results)
         case 40: return st_gemm_asm4_dispatch(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, accumulate, M, N, K, s);   // 4 waves x 128x128, hand-scheduled K loop (gemm_asm4.hip)
         case 0: TILE_GO(128, 128, 2, 2, 2, false);
         case 1: TILE_GO(128, 128, 2, 2, 3, false);

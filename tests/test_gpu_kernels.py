@@ -301,7 +301,7 @@ def test_gemm_tile_variants_all_pipeline_lengths(ops, variant, K):
     assert float((acc - want - 0.25).abs().max()) < scale * 1e-5 + 1e-4
 
 
-@pytest.mark.parametrize("variant", [6, 8, 23])
+@pytest.mark.parametrize("variant", [6, 8, 23, 40])
 @pytest.mark.parametrize("shape", [(4200, 4096, 4096), (3000, 5700, 3200), (70000, 300, 4096)])
 def test_gemm_tail_split_matches_unsplit(ops, variant, shape):
     """st_gemm_set_workspace: the tiles beyond whole rounds of the CUs are cut into K-slices (fp32 partials + a finish launch

@@ -74,7 +74,8 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // SWIGLU: B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows, so a lane holds gate
 // and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
-// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only
+// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only,
+// 5 = the 16 copies spread evenly over the tile (one every 8th MFMA), 6 = the same without the per-wave skew
 template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
@@ -228,14 +229,21 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
             constexpr int sl = decltype(ic)::value;
             constexpr int ks = sl >> 6, idx = sl & 63;
             a4_mfma(acc[idx >> 3][idx & 7], bfr[ks][idx >> 3], af[ks][idx & 7]);
-            constexpr bool RD = DBG != 3 && DBG != 4, BAR = DBG != 2 && DBG != 4, DMA = DBG != 1 && DBG != 4;
+            constexpr bool RD = DBG != 3 && DBG != 4, BAR = DBG != 2 && DBG != 4, DMA = DBG != 1 && DBG != 4 && DBG != 5 && DBG != 6;
+            if constexpr (DBG == 5 || DBG == 6) {
+                if constexpr (sl == 2) a4_m0_set(m0A_cur);
+                if constexpr (sl % 8 == 3) dma_tile(std::integral_constant<int, (sl / 8)>{});
+                if constexpr (sl % 8 == 4 && sl / 8 != 7 && sl / 8 < 15) a4_m0_next();
+                if constexpr (sl == 61) a4_m0_set(m0B_cur);
+                if constexpr (sl == 104) a4_wait_vm<16>();
+            }
             if constexpr (sl == 7) a4_wait_lgkm<9>();            // before MFMA 8 (B1): B2..B7 + the 3 k-step-1 reads issued so far (slots 1, 3, 5)
             if constexpr (sl == 15) a4_wait_lgkm<12>();          // B2: B3..B7 + 7 reads
             if constexpr (sl == 23) a4_wait_lgkm<15>();          // B3: B4..B7 + 11 reads
             if constexpr (sl == 31) a4_wait_lgkm<15>();          // B4..B7: the 4 oldest of the 19 then outstanding (the counter saturates at 15)
             if constexpr (RD && sl >= 1 && sl <= 31 && (sl & 1) == 1) rd_k1(std::integral_constant<int, (sl >> 1)>{});
             if constexpr (sl == 40) a4_wait_lgkm<0>();
-            if constexpr (BAR && sl == 41) { a4_barrier(); a4_stagger(wave); }
+            if constexpr (BAR && sl == 41) { a4_barrier(); if constexpr (DBG != 6) a4_stagger(wave); }
             if constexpr (sl == 42) a4_m0_set(m0A_cur);
             if constexpr (DMA && sl >= 43 && sl <= 103 && (sl - 43) % 4 == 0) dma_tile(std::integral_constant<int, ((sl - 43) / 4)>{});
             if constexpr (sl >= 44 && sl <= 103 && (sl - 44) % 4 == 0 && (sl - 44) / 4 != 7 && (sl - 44) / 4 < 15) a4_m0_next();
@@ -450,7 +458,7 @@ int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* 
 #define A4DBG(D) { auto kern = gemm_nt4_kernel<false, false, true, false, false, D>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, \
                            (uint16_t*)nullptr, (int64_t)0, M, N, K, tiles_m, tiles_n, (float*)nullptr, tiles_m * tiles_n, 1); }
-    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; default: return ST_EINVAL; }
+    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; case 5: A4DBG(5); break; case 6: A4DBG(6); break; default: return ST_EINVAL; }
 #undef A4DBG
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -67,6 +67,7 @@ template <int N> __device__ __forceinline__ void a4_wait_lgkm() {          // LD
 }
 template <int N> __device__ __forceinline__ void a4_wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
 }
@@ -75,7 +76,7 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
 // DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only,
-// 5 = the 16 copies spread evenly over the tile (one every 8th MFMA), 6 = the same without the per-wave skew
+
 template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
@@ -217,38 +218,34 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 
     // ---- one K-tile: 128 MFMA slots; every other instruction sits between two of them
     //   slot   0..63  MFMAs of k-step 0          64..127  MFMAs of k-step 1
-    //   7,15,23,31     counted lgkmcnt waits: B fragments 1..7 of k-step 0 were issued LAST in the previous tile and land now
-    //   1..31 (odd)    the 16 fragment reads of k-step 1 (this tile's slot)
-    //   40 / 41        lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot; per-wave skew of the copy streams
-    //   43..103        the 16 LDS-DMA copies of tile t+2 into that slot, one every FOURTH MFMA = 64 cycles, the time the CU's texture
-    //                  addresser needs for the four waves' copies (closer spacing only queues them up behind each other)
-    //   104 / 105      vmcnt(16) + barrier #2: tile t+1 has landed for every wave (tile t+2's copies stay in flight)
+    //   1..16          the 16 fragment reads of k-step 1 (this tile's slot), one per MFMA
+    //   7,15,23        counted lgkmcnt waits: B fragments 1..7 of k-step 0 were issued LAST in the previous tile and land now
+    //   30 / 31        lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot
+    //   33..123        the 16 LDS-DMA copies of tile t+2 into that slot, one every SIXTH MFMA: an issue costs the wave ~30-55 cycles of
+    //                  MFMA issue time (measured by elimination, tools/gemm_ksweep.py debug), the more the closer the four waves' copies
+    //                  follow each other through the CU's one texture addresser — so they are spread over the whole rest of the tile
+    //   104 / 105      vmcnt(12) + barrier #2: tile t+1 has landed for every wave (12 copies of tile t+2 issued so far stay in flight;
+    //                  the last four go out behind this barrier and are covered by the next tile's wait)
     //   106..121       the 16 fragment reads of (t+1, k-step 0): A0..A7, B0, then B1..B7; lgkmcnt(7) closes the tile
     for (int kt = 0; kt < nk; ++kt) {
         static_for<0, 128>([&](auto ic) {
             constexpr int sl = decltype(ic)::value;
             constexpr int ks = sl >> 6, idx = sl & 63;
             a4_mfma(acc[idx >> 3][idx & 7], bfr[ks][idx >> 3], af[ks][idx & 7]);
-            constexpr bool RD = DBG != 3 && DBG != 4, BAR = DBG != 2 && DBG != 4, DMA = DBG != 1 && DBG != 4 && DBG != 5 && DBG != 6;
-            if constexpr (DBG == 5 || DBG == 6) {
-                if constexpr (sl == 2) a4_m0_set(m0A_cur);
-                if constexpr (sl % 8 == 3) dma_tile(std::integral_constant<int, (sl / 8)>{});
-                if constexpr (sl % 8 == 4 && sl / 8 != 7 && sl / 8 < 15) a4_m0_next();
-                if constexpr (sl == 61) a4_m0_set(m0B_cur);
-                if constexpr (sl == 104) a4_wait_vm<16>();
+            constexpr bool RD = DBG != 3 && DBG != 4, BAR = DBG != 2 && DBG != 4, DMA = DBG != 1 && DBG != 4;
+            if constexpr (sl == 7) a4_wait_lgkm<12>();           // before MFMA 8 (B1): B2..B7 + the 6 k-step-1 reads issued so far
+            if constexpr (sl == 15) a4_wait_lgkm<15>();          // B2 (the counter saturates at 15: at least the 5 oldest of <= 20 are done)
+            if constexpr (sl == 23) a4_wait_lgkm<15>();          // B3..B7: the 6 oldest of the <= 21 then outstanding
+            if constexpr (RD && sl >= 1 && sl <= 16) rd_k1(std::integral_constant<int, (sl - 1)>{});
+            if constexpr (sl == 30) a4_wait_lgkm<0>();
+            if constexpr (BAR && sl == 31) a4_barrier();
+            if constexpr (DMA) {
+                if constexpr (sl == 32) a4_m0_set(m0A_cur);
+                if constexpr (sl >= 33 && sl <= 123 && (sl - 33) % 6 == 0) dma_tile(std::integral_constant<int, ((sl - 33) / 6)>{});
+                if constexpr (sl >= 34 && sl <= 123 && (sl - 34) % 6 == 0 && (sl - 34) / 6 != 7 && (sl - 34) / 6 < 15) a4_m0_next();
+                if constexpr (sl == 78) a4_m0_set(m0B_cur);      // after the 8th A copy (slot 75), before the first B copy (slot 81)
+                if constexpr (sl == 104) a4_wait_vm<12>();
             }
-            if constexpr (sl == 7) a4_wait_lgkm<9>();            // before MFMA 8 (B1): B2..B7 + the 3 k-step-1 reads issued so far (slots 1, 3, 5)
-            if constexpr (sl == 15) a4_wait_lgkm<12>();          // B2: B3..B7 + 7 reads
-            if constexpr (sl == 23) a4_wait_lgkm<15>();          // B3: B4..B7 + 11 reads
-            if constexpr (sl == 31) a4_wait_lgkm<15>();          // B4..B7: the 4 oldest of the 19 then outstanding (the counter saturates at 15)
-            if constexpr (RD && sl >= 1 && sl <= 31 && (sl & 1) == 1) rd_k1(std::integral_constant<int, (sl >> 1)>{});
-            if constexpr (sl == 40) a4_wait_lgkm<0>();
-            if constexpr (BAR && sl == 41) { a4_barrier(); if constexpr (DBG != 6) a4_stagger(wave); }
-            if constexpr (sl == 42) a4_m0_set(m0A_cur);
-            if constexpr (DMA && sl >= 43 && sl <= 103 && (sl - 43) % 4 == 0) dma_tile(std::integral_constant<int, ((sl - 43) / 4)>{});
-            if constexpr (sl >= 44 && sl <= 103 && (sl - 44) % 4 == 0 && (sl - 44) / 4 != 7 && (sl - 44) / 4 < 15) a4_m0_next();
-            if constexpr (sl == 73) a4_m0_set(m0B_cur);          // after the 8th A copy (slot 71), before the first B copy (slot 75)
-            if constexpr (DMA && sl == 104) a4_wait_vm<16>();
             if constexpr (BAR && sl == 105) a4_barrier();
             if constexpr (RD && sl >= 106 && sl <= 121) rd_k0n(std::integral_constant<int, (sl - 106)>{});
             if constexpr (sl == 127) a4_wait_lgkm<7>();
@@ -458,7 +455,7 @@ int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* 
 #define A4DBG(D) { auto kern = gemm_nt4_kernel<false, false, true, false, false, D>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, \
                            (uint16_t*)nullptr, (int64_t)0, M, N, K, tiles_m, tiles_n, (float*)nullptr, tiles_m * tiles_n, 1); }
-    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; case 5: A4DBG(5); break; case 6: A4DBG(6); break; default: return ST_EINVAL; }
+    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; default: return ST_EINVAL; }
 #undef A4DBG
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

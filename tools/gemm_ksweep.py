@@ -15,7 +15,7 @@ for K in (3584, 14336):
     cands = [("v23", lambda: ops.gemm_nt_variant(23, a, w, out=out)), ("v40", lambda: ops.gemm_nt_variant(40, a, w, out=out)),
              ("lib", lambda: torch.matmul(a, w.t(), out=out))]
     if len(sys.argv) > 1 and sys.argv[1] == "debug":
-        cands = [("v40", lambda: ops.gemm_nt_variant(40, a, w, out=out))] + [(f"v4{d}", (lambda d=d: ops.gemm_nt_variant(40 + d, a, w, out=out))) for d in (1, 5, 6)]
+        cands = [("v40", lambda: ops.gemm_nt_variant(40, a, w, out=out)), ("lib", lambda: torch.matmul(a, w.t(), out=out))] + [(f"v4{d}", (lambda d=d: ops.gemm_nt_variant(40 + d, a, w, out=out))) for d in (1, 2, 3)]
     for tag, fn in cands:
         for _ in range(3): fn()
         torch.cuda.synchronize()

@@ -666,8 +666,11 @@ def test_gemm_asm4_swiglu_epilogue_bit_identical(ops, M_, I, K):
         ops.gemm_select(40)
         gu, m = ops.gemm_swiglu(a, w, want_gu=True)
         gu2, m2 = ops.gemm_swiglu(a, w, want_gu=False)
+        ops.gemm_select(23)                                      # ... and the 8-wave tile's fused epilogue gives the same bits
+        gu3, m3 = ops.gemm_swiglu(a, w, want_gu=True)
+        assert torch.equal(gu3, gu_ref) and torch.equal(m3, m_ref)
     finally:
-        ops.gemm_select(23)
+        ops.gemm_select(40)
     if -(-M_ // 256) * -(-I // 128) >= 128:                      # below that the launcher keeps the 8-wave tile
         pass
     assert torch.equal(gu, gu_ref) and torch.equal(m, m_ref)

@@ -200,14 +200,15 @@ def synth_reward_strings(n, rs):
 
 # ------------------------------------------------------------------ CPU baseline (oracle, bounded sample)
 def cpu_baseline():
-    """SURVEY 8(d) CPU baseline = BASELINE.json config #1 (Qwen2.5-VL-3B shape, 2 prompts x G=4, one 224x224 image = 256 patches =
-    64 image tokens, 700 text tokens, ~512-token responses) through the build's CPU restatement of the actor path (oracle/, plain
-    PyTorch, all host cores): old-log-prob forward + ref forward + update forward/backward + AdamW + KV-cache generation.
-    BOUNDED SAMPLE (about 20 s): one update micro-batch (1 prompt x G=4 = 4 sequences of 1276 tokens) at the real 3B widths,
-    timed COMPONENT by component — one LM decoder layer, one ViT block, final norm + lm_head + log-softmax on the response rows,
-    one KV-cache decode step of one layer for the 8 concurrent rollouts, one AdamW-Kahan step on 2M parameters — fp32, plus the
-    LM layer forward in bf16; the step cost is assembled as 36 x layer + 32 x block + head (+ per-token decode x 512) and doubled
-    for the second prompt."""
+    """SURVEY 8(d) CPU baseline through the build's CPU restatement of the actor path (oracle/, plain PyTorch fp32, all host cores),
+    a BOUNDED SAMPLE of ~25 s in two legs, each timing WHOLE passes over a 4-layer model (not one layer multiplied out):
+      leg 1 = BASELINE config #1 (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image = 256 patches = 64 image tokens, 700 text
+              tokens, 512-token responses): a 4-LM-layer / 4-ViT-block model on 1 of the 8 sequences — no-grad pass (old / ref),
+              forward + backward (update), final norm + tied lm_head + log-softmax on the response rows, 16 KV-cache decode steps of
+              the 4 layers for the 8 rollouts, AdamW-Kahan on 2M parameters; scaled by layers (36 / 4, 32 / 4), sequences (8 / 1),
+              decode steps (512 / 16) and parameters to the full step;
+      leg 2 = truncated BASELINE config #3 (7B widths): a no-grad pass of 4 LM layers over one 1614-token STVQA-shaped sequence, so
+              the CPU number exists at the GPU line's own widths (reported as forward tokens/s per layer-normalised pass)."""
     from oracle import positions as OP
     from oracle import qwen25vl as Q
     from oracle import rl_math as M
@@ -219,28 +220,26 @@ def cpu_baseline():
     except Exception:
         pass
     torch.set_num_threads(threads)
-    L_LM, L_VIT, G, n_prompt, P_txt, n_img_tok, R = 36, 32, 4, 2, 700, 64, 512
-    c = Q.VLConfig(hidden_size=2048, intermediate_size=11008, num_layers=1, num_heads=16, num_kv_heads=2, vocab_size=151936, v_depth=1,
-                   tie_word_embeddings=True)
-    H, I, D, V = c.hidden_size, c.intermediate_size, c.head_dim, c.vocab_size
-    S = P_txt + n_img_tok + R
-    T = G * S
     gen = torch.Generator().manual_seed(0)
     rnd = lambda *sh: torch.randn(*sh, generator=gen) * 0.02
-    kv = c.num_kv_heads * D
-    lm = {"input_layernorm.weight": torch.ones(H), "post_attention_layernorm.weight": torch.ones(H), "self_attn.q_proj.weight": rnd(H, H),
-          "self_attn.q_proj.bias": torch.zeros(H), "self_attn.k_proj.weight": rnd(kv, H), "self_attn.k_proj.bias": torch.zeros(kv),
-          "self_attn.v_proj.weight": rnd(kv, H), "self_attn.v_proj.bias": torch.zeros(kv), "self_attn.o_proj.weight": rnd(H, H),
-          "mlp.gate_proj.weight": rnd(I, H), "mlp.up_proj.weight": rnd(I, H), "mlp.down_proj.weight": rnd(H, I)}
-    p = {"model.language_model.layers.0." + k: v for k, v in lm.items()}
-    vh, vi = c.v_hidden, c.v_intermediate
-    vit = {"norm1.weight": torch.ones(vh), "norm2.weight": torch.ones(vh), "attn.qkv.weight": rnd(3 * vh, vh), "attn.qkv.bias": torch.zeros(3 * vh),
-           "attn.proj.weight": rnd(vh, vh), "attn.proj.bias": torch.zeros(vh), "mlp.gate_proj.weight": rnd(vi, vh), "mlp.gate_proj.bias": torch.zeros(vi),
-           "mlp.up_proj.weight": rnd(vi, vh), "mlp.up_proj.bias": torch.zeros(vi), "mlp.down_proj.weight": rnd(vh, vi), "mlp.down_proj.bias": torch.zeros(vh)}
-    p.update({"model.visual.blocks.0." + k: v for k, v in vit.items()})
-    n = V * H                                                # the 311M-entry tied table: a cheap ramp (timing does not depend on the values)
-    p["model.language_model.embed_tokens.weight"] = torch.arange(n, dtype=torch.float32).remainder_(997.0).mul_(4e-5).sub_(0.02).view(V, H)
-    p["model.language_model.norm.weight"] = torch.ones(H)
+
+    def lm_params(c, L, with_head):
+        H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
+        kv = c.num_kv_heads * D
+        p = {}
+        for i in range(L):
+            b = f"model.language_model.layers.{i}."
+            p.update({b + "input_layernorm.weight": torch.ones(H), b + "post_attention_layernorm.weight": torch.ones(H),
+                      b + "self_attn.q_proj.weight": rnd(H, H), b + "self_attn.q_proj.bias": torch.zeros(H),
+                      b + "self_attn.k_proj.weight": rnd(kv, H), b + "self_attn.k_proj.bias": torch.zeros(kv),
+                      b + "self_attn.v_proj.weight": rnd(kv, H), b + "self_attn.v_proj.bias": torch.zeros(kv),
+                      b + "self_attn.o_proj.weight": rnd(H, H), b + "mlp.gate_proj.weight": rnd(I, H), b + "mlp.up_proj.weight": rnd(I, H),
+                      b + "mlp.down_proj.weight": rnd(H, I)})
+        if with_head:
+            n = c.vocab_size * H                            # a cheap ramp for the big table (timing does not depend on the values)
+            p["model.language_model.embed_tokens.weight"] = torch.arange(n, dtype=torch.float32).remainder_(997.0).mul_(4e-5).sub_(0.02).view(c.vocab_size, H)
+            p["model.language_model.norm.weight"] = torch.ones(H)
+        return p
 
     def timed(fn, reps=1):
         best = 1e30
@@ -248,65 +247,92 @@ def cpu_baseline():
             t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
         return best
 
-    def grad_on(prefix, on):
-        for k, v in p.items():
-            if k.startswith(prefix):
-                v.requires_grad_(on); v.grad = None
-
-    # ---- LM decoder layer on the packed micro-batch (4 sequences x 1276 tokens)
-    pos = torch.arange(S).repeat(G)[None, :].repeat(3, 1)
+    # ---------------------------------------------------------------- leg 1: config #1 (3B widths)
+    L_LM, L_VIT, G, n_prompt, P_txt, n_img_tok, R = 36, 32, 4, 2, 700, 64, 512
+    LS, NSEQ = 4, 1                                          # layers and sequences of the timed sample
+    c = Q.VLConfig(hidden_size=2048, intermediate_size=11008, num_layers=LS, num_heads=16, num_kv_heads=2, vocab_size=151936, v_depth=LS,
+                   tie_word_embeddings=True)
+    H, D, V = c.hidden_size, c.head_dim, c.vocab_size
+    p = lm_params(c, LS, with_head=True)
+    vh, vi = c.v_hidden, c.v_intermediate
+    for i in range(LS):
+        b = f"model.visual.blocks.{i}."
+        p.update({b + "norm1.weight": torch.ones(vh), b + "norm2.weight": torch.ones(vh), b + "attn.qkv.weight": rnd(3 * vh, vh),
+                  b + "attn.qkv.bias": torch.zeros(3 * vh), b + "attn.proj.weight": rnd(vh, vh), b + "attn.proj.bias": torch.zeros(vh),
+                  b + "mlp.gate_proj.weight": rnd(vi, vh), b + "mlp.gate_proj.bias": torch.zeros(vi), b + "mlp.up_proj.weight": rnd(vi, vh),
+                  b + "mlp.up_proj.bias": torch.zeros(vi), b + "mlp.down_proj.weight": rnd(vh, vi), b + "mlp.down_proj.bias": torch.zeros(vh)})
+    S = P_txt + n_img_tok + R
+    T = NSEQ * S
+    pos = torch.arange(S).repeat(NSEQ)[None, :].repeat(3, 1)
     cos, sin = Q.mrope_cos_sin(pos, D, c.rope_theta, c.mrope_section)
-    cu = [i * S for i in range(G + 1)]
+    cu = [i * S for i in range(NSEQ + 1)]
     x = torch.randn(T, H, generator=gen) * 0.1
+
+    def lm_pass(xx):
+        for i in range(LS):
+            xx = Q.lm_layer(p, c, i, xx, cos, sin, cu)
+        return xx
+    lm_names = [k for k in p if k.startswith("model.language_model.layers.")]
+
+    def grad_on(names, on):
+        for k in names:
+            p[k].requires_grad_(on); p[k].grad = None
+
     with torch.no_grad():
-        Q.lm_layer(p, c, 0, x[:S], cos[:S], sin[:S], [0, S])                         # warm-up: thread pool, allocator
-        t_layer_f = timed(lambda: Q.lm_layer(p, c, 0, x, cos, sin, cu), 2)
-        p16 = {k: v.bfloat16() for k, v in p.items() if k.startswith("model.language_model.layers.0.")}
-        x16, c16, s16 = x.bfloat16(), cos.bfloat16(), sin.bfloat16()
-        t_layer_f_bf16 = timed(lambda: Q.lm_layer(p16, c, 0, x16, c16, s16, cu), 1)
-        del p16
-    grad_on("model.language_model.layers.0.", True)
+        Q.lm_layer(p, c, 0, x[:S], cos[:S], sin[:S], [0, S])                          # warm-up: thread pool, allocator
+        t_lm_f = timed(lambda: lm_pass(x))
+    grad_on(lm_names, True)
     xg = x.clone().requires_grad_(True)
-    t_layer_fb = timed(lambda: Q.lm_layer(p, c, 0, xg, cos, sin, cu).sum().backward())
-    grad_on("model.language_model.layers.0.", False)
-    # ---- ViT block on the micro-batch's ONE 16x16-patch image per sequence (the reference runs the tower per sequence: G copies)
-    grid = np.asarray([[1, 16, 16]] * G)
+    t_lm_fb = timed(lambda: lm_pass(xg).sum().backward())
+    grad_on(lm_names, False)
+    # ViT: the reference runs the tower per sequence (one 16x16-patch image each)
+    grid = np.asarray([[1, 16, 16]] * NSEQ)
     _, cu_win = OP.vision_window_index(grid, merge_size=2, window_size=112, patch_size=14)
-    N = 256 * G
+    N = 256 * NSEQ
     xv = torch.randn(N, vh, generator=gen) * 0.1
     ang = torch.randn(N, 1, c.v_head_dim, generator=gen)
+
+    def vit_pass(xx):
+        for i in range(LS):
+            xx = Q.vit_block(p, c, i, xx, ang.cos(), ang.sin(), cu_win)
+        return xx
+    vit_names = [k for k in p if k.startswith("model.visual.blocks.")]
     with torch.no_grad():
-        t_vit_f = timed(lambda: Q.vit_block(p, c, 0, xv, ang.cos(), ang.sin(), cu_win), 2)
-    grad_on("model.visual.blocks.0.", True)
+        t_vit_f = timed(lambda: vit_pass(xv))
+    grad_on(vit_names, True)
     xvg = xv.clone().requires_grad_(True)
-    t_vit_fb = timed(lambda: Q.vit_block(p, c, 0, xvg, ang.cos(), ang.sin(), cu_win).sum().backward())
-    grad_on("model.visual.blocks.0.", False)
-    # ---- final norm + tied lm_head + log-softmax on the response rows (dp_actor.py:126-153)
-    rows = G * R
+    t_vit_fb = timed(lambda: vit_pass(xvg).sum().backward())
+    grad_on(vit_names, False)
+    # final norm + tied lm_head + log-softmax on the response rows (dp_actor.py:126-153)
+    rows = NSEQ * R
     xr = torch.randn(rows, H, generator=gen) * 0.1
     lab = torch.randint(0, V, (rows,), generator=gen)
     head_fn = lambda xx: torch.log_softmax(Q.lm_head(p, c, xx), -1).gather(-1, lab[:, None]).sum()
     with torch.no_grad():
         t_head_f = timed(lambda: head_fn(xr))
-    p["model.language_model.embed_tokens.weight"].requires_grad_(True)
+    emb = p["model.language_model.embed_tokens.weight"]
+    emb.requires_grad_(True)
     xrg = xr.clone().requires_grad_(True)
     t_head_fb = timed(lambda: head_fn(xrg).backward())
-    p["model.language_model.embed_tokens.weight"].requires_grad_(False); p["model.language_model.embed_tokens.weight"].grad = None
-    # ---- generation: KV-cache decode, all 8 rollouts of the step in one batch, 32 tokens timed at a ~1000-token context
-    Bd, ctx, n_dec = n_prompt * G, P_txt + n_img_tok + R // 2, 32
-    kc, vc = torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen), torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen)
+    emb.requires_grad_(False); emb.grad = None
+    # generation: KV-cache decode of the 4 layers, all 8 rollouts of the step in one batch, 16 tokens at a ~1000-token context
+    Bd, ctx, n_dec = n_prompt * G, P_txt + n_img_tok + R // 2, 16
+    kc = [torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen) for _ in range(LS)]
+    vc = [torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen) for _ in range(LS)]
     xd = torch.randn(Bd, H, generator=gen) * 0.1
-    lens = torch.full((Bd,), ctx)
     cd, sd = Q.mrope_cos_sin(torch.full((3, Bd), ctx), D, c.rope_theta, c.mrope_section)
 
     def dec():
-        ln = lens.clone()
+        ln = torch.full((Bd,), ctx)
         for _ in range(n_dec):
-            Q.lm_layer_decode(p, c, 0, xd, cd, sd, kc, vc, ln); ln += 1
+            h = xd
+            for i in range(LS):
+                h = Q.lm_layer_decode(p, c, i, h, cd, sd, kc[i], vc[i], ln)
+            ln = ln + 1
     with torch.no_grad():
-        t_dec_layer = timed(dec) / n_dec
-        t_dec_head = timed(lambda: Q.lm_head(p, c, xd).argmax(-1), 2)
-    # ---- AdamW (AnyPrecisionAdamW with bf16 states + Kahan, the oracle's numpy restatement) on 2M parameters
+        t_dec = timed(dec) / n_dec                           # per decode step of 4 layers
+        t_dec_head = timed(lambda: Q.lm_head(p, c, xd).argmax(-1))
+    # AdamW (AnyPrecisionAdamW with bf16 states + Kahan, the oracle's numpy restatement) on 2M parameters
     n_par = 1 << 21
     rs = np.random.RandomState(0)
     opt = M.AdamWKahanBF16(scalar_mode="cpu")
@@ -314,25 +340,46 @@ def cpu_baseline():
     pa = opt.step(pa, ga)
     t_adam = timed(lambda: opt.step(pa, ga))
     n_params_3b = 3.75e9
-    # ---- assemble one GRPO step of config #1: 8 samples = 2 micro-batches of the timed size
-    fwd = n_prompt * (L_LM * t_layer_f + L_VIT * t_vit_f + t_head_f)                 # one no-grad pass over the 8 sequences
-    fb = n_prompt * (L_LM * t_layer_fb + L_VIT * t_vit_fb + t_head_fb)
+    seq_scale, lm_scale, vit_scale = (n_prompt * G) / NSEQ, L_LM / LS, L_VIT / LS
+    fwd = seq_scale * (lm_scale * t_lm_f + vit_scale * t_vit_f + t_head_f)             # one no-grad pass over the 8 sequences
+    fb = seq_scale * (lm_scale * t_lm_fb + vit_scale * t_vit_fb + t_head_fb)
     prefill = fwd * (P_txt + n_img_tok) / S
-    gen_s = prefill + R * (L_LM * t_dec_layer + t_dec_head)
+    gen_s = prefill + R * (lm_scale * t_dec + t_dec_head)
     adam_s = t_adam * n_params_3b / n_par
     step_s = gen_s + 2 * fwd + fb + adam_s
+    del p, kc, vc, emb
+    # ---------------------------------------------------------------- leg 2: truncated config #3 (7B widths)
+    c7 = Q.VLConfig(num_layers=LS, v_depth=0)
+    p7 = lm_params(c7, LS, with_head=False)
+    S7 = 1614
+    pos7 = torch.arange(S7)[None, :].repeat(3, 1)
+    cos7, sin7 = Q.mrope_cos_sin(pos7, c7.head_dim, c7.rope_theta, c7.mrope_section)
+    x7 = torch.randn(S7, c7.hidden_size, generator=gen) * 0.1
+
+    def lm7(xx):
+        for i in range(LS):
+            xx = Q.lm_layer(p7, c7, i, xx, cos7, sin7, [0, S7])
+        return xx
+    with torch.no_grad():
+        t7 = timed(lambda: lm7(x7))
+    del p7
+    fwd7_per_sample = t7 * 28 / LS                            # the 28 LM layers of one 1614-token sample (ViT + head excluded)
     return {"value": n_prompt * G / step_s, "unit": "samples/s (full GRPO step: gen + old + ref + update + AdamW)", "cores": threads, "kind": "port",
-            "sample": "config #1 shape (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image -> 256 patches / 64 image tokens, 700 text tokens, "
-                      "512-token responses), fp32 torch oracle: ONE micro-batch of 4 sequences (5104 tokens) timed per component — 1 LM layer "
-                      "fwd / fwd+bwd, 1 ViT block, final norm + tied lm_head + log-softmax on 2048 response rows, 32 KV-cache decode steps of 1 "
-                      "layer for the 8 rollouts, AdamW-Kahan on 2M parameters — assembled as 36 layers + 32 blocks + head per pass (x2 prompts), "
-                      "512 decode steps, 3.75B parameters",
+            "sample": f"leg 1 = config #1 shape (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image -> 64 image tokens, 700 text tokens, 512-token "
+                      f"responses), fp32 torch oracle, whole passes over a {LS}-LM-layer / {LS}-ViT-block model on {NSEQ} of the 8 sequences ({T} tokens): "
+                      f"no-grad pass, forward+backward, final norm + tied lm_head + log-softmax on {rows} response rows, {n_dec} KV-cache decode steps "
+                      f"of the {LS} layers for the 8 rollouts, AdamW-Kahan on 2M parameters; scaled by layers ({L_LM}/{LS}, {L_VIT}/{LS}), sequences "
+                      f"(8/{NSEQ}), 512 decode steps, 3.75B parameters.  leg 2 = truncated config #3: no-grad pass of {LS} LM layers at 7B widths over "
+                      f"one {S7}-token sequence",
             "timing_s": {"gen": gen_s, "old": fwd, "ref": fwd, "update_actor": fb, "adamw": adam_s},
-            "components_s": {"lm_layer_fwd": t_layer_f, "lm_layer_fwd_bwd": t_layer_fb, "lm_layer_fwd_bf16": t_layer_f_bf16, "vit_block_fwd": t_vit_f,
-                             "vit_block_fwd_bwd": t_vit_fb, "head_fwd": t_head_f, "head_fwd_bwd": t_head_fb, "decode_layer_step": t_dec_layer,
-                             "decode_head_step": t_dec_head, "adamw_2M_params": t_adam},
-            "bf16_over_fp32_layer_fwd_time": t_layer_f_bf16 / t_layer_f,
-            "value_excl_generation_and_adamw": n_prompt * G / (2 * fwd + fb)}
+            "measured_s": {"lm_4_layers_fwd": t_lm_f, "lm_4_layers_fwd_bwd": t_lm_fb, "vit_4_blocks_fwd": t_vit_f, "vit_4_blocks_fwd_bwd": t_vit_fb,
+                           "head_fwd": t_head_f, "head_fwd_bwd": t_head_fb, "decode_step_4_layers": t_dec, "decode_head_step": t_dec_head,
+                           "adamw_2M_params": t_adam, "cfg3_7b_widths_4_layers_fwd_1614_tokens": t7},
+            "value_excl_generation_and_adamw": n_prompt * G / (2 * fwd + fb),
+            "config3_truncated": {"widths": "Qwen2.5-VL-7B", "forward_s_per_sample_28_lm_layers": fwd7_per_sample,
+                                  "forward_samples_per_s": 1.0 / fwd7_per_sample,
+                                  "note": "LM layers of ONE no-grad pass over one STVQA-shaped sample; a GRPO sample costs ~5 such forwards (old + ref + 3x update) "
+                                          "plus generation"}}
 
 
 # ------------------------------------------------------------------ main

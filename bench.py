@@ -32,6 +32,16 @@ PEAK_FP8 = 5.0e15           # dense MFMA fp8 (block-scaled K=128 instructions), 
 PEAK_HBM = 8.0e12
 
 
+def gemm_source_sha() -> str:
+    """sha256 (16 hex digits) of the GEMM kernel sources: ties a committed PMC traffic figure to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm_asm4.hip", "gemm_tile_kernel.h", "gemm.hip", "gemm_tiles_train.hip", "gemm_tiles_swiglu.hip", "gemm_tiles_layout.hip"):
+        with open(os.path.join(ROOT, "spatialthinker_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -538,6 +548,7 @@ def main():
     for k in classes:
         ops.prof_enable(k, max(4096, 6000 * a.steps if k == ops.K_GEMM else 1500 * a.steps), PROF_STRIDE if k != ops.K_ADAMW else 1)
     gen.stats = {k: 0 for k in gen.stats}
+    ops.gemm_bytes.update(on=True, bytes=0.0, launches=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -571,25 +582,43 @@ def main():
             return {"bound": bound, "kernel": names, "achieved": ach / scale if ach else None, "peak": peak / scale, "unit": unit,
                     "frac": ach / peak if ach else None, "launches_timed": n_launch, "launches_seen": seen,
                     "avg_launch_ms": ms / max(n_launch, 1)}
+        dec_traffic = None
         main_roof = roof(ops.K_GEMM)
-        # HBM traffic of the dominant kernel from the committed PMC pass over this same workload (profiles/r02_gemm_traffic.json:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)
-        tp = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        main_roof["algorithmic_bytes_per_launch"] = ops.gemm_bytes["bytes"] / max(1, ops.gemm_bytes["launches"])
+        main_roof["algorithmic_bytes"] = "operands once + result once (+ residual / fp32 read-modify-write), averaged over the class's launches"
+        # HBM traffic per launch of the GEMM class: a PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
+        # doubled per the gfx950 note of MI355X_MICROARCH.md) over THIS command (`bench.py --steps 1`, tools/bench_traffic.sh) is kept
+        # under profiles/; it is quoted only while the kernel sources it was taken on are the ones being run (sha of the GEMM sources),
+        # otherwise the field is null — a measured number must not outlive the kernel it measured
+        tp = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
         main_roof["traffic"] = None
         if os.path.exists(tp) and a.model == "7b":
             tj = json.load(open(tp))
-            main_roof["traffic"] = tj.get("hbm_bytes_per_launch")
-            main_roof["traffic_source"] = "profiles/r02_gemm_traffic.json"
-            main_roof["traffic_over_algorithmic_operand_bytes"] = tj.get("traffic_over_algorithmic")
+            if tj.get("kernel_source_sha16") == gemm_source_sha():
+                main_roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                main_roof["traffic_source"] = "profiles/r03_gemm_traffic.json (PMC pass over bench.py --steps 1, time-weighted over the top GEMM instantiations)"
+                main_roof["traffic_over_algorithmic_operand_bytes"] = tj.get("traffic_over_algorithmic")
+                if dec_traffic is None:
+                    dec_traffic = tj.get("decode_hbm_bytes_per_iteration")
+            else:
+                main_roof["traffic_stale"] = "profiles/r03_gemm_traffic.json was measured on other kernel sources"
         st = gen.stats
         dec = None
         if st["decode_s"] > 0:
+            # at ~340 rows the iteration sits AT the ridge of the roofline (2 flop per weight byte and row = ~340 flop/B vs 312 flop/B):
+            # both bounds are reported, `frac` is the larger of the two fractions (the bound that is closer to binding)
             bw = st["decode_bytes"] / st["decode_s"]
-            dec = {"bound": "hbm", "kernel": "decode iteration (hipGraph replay: gemm_tile_kernel<M<=256> x4 + attn_fwd128_kernel<false> + merge + fused "
-                                             "finishes per layer, lm_head, sampler)", "achieved": bw / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                   "frac": bw / PEAK_HBM, "traffic": None, "iterations": st["decode_steps"], "ms_per_iteration": st["decode_s"] / st["decode_steps"] * 1e3,
+            tf = st.get("decode_flops", 0.0) / st["decode_s"]
+            dec = {"bound": "hbm" if bw / PEAK_HBM >= tf / PEAK_BF16 else "mfma",
+                   "kernel": "decode iteration (hipGraph replay: decode GEMM tiles x4 + attn_fwd128_kernel<false> + merge + fused finishes per layer, "
+                             "lm_head, sampler + decode_step_kernel)",
+                   "achieved": bw / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": max(bw / PEAK_HBM, tf / PEAK_BF16),
+                   "hbm": {"achieved_GBps": bw / 1e9, "peak_GBps": PEAK_HBM / 1e9, "frac": bw / PEAK_HBM},
+                   "mfma": {"achieved_TFLOPs": tf / 1e12, "peak_TFLOPs": PEAK_BF16 / 1e12, "frac": tf / PEAK_BF16},
+                   "traffic": dec_traffic, "iterations": st["decode_steps"], "ms_per_iteration": st["decode_s"] / st["decode_steps"] * 1e3,
                    "mean_rows_per_iteration": st["decode_row_steps"] / st["decode_steps"],
-                   "algorithmic_bytes": "every LM weight once per iteration + K/V of the live context (prompt K/V once per prompt)"}
+                   "algorithmic_bytes": "every LM weight once per iteration + K/V of the live context (prompt K/V once per prompt)",
+                   "algorithmic_flops": "2 flop per LM weight and row + 4*D flop per (query head, cached key)"}
         out = {
             "metric": "GRPO samples/sec (G=8 rollouts/prompt) Qwen2.5-VL-7B at 1/2/4/8 MI355X",
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,

@@ -216,6 +216,16 @@ def autotune_decode_gemm(M: int, weights, reps: int = 2):
 
 
 _gemm_ws = {}
+# algorithmic HBM bytes (operands once + result once) and launches of the training-shape GEMM entries while counting is on
+# (bench.py: the denominator of roofline.traffic_over_algorithmic)
+gemm_bytes = {"on": False, "bytes": 0.0, "launches": 0}
+
+
+def _count_gemm(M, N, K, out_bytes_per_elem, extra=0.0):
+    if gemm_bytes["on"]:
+        gemm_bytes["bytes"] += 2.0 * (M * K + N * K) + out_bytes_per_elem * M * N + extra
+        gemm_bytes["launches"] += 1
+
 
 
 def _gemm_workspace(device, nbytes: int = 128 << 20):
@@ -261,6 +271,7 @@ def gemm_nt(a, b, *, bias=None, residual=None, out=None, out_f32=None, accumulat
         return out
     c = out if out_f32 is None else out_f32
     _gemm_workspace(a.device)
+    _count_gemm(M, N, K, 2 if out_f32 is None else (8 if accumulate else 4), (2.0 * M * N if residual is not None else 0.0))
     lib().st_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), _p(residual),
                      residual.stride(0) if residual is not None else 0, _p(out) if out_f32 is None else None,
                      _p(out_f32), c.stride(0), int(accumulate), M, N, K, _s())
@@ -286,6 +297,7 @@ def gemm_tn(a_km, b_kn, out_f32, accumulate=False):
     N = b_kn.shape[1]
     assert b_kn.shape[0] == K and out_f32.shape == (M, N), (a_km.shape, b_kn.shape, out_f32.shape)
     _gemm_workspace(a_km.device)
+    _count_gemm(M, N, K, 8 if accumulate else 4)
     lib().st_gemm_tn(_p(a_km), a_km.stride(0), _p(b_kn), b_kn.stride(0), _p(out_f32), out_f32.stride(0), int(accumulate), M, N, K, _s())
     return out_f32
 
@@ -348,6 +360,7 @@ def gemm_swiglu(a, gate_up_w, want_gu=True):
     I = gate_up_w.shape[0] // 2
     m = torch.empty(M, I, dtype=BF16, device=a.device)
     gu = torch.empty(M, 2 * I, dtype=BF16, device=a.device) if want_gu else None
+    _count_gemm(M, 2 * I, K, 0, 2.0 * M * I * (3 if want_gu else 1))
     lib().st_gemm_swiglu(_p(a), a.stride(0), _p(gate_up_w), gate_up_w.stride(0), _p(gu), gu.stride(0) if gu is not None else 0,
                          _p(m), m.stride(0), M, I, K, _s())
     return gu, m

@@ -39,7 +39,7 @@ class Generator:
         # decode-loop accounting for the HBM roofline of the rollout (bench.py `roofline_decode`): seconds inside the replayed
         # decode iterations (device events), iterations, and the ALGORITHMIC bytes one iteration must read — every LM weight once
         # + the K/V of the live context (prompt K/V once per prompt and kv-head group, generated K/V per row)
-        self.stats = {"decode_s": 0.0, "decode_steps": 0, "decode_bytes": 0.0, "decode_row_steps": 0, "prefill_s": 0.0, "phases": 0}
+        self.stats = {"decode_s": 0.0, "decode_steps": 0, "decode_bytes": 0.0, "decode_row_steps": 0, "decode_flops": 0.0, "prefill_s": 0.0, "phases": 0}
         self._timers: list = []
         self.tap = None                   # test hook, see iteration(); needs use_graph=False
 
@@ -301,7 +301,11 @@ class Generator:
                 kv_row = 2 * width * 2 * L                                   # K and V bytes of one cached position over all layers
                 prompt_ctx = float(sum(int(pe[p_] - pb[p_]) for p_ in pids))
                 gen_ctx = float(len0.item() + gen_len.sum().item()) / 2.0    # mean generated context per iteration, summed over the rows
-                self._timers.append((ev0, ev1, steps, steps * (w_bytes + (prompt_ctx + gen_ctx) * kv_row), steps * Ba))
+                # algorithmic flops of the iterations: every live-or-not row of the phase runs the projections + lm_head (2 flop per weight)
+                # and attends to its prompt + generated context (4 * D flop per (query head, key))
+                row_ctx = float(sum(int(pe[p_] - pb[p_]) * int(c_) for p_, c_ in zip(pids, cnt))) + gen_ctx
+                flops = steps * (Ba * w_bytes + 4.0 * D * nq * L * row_ctx)
+                self._timers.append((ev0, ev1, steps, steps * (w_bytes + (prompt_ctx + gen_ctx) * kv_row), steps * Ba, flops))
             out[S_l] = out_l
             gen_len_g[S_l] = gen_len
             pos_g[:, S_l] = pos
@@ -336,11 +340,12 @@ class Generator:
         torch.cuda.synchronize()
         self.stats["prefill_s"] += ev_p0.elapsed_time(ev_p1) * 1e-3
         self.stats["phases"] += len(self._timers)
-        for ev0, ev1, steps, nbytes, rows in self._timers:
+        for ev0, ev1, steps, nbytes, rows, flops in self._timers:
             self.stats["decode_s"] += ev0.elapsed_time(ev1) * 1e-3
             self.stats["decode_steps"] += steps
             self.stats["decode_bytes"] += nbytes
             self.stats["decode_row_steps"] += rows
+            self.stats["decode_flops"] = self.stats.get("decode_flops", 0.0) + flops
         self._timers = []
         del kg, vg, logits_g
         from .actor import release_cached_blocks

@@ -67,9 +67,9 @@ def test_32_rows_at_the_2048_token_cap_run_in_budgeted_passes_with_bounded_memor
         tok = int(am[a:b, -2048:].sum()) + 1102 * len({r // 8 for r in range(a, b)})
         assert (b - a) % 4 == 0 and (tok <= 24576 or b - a == 4), (a, b, tok)
     measured("token_budget_7bwidth_peak_gb_above_weights", peak)
-    # a pass keeps ~17.5k packed tokens of one LM layer (~1.9 GB) + 16k x 152064 logits (~5 GB) + transients; the unbudgeted 32-row pass
-    # would need 4x that (20 GB of logits alone)
-    assert peak < 14.0, peak
+    # a pass keeps <= 24.5k packed tokens of one LM layer (~2.6 GB) + <= 24k x 152064 logits (~7.5 GB) + transients: measured 15.0 GB; the
+    # unbudgeted 32-row pass would need ~3x that (20 GB of logits alone)
+    assert peak < 18.0, peak
     g_budget = grads[0]
     del eng
     torch.cuda.empty_cache()

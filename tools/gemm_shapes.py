@@ -1,5 +1,7 @@
-"""All twelve GEMM shapes of one 7B LM layer (forward, dX, dW) at the micro-batch token counts of the bench: the dispatched
-st_gemm_nt vs the two tile kernels (variant 0 = 128x128, 4 = 256x256) vs hipBLASLt (torch.matmul)."""
+"""All twelve GEMMs of one 7B LM layer (forward, dX, dW) through the entry points the engine uses (st_gemm_nt with its fused
+epilogues, st_gemm_swiglu, st_gemm_tn) at the packed-token count of a fused update pass: production tile (variant 40) vs the 8-wave
+tile (variant 23) vs hipBLASLt (torch.matmul, plain product).  TF/s count the matmul flops only.
+    python tools/gemm_shapes.py [T ...]      default T = 21504"""
 import os
 import sys
 import torch
@@ -7,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialthinker_amd import ops  # noqa: E402
 
 
-def bench(fn, iters=8):
+def bench(fn, iters=6):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -19,28 +21,36 @@ def bench(fn, iters=8):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-H, QKV, I2, I = 3584, 4608, 37888, 18944
-for T in [int(a) for a in sys.argv[1:]] or [6528, 8704]:
-    shapes = [("qkv", T, QKV, H), ("o", T, H, H), ("gateup", T, I2, H), ("down", T, H, I),
-              ("dx_qkv", T, H, QKV), ("dx_o", T, H, H), ("dx_gu", T, H, I2), ("dx_down", T, I, H),
-              ("dw_qkv", QKV, H, T), ("dw_o", H, H, T), ("dw_gu", I2, H, T), ("dw_down", H, I, T)]
-    tot = {"disp": 0.0, "v0": 0.0, "v4": 0.0, "blas": 0.0}
-    for name, M, N, K in shapes:
-        a = torch.randn(M, K, device="cuda").bfloat16(); b = torch.randn(N, K, device="cuda").bfloat16()
-        dw = name.startswith("dw")
-        c = torch.empty(M, N, device="cuda", dtype=torch.float32 if dw else torch.bfloat16)
-        if dw:
-            td = bench(lambda: ops.gemm_nt(a, b, out_f32=c, accumulate=True))
-            t0 = bench(lambda: ops.gemm_nt_variant(0, a, b, out_f32=c, accumulate=True))
-            t4 = bench(lambda: ops.gemm_nt_variant(4, a, b, out_f32=c, accumulate=True))
-        else:
-            td = bench(lambda: ops.gemm_nt(a, b, out=c))
-            t0 = bench(lambda: ops.gemm_nt_variant(0, a, b, out=c))
-            t4 = bench(lambda: ops.gemm_nt_variant(4, a, b, out=c))
-        tb = bench(lambda: torch.matmul(a, b.t()))
-        f = 2.0 * M * N * K / 1e12
-        for k_, t in (("disp", td), ("v0", t0), ("v4", t4), ("blas", tb)):
-            tot[k_] += t
-        print(f"T={T} {name:8s} {M:6d}x{N:6d}x{K:6d}: dispatched {f / td:6.0f}  v0 {f / t0:6.0f}  v4 {f / t4:6.0f}  hipblaslt {f / tb:6.0f} TF   ({td * 1e6:7.0f} us)", flush=True)
-        del a, b, c
-    print(f"T={T} layer total: dispatched {tot['disp'] * 1e3:.2f} ms, v0 {tot['v0'] * 1e3:.2f}, v4 {tot['v4'] * 1e3:.2f}, hipblaslt {tot['blas'] * 1e3:.2f}")
+H, QKV, I = 3584, 4608, 18944
+ops._gemm_workspace(torch.device("cuda"))
+rb = lambda *s: (torch.randn(*s, device="cuda") * 0.1).bfloat16()
+for T in [int(a) for a in sys.argv[1:]] or [21504]:
+    x, bias = rb(T, H), rb(QKV)
+    res = rb(T, H)
+    w = {"qkv": rb(QKV, H), "o": rb(H, H), "gu": rb(2 * I, H), "down": rb(H, I)}
+    wT = {k: ops.transpose(v) for k, v in w.items()}
+    m = rb(T, I)
+    dy = {"qkv": rb(T, QKV), "o": rb(T, H), "gu": rb(T, 2 * I), "down": rb(T, H)}
+    gw = {k: torch.zeros(v.shape, dtype=torch.float32, device="cuda") for k, v in w.items()}
+    cases = [("qkv+bias", 2.0 * T * QKV * H, lambda: ops.gemm_nt(x, w["qkv"], bias=bias), lambda: torch.matmul(x, w["qkv"].t())),
+             ("o+res", 2.0 * T * H * H, lambda: ops.gemm_nt(x, w["o"], residual=res), lambda: torch.matmul(x, w["o"].t())),
+             ("gateup+swiglu", 2.0 * T * 2 * I * H, lambda: ops.gemm_swiglu(x, w["gu"], want_gu=True), lambda: torch.matmul(x, w["gu"].t())),
+             ("down+res", 2.0 * T * H * I, lambda: ops.gemm_nt(m, w["down"], residual=res), lambda: torch.matmul(m, w["down"].t())),
+             ("dx_qkv", 2.0 * T * H * QKV, lambda: ops.gemm_nt(dy["qkv"], wT["qkv"]), lambda: torch.matmul(dy["qkv"], w["qkv"])),
+             ("dx_o", 2.0 * T * H * H, lambda: ops.gemm_nt(dy["o"], wT["o"]), lambda: torch.matmul(dy["o"], w["o"])),
+             ("dx_gu", 2.0 * T * H * 2 * I, lambda: ops.gemm_nt(dy["gu"], wT["gu"]), lambda: torch.matmul(dy["gu"], w["gu"])),
+             ("dx_down", 2.0 * T * I * H, lambda: ops.gemm_nt(dy["down"], wT["down"]), lambda: torch.matmul(dy["down"], w["down"])),
+             ("dw_qkv", 2.0 * T * QKV * H, lambda: ops.gemm_tn(dy["qkv"], x, gw["qkv"], accumulate=True), lambda: torch.matmul(dy["qkv"].t(), x)),
+             ("dw_o", 2.0 * T * H * H, lambda: ops.gemm_tn(dy["o"], x, gw["o"], accumulate=True), lambda: torch.matmul(dy["o"].t(), x)),
+             ("dw_gu", 2.0 * T * 2 * I * H, lambda: ops.gemm_tn(dy["gu"], x, gw["gu"], accumulate=True), lambda: torch.matmul(dy["gu"].t(), x)),
+             ("dw_down", 2.0 * T * H * I, lambda: ops.gemm_tn(dy["down"], m, gw["down"], accumulate=True), lambda: torch.matmul(dy["down"].t(), m))]
+    tot = {"v40": 0.0, "v23": 0.0, "lib": 0.0}
+    for name, fl, ours, lib_ in cases:
+        ops.gemm_select(40); t40 = bench(ours)
+        ops.gemm_select(23); t23 = bench(ours)
+        ops.gemm_select(40)
+        tl = bench(lib_)
+        tot["v40"] += t40; tot["v23"] += t23; tot["lib"] += tl
+        print(f"T={T} {name:14s}: v40 {fl / t40 / 1e12:6.0f}  v23 {fl / t23 / 1e12:6.0f}  hipblaslt {fl / tl / 1e12:6.0f} TF/s   ({t40 * 1e6:7.0f} us)", flush=True)
+    fl_all = sum(c[1] for c in cases)
+    print(f"T={T} layer total: v40 {tot['v40'] * 1e3:.2f} ms ({fl_all / tot['v40'] / 1e12:.0f} TF/s), v23 {tot['v23'] * 1e3:.2f} ms, hipblaslt (plain products) {tot['lib'] * 1e3:.2f} ms")

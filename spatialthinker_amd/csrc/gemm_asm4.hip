@@ -75,7 +75,7 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // SWIGLU: B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows, so a lane holds gate
 // and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
-// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only,
+// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only, 5 = no epilogue, 6 = epilogue without the global stores,
 
 template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 
     // ---- epilogue through LDS: 2 passes of 256 rows x 128 columns of fp32 (rows padded to 528 bytes: conflict-free b128 writes)
     constexpr int ROWB = 128 * 4 + 16;
+    if constexpr (DBG == 5) { if (M > 0) return; }                   // timing: no epilogue at all
     __syncthreads();                                                 // every wave is done with the operand slots; no DMA in flight
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rr[r];
                 }
+                if constexpr (DBG == 6) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])); if (M > 0) continue; }
                 if constexpr (OUT_BF16) {
                     uint16_t* cp = Cb + (int64_t)m * ldc + n;
                     if (ncols && (reinterpret_cast<uintptr_t>(cp) & 15) == 0) *reinterpret_cast<uint4*>(cp) = pack8(v);
@@ -455,7 +457,7 @@ int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* 
 #define A4DBG(D) { auto kern = gemm_nt4_kernel<false, false, true, false, false, D>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, \
                            (uint16_t*)nullptr, (int64_t)0, M, N, K, tiles_m, tiles_n, (float*)nullptr, tiles_m * tiles_n, 1); }
-    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; default: return ST_EINVAL; }
+    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; case 5: A4DBG(5); break; case 6: A4DBG(6); break; default: return ST_EINVAL; }
 #undef A4DBG
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

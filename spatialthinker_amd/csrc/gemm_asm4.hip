@@ -265,6 +265,16 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
 
     // ---- epilogue through LDS: 2 passes of 256 rows x 128 columns of fp32 (rows padded to 528 bytes: conflict-free b128 writes)
     constexpr int ROWB = 128 * 4 + 16;
+    bool interior;                                                   // uniform: no edge handling, vector accesses everywhere
+    if constexpr (SWIGLU) {
+        interior = m0 + A4_BM <= M && n0 + A4_BN / 2 <= N && (N & 7) == 0 && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 &&
+                   (gu == nullptr || ((ldgu & 7) == 0 && (reinterpret_cast<uintptr_t>(gu) & 15) == 0));
+    } else {
+        interior = m0 + A4_BM <= M && n0 + A4_BN <= N && (ldc & (OUT_BF16 ? 7 : 3)) == 0 &&
+                   (reinterpret_cast<uintptr_t>(OUT_BF16 ? (const void*)Cb : (const void*)Cf) & 15) == 0 &&
+                   (!HAS_BIAS || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
+                   (!HAS_RES || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
+    }
     if constexpr (DBG == 5) { if (M > 0) return; }                   // timing: no epilogue at all
     __syncthreads();                                                 // every wave is done with the operand slots; no DMA in flight
 #pragma unroll
@@ -285,7 +295,39 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
             const int wn_ = c8 >> 5, q = (c8 >> 4) & 1, h = c8 & 8;
             const int lcol = wn_ * 64 + q * 32 + h;                  // gate columns at lcol .. lcol+7, up at +16
             const int n = n0 + wn_ * 64 + p * 32 + q * 16 + h;      // output column
-#pragma unroll 2
+            if (interior) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4 q4[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (h * 4 + i) * 32 + (t >> 3);
+                        q4[i][0] = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4);
+                        q4[i][1] = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4 + 16);
+                        q4[i][2] = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 16) * 4);
+                        q4[i][3] = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 16) * 4 + 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = (h * 4 + i) * 32 + (t >> 3), m = m0 + row;
+                        float g[8] = {q4[i][0].x, q4[i][0].y, q4[i][0].z, q4[i][0].w, q4[i][1].x, q4[i][1].y, q4[i][1].z, q4[i][1].w};
+                        float u[8] = {q4[i][2].x, q4[i][2].y, q4[i][2].z, q4[i][2].w, q4[i][3].x, q4[i][3].y, q4[i][3].z, q4[i][3].w};
+                        float o[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            g[r] = bfround(g[r]); u[r] = bfround(u[r]);
+                            o[r] = bfround(g[r] * sigmoidf_(g[r])) * u[r];
+                        }
+                        *reinterpret_cast<uint4*>(Cb + (int64_t)m * ldc + n) = pack8(o);
+                        if (gu) {
+                            uint16_t* gp = gu + (int64_t)m * ldgu + n;
+                            *reinterpret_cast<uint4*>(gp) = pack8(g);
+                            *reinterpret_cast<uint4*>(gp + N) = pack8(u);
+                        }
+                    }
+                }
+            } else
+#pragma unroll 1
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 32 + (t >> 3), m = m0 + row;
                 if (m >= M || n >= N) continue;
@@ -321,6 +363,55 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
                 *reinterpret_cast<float4*>(wp + row * A4_BN + col) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
                 *reinterpret_cast<float4*>(wp + row * A4_BN + col + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
             }
+        } else if (interior) {
+            // whole tile inside the matrix, every pointer 16-byte aligned (the production case): straight-line code, two batches of 8
+            // rows — 16 LDS reads (and 8 residual loads) in flight, then the stores back to back.  The generic path below pays a
+            // branch and a serialised LDS round trip per row (measured: 10 us of an 87-us tile, tools/epilogue_cost.py).
+            const int c8 = (t & 15) * 8;
+            const int n = n0 + (c8 >> 6) * 128 + p * 64 + (c8 & 63);
+            float bvals[8];
+            if constexpr (HAS_BIAS) unpack8(*reinterpret_cast<const uint4*>(bias + n), bvals);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 lo[8], hi[8];
+                uint4 rr[8];
+                float4 c0[8], c1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = (h * 8 + i) * 16 + (t >> 4);
+                    lo[i] = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
+                    hi[i] = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
+                    if constexpr (HAS_RES) rr[i] = *reinterpret_cast<const uint4*>(res + (int64_t)(m0 + row) * ldr + n);
+                    if constexpr (!OUT_BF16 && ACCUM) {
+                        c0[i] = *reinterpret_cast<const float4*>(Cf + (int64_t)(m0 + row) * ldc + n);
+                        c1[i] = *reinterpret_cast<const float4*>(Cf + (int64_t)(m0 + row) * ldc + n + 4);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = (h * 8 + i) * 16 + (t >> 4);
+                    float v[8] = {lo[i].x, lo[i].y, lo[i].z, lo[i].w, hi[i].x, hi[i].y, hi[i].z, hi[i].w};
+                    if constexpr (HAS_BIAS) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += bvals[r];
+                    }
+                    if constexpr (HAS_RES) {
+                        float r8[8];
+                        unpack8(rr[i], r8);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += r8[r];
+                    }
+                    if constexpr (DBG == 6) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])); if (M > 0) continue; }
+                    if constexpr (OUT_BF16) {
+                        *reinterpret_cast<uint4*>(Cb + (int64_t)(m0 + row) * ldc + n) = pack8(v);
+                    } else {
+                        float* cp = Cf + (int64_t)(m0 + row) * ldc + n;
+                        float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                        if constexpr (ACCUM) { o0.x += c0[i].x; o0.y += c0[i].y; o0.z += c0[i].z; o0.w += c0[i].w; o1.x += c1[i].x; o1.y += c1[i].y; o1.z += c1[i].z; o1.w += c1[i].w; }
+                        *reinterpret_cast<float4*>(cp) = o0; *reinterpret_cast<float4*>(cp + 4) = o1;
+                    }
+                }
+            }
         } else {
             const int c8 = (t & 15) * 8;
             const int n = n0 + (c8 >> 6) * 128 + p * 64 + (c8 & 63);
@@ -330,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
                 if (ncols && (reinterpret_cast<uintptr_t>(bias + n) & 15) == 0) unpack8(*reinterpret_cast<const uint4*>(bias + n), bvals);
                 else for (int r = 0; r < 8; ++r) bvals[r] = n + r < N ? bf2f(bias[n + r]) : 0.f;
             }
-#pragma unroll
+#pragma unroll 1
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 16 + (t >> 4), m = m0 + row;
                 if (m >= M || n >= N) continue;

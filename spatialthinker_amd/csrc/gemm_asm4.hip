@@ -75,7 +75,7 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // SWIGLU: B = [gate rows | up rows] (2N x K); the B tile interleaves 16 gate rows with the 16 matching up rows, so a lane holds gate
 // and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
-// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only, 5 = no epilogue, 6 = epilogue without the global stores,
+// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only, 5 = no epilogue, 6 = epilogue without the global stores, 7 = the real kernel + a per-workgroup time trace in the workspace,
 
 template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    uint64_t t_start = 0;
+    if constexpr (DBG == 7) t_start = __builtin_amdgcn_s_memrealtime();   // timing trace: [start, epilogue start, end, hw id] per workgroup in tail_ws
 
     // XCD-aware bijective remap + grouped tile order (as gemm_tile_kernel.h): each XCD walks a contiguous range of tiles in groups
     // of 8 tile-rows, so co-resident tiles share their A and B panels in the XCD's L2
@@ -275,7 +277,9 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
                    (!HAS_BIAS || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                    (!HAS_RES || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
     }
-    if constexpr (DBG == 5) { if (M > 0) return; }                   // timing: no epilogue at all
+    if constexpr (DBG == 5) { if (M > 0) return; }
+    uint64_t t_epi = 0;
+    if constexpr (DBG == 7) t_epi = __builtin_amdgcn_s_memrealtime();                   // timing: no epilogue at all
     __syncthreads();                                                 // every wave is done with the operand slots; no DMA in flight
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -460,6 +464,14 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         }
         if (p == 0) __syncthreads();                             // the second pass overwrites the image
     }
+    if constexpr (DBG == 7) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the stores have been accepted by L2
+        const uint64_t t_end = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            uint64_t* tr = reinterpret_cast<uint64_t*>(tail_ws) + (int64_t)blockIdx.x * 4;
+            tr[0] = t_start; tr[1] = t_epi; tr[2] = t_end; tr[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+        }
+    }
 }
 
 // Sum the K-slices of the tail tiles (fixed order: deterministic) and run the epilogue.  grid (tail tiles, 32): a block owns 8 rows of a
@@ -547,8 +559,8 @@ int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* 
     const int tiles_m = st_cdiv(M, A4_BM), tiles_n = st_cdiv(N, A4_BN);
 #define A4DBG(D) { auto kern = gemm_nt4_kernel<false, false, true, false, false, D>; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, A, lda, B, ldb, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (int64_t)0, Cb, (float*)nullptr, ldc, \
-                           (uint16_t*)nullptr, (int64_t)0, M, N, K, tiles_m, tiles_n, (float*)nullptr, tiles_m * tiles_n, 1); }
-    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; case 5: A4DBG(5); break; case 6: A4DBG(6); break; default: return ST_EINVAL; }
+                           (uint16_t*)nullptr, (int64_t)0, M, N, K, tiles_m, tiles_n, D == 7 ? g_tail_ws : (float*)nullptr, tiles_m * tiles_n, 1); }
+    switch (dbg) { case 1: A4DBG(1); break; case 2: A4DBG(2); break; case 3: A4DBG(3); break; case 4: A4DBG(4); break; case 5: A4DBG(5); break; case 6: A4DBG(6); break; case 7: if (!g_tail_ws || g_tail_ws_bytes < (int64_t)tiles_m * tiles_n * 32) return ST_EINVAL; A4DBG(7); break; default: return ST_EINVAL; }
 #undef A4DBG
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

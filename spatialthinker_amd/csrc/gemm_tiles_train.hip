@@ -24,7 +24,7 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
         return launch_tile<BM, BN, WM, WN, ST, false, false, false, false, MB, LE, PPV>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, M, N, K, s);                     \
     } while (0)
     switch (variant) {
-        case 41: case 42: case 43: case 44: case 45: case 46: return st_gemm_asm4_debug(variant - 40, A, lda, B, ldb, Cb, ldc, M, N, K, s);   // timing experiments (wrong results)
+        case 41: case 42: case 43: case 44: case 45: case 46: case 47: return st_gemm_asm4_debug(variant - 40, A, lda, B, ldb, Cb, ldc, M, N, K, s);   // timing experiments (wrong results)
         case 40: return st_gemm_asm4_dispatch(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, accumulate, M, N, K, s);   // 4 waves x 128x128, hand-scheduled K loop (gemm_asm4.hip)
         case 0: TILE_GO(128, 128, 2, 2, 2, false);
         case 1: TILE_GO(128, 128, 2, 2, 3, false);

@@ -36,11 +36,11 @@ __global__ __launch_bounds__(256) void k(uint8_t* base, int tiles, int stride) {
                 *reinterpret_cast<uint4*>(tile + row * PITCH + (t & 31) * 16) = v;
             }
         } else if constexpr (MODE == 3) {                                // same bytes, contiguous 128 KiB (fresh every time)
-            uint8_t* lin = base + (int64_t)id * 131072;
+            uint8_t* lin = base + (int64_t)(id % 16384) * 131072;
 #pragma unroll
             for (int i = 0; i < 32; ++i) *reinterpret_cast<uint4*>(lin + i * 4096 + t * 16) = v;
         } else if constexpr (MODE == 4) {                                // pitch 4096 (one page per row... rows 4 KiB apart): 256 x 512 B
-            uint8_t* lin = base + (int64_t)id * (256 * 4096);
+            uint8_t* lin = base + (int64_t)(id % 2048) * (256 * 4096);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int row = i * 8 + (t >> 5);

@@ -31,7 +31,7 @@ template <int D> struct AttnCfg {
     static constexpr int V_BYTES = DP * VT_PITCH;
 };
 
-__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return f2bf2(a, b); }
 
 // Stage one K tile (natural) and one V tile (transposed) into LDS.  256 threads.
 template <int D>

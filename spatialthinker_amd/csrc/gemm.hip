@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const uint16_t* __restr
                 uint16_t* cp = Cb + (int64_t)m * ldc + n;
                 if (full && ((ldc & 3) == 0)) {
                     uint2 o;
-                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    o.x = f2bf2(v[0], v[1]);
+                    o.y = f2bf2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(cp) = o;
                 } else {
 #pragma unroll
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const uint16_t* __rest
             uint16_t* cp = C + (int64_t)m * ldc + n;
             if (n + 3 < N && (ldc & 3) == 0) {
                 uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                o.x = f2bf2(v[0], v[1]);
+                o.y = f2bf2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(cp) = o;
             } else {
 #pragma unroll

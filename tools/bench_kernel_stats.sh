@@ -1,7 +1,11 @@
+# rocprofv3 --kernel-trace --stats over the default bench command; the summary lands in gpurun_out/<tag>_bench_kernel_stats.csv
+#   bash tools/bench_kernel_stats.sh <tag>        (from the repo root on the GPU box; the program sits directly after `--`)
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r02n -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_prof_n.json 2> /tmp/prof_n.err
-ls /tmp/prof_r02n | head
-cp /tmp/prof_r02n/x_kernel_stats.csv gpurun_out/r02_bench_kernel_stats_n.csv
-tail -c 400 gpurun_out/r02_bench_prof_n.json
+rm -rf /tmp/prof_$tag
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_prof.json 2> /tmp/prof_$tag.err
+ls /tmp/prof_$tag | head
+cp /tmp/prof_$tag/x_kernel_stats.csv gpurun_out/${tag}_bench_kernel_stats.csv
+tail -c 300 gpurun_out/${tag}_bench_prof.json

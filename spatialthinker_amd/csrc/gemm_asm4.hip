@@ -45,6 +45,14 @@ template <int OFF> __device__ __forceinline__ void a4_read(bf16x8& f, uint32_t a
 __device__ __forceinline__ void a4_dma(uint32_t voff, i32x4 srd, uint32_t soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
+// K-major operand fragment: 4 consecutive k of one m per lane (gfx950 LDS transpose read), two of them make an MFMA operand
+template <int OFF> __device__ __forceinline__ void a4_read_tr(s16x4_t& f, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void a4_dma0(uint32_t voff, i32x4 srd) {        // the K-tile offset sits in the resource's base address
+    asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(srd) : "memory");
+}
+__device__ __forceinline__ void a4_flip(uint32_t& addr) { asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(addr)); }
 __device__ __forceinline__ void a4_m0_set(uint32_t v) { asm volatile("s_mov_b32 m0, %0" : : "s"(v) : "memory"); }
 __device__ __forceinline__ void a4_m0_next() { asm volatile("s_add_u32 m0, m0, 0x400" : : : "memory", "scc"); }
 __device__ __forceinline__ void a4_barrier() { asm volatile("s_barrier" : : : "memory"); }
@@ -67,6 +75,8 @@ template <int N> __device__ __forceinline__ void a4_wait_lgkm() {          // LD
 }
 template <int N> __device__ __forceinline__ void a4_wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
@@ -77,7 +87,7 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
 // DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only, 5 = no epilogue, 6 = epilogue without the global stores, 7 = the real kernel + a per-workgroup time trace in the workspace,
 
-template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0>
+template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0, bool AS = false, bool BS = false>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
                                                       uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc, uint16_t* __restrict__ gu,
@@ -112,7 +122,10 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     const int n0 = SWIGLU ? tn * (A4_BN / 2) : tn * A4_BN;           // SWIGLU: first OUTPUT column (N = output width I)
 
     // ---- buffer resources: base = first row of the tile, num_records cuts the rows beyond the matrix (they load as zero)
-    const uint64_t a_base = (uint64_t)(A + (int64_t)m0 * lda);
+    static_assert(!(AS || BS) || (!SWIGLU && !HAS_BIAS && !HAS_RES), "contraction-major operands: plain bf16 or fp32 (+=) results");
+    // AS / BS: the operand is stored CONTRACTION-MAJOR (A[k][m], lda = pitch of a k-row): dX = dY W reads W that way (BS), dW = dY^T X
+    // both operands (AS + BS).  Its K-tile is staged as [64 k-rows][256 m] (512-byte rows) and read with the LDS transpose read.
+    uint64_t a_base = AS ? (uint64_t)(A + m0) : (uint64_t)(A + (int64_t)m0 * lda);
     const int rows_a = min(A4_BM, M - m0);
     i32x4 srdA, srdB, srdB2;
     srdA.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a_base);
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     srdA.z = (int)0xffffffffu;                                       // rows are clamped per lane: nothing to cut off
     srdA.w = 0x00020000;
     const int cols_b = SWIGLU ? min(A4_BN / 2, N - n0) : min(A4_BN, N - n0);        // B rows (= output columns) this tile owns
-    const uint64_t b_base = (uint64_t)(B + (int64_t)n0 * ldb);
+    uint64_t b_base = BS ? (uint64_t)(B + n0) : (uint64_t)(B + (int64_t)n0 * ldb);
     srdB.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b_base);
     srdB.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b_base >> 32) & 0xffffu));
     srdB.z = (int)0xffffffffu;
@@ -138,11 +151,22 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     static_for<0, 8>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int rl = lane >> 3, ch = ((lane & 7) ^ rl) << 4;
-        const int ra = min(wave * 64 + j * 8 + rl, rows_a - 1);
-        voffA[j] = (uint32_t)ra * (uint32_t)(lda * 2) + ch;
-        const int r = wave * 64 + j * 8 + rl;                        // tile row (SWIGLU: tile rows alternate 16 gate / 16 up rows)
-        const int src = min(SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r, cols_b - 1);
-        voffB[j] = (uint32_t)src * (uint32_t)(ldb * 2) + ch;
+        // contraction-major image: copy j of this wave = k-rows kr = wave*16 + 2j + (lane >> 5); the 32-byte chunk c (16 m) of k-row kr
+        // sits at chunk position c ^ g(kr) (gemm_tile_kernel.h, AS / BS): lane piece sl covers m = ((sl >> 1) ^ g) * 16 + (sl & 1) * 8 ..+7;
+        // columns past the matrix edge are clamped (they compute values that are never stored)
+        const int kr = wave * 16 + j * 2 + (lane >> 5), sl = lane & 31, g = (kr & 3) | (((kr >> 3) & 1) << 2);
+        const int lc = (((sl >> 1) ^ g) << 4) + (sl & 1) * 8;
+        if constexpr (AS) voffA[j] = (uint32_t)kr * (uint32_t)(lda * 2) + (uint32_t)min(lc, rows_a - 8) * 2u;
+        else {
+            const int ra = min(wave * 64 + j * 8 + rl, rows_a - 1);
+            voffA[j] = (uint32_t)ra * (uint32_t)(lda * 2) + ch;
+        }
+        if constexpr (BS) voffB[j] = (uint32_t)kr * (uint32_t)(ldb * 2) + (uint32_t)min(lc, cols_b - 8) * 2u;
+        else {
+            const int r = wave * 64 + j * 8 + rl;                    // tile row (SWIGLU: tile rows alternate 16 gate / 16 up rows)
+            const int src = min(SWIGLU ? ((r >> 5) * 16 + (r & 15)) : r, cols_b - 1);
+            voffB[j] = (uint32_t)src * (uint32_t)(ldb * 2) + ch;
+        }
     });
     uint32_t koff = 0;                                               // byte offset of the K-tile the next copies fetch (SGPR)
     const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
@@ -160,7 +184,23 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         const int per = (nk + split - 1) / split, kt0 = (piece % split) * per;
         nk = min(nk - kt0, per);
         koff = (uint32_t)kt0 * 128u;
+        if constexpr (AS) a_base += (uint64_t)kt0 * 64u * (uint64_t)lda * 2u;
+        if constexpr (BS) b_base += (uint64_t)kt0 * 64u * (uint64_t)ldb * 2u;
     }
+    // contraction-major operands advance their resource's BASE by 64 k-rows per K-tile (the 32-bit offsets could not span a
+    // [tokens][vocabulary] operand); row-major ones keep the base and move the SGPR offset by 128 bytes
+    const uint64_t stepA = (uint64_t)lda * 128u, stepB = (uint64_t)ldb * 128u;
+    auto set_base = [&](i32x4& srd, uint64_t base) {
+        srd.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        srd.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((base >> 32) & 0xffffu));
+    };
+    if constexpr (AS) set_base(srdA, a_base);
+    if constexpr (BS) set_base(srdB, b_base);
+    auto advance = [&](bool go) {                                    // the K-tile the NEXT copies fetch
+        koff += go ? 128u : 0u;
+        if constexpr (AS) { a_base += go ? stepA : 0; set_base(srdA, a_base); }
+        if constexpr (BS) { b_base += go ? stepB : 0; set_base(srdB, b_base); }
+    };
     // fragment addresses: row = wave tile base + i*16 + (lane & 15), 16-byte chunk (s*4 + lane>>4) ^ (row & 7)
     const int frow = lane & 15, fk = lane >> 4;
     // fragment read addresses; the two LDS slots are 64 KiB apart, so "the other slot" is an XOR with 0x10000: the k-step-1 reads of
@@ -174,10 +214,30 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         adB_k0n = smem32 + A4_SLOT + A4_ABYTES + (wn * 128 + frow) * 128 + (kc0 << 4);
     }
     bf16x8 af[2][8], bfr[2][8];
+    // contraction-major fragments: m = chunk*16 + (lane & 15) with chunk = 8*w + i, k = (lane >> 4)*8 + 0..7 as two transpose reads
+    // (k-rows +0..3 and +4..7 = 2048 bytes further).  Chunk c of k-row r sits at position c ^ g(r); for the rows a lane addresses
+    // g = tr_g, so fragment i needs its own per-lane address (i ^ tr_g) << 5: 8 registers per operand, pointing at the slot of the
+    // tile whose k-step 1 is read next; they flip ONCE per tile, between the k-step-1 reads (tile t) and the k-step-0 reads (t+1).
+    uint32_t trA[8], trB[8];
+    union Frag { bf16x8 v; s16x4_t h[2]; };
+    if constexpr (AS || BS) {
+        const int tr_g = ((lane >> 2) & 3) | (((lane >> 4) & 1) << 2);
+        const int tr_row = (lane >> 4) * 8 + ((lane & 15) >> 2);
+        static_for<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            trA[i] = smem32 + tr_row * 512 + wm * 256 + ((i ^ tr_g) << 5) + (lane & 3) * 8;
+            trB[i] = smem32 + A4_ABYTES + tr_row * 512 + wn * 256 + ((i ^ tr_g) << 5) + (lane & 3) * 8;
+        });
+    }
+    auto rd_tr = [&](bf16x8& f, uint32_t addr, auto s2c, auto hc) {  // half h of the fragment of k-step s2
+        constexpr int s2 = decltype(s2c)::value, h = decltype(hc)::value;
+        a4_read_tr<s2 * 16384 + h * 2048>(reinterpret_cast<Frag&>(f).h[h], addr);
+    };
 
     auto dma_tile = [&](auto jc) {                                   // copy j of the NEXT issue (voff already points at its K-tile)
         constexpr int j = decltype(jc)::value;
-        if constexpr (j < 8) a4_dma(voffA[j], srdA, koff);
+        if constexpr (j < 8) { if constexpr (AS) a4_dma0(voffA[j], srdA); else a4_dma(voffA[j], srdA, koff); }
+        else if constexpr (BS) a4_dma0(voffB[j - 8], srdB);
         else if (SWIGLU && (((wave * 64 + (j - 8) * 8) >> 4) & 1)) a4_dma(voffB[j - 8], srdB2, koff);
         else a4_dma(voffB[j - 8], srdB, koff);
     };
@@ -192,6 +252,21 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         if constexpr (i < 8) a4_read<i * 2048>(af[0][i], adA_k0n);
         else a4_read<(i - 8) * 2048>(bfr[0][i - 8], adB_k0n);
     };
+    // contraction-major kernels: read number r of a k-step, A first (AS: 16 transpose reads, else 8 ds_read_b128), then B
+    constexpr int NRA = AS ? 16 : 8, NRB = BS ? 16 : 8, NRD = NRA + NRB;
+    auto rd_km = [&](auto r_c, auto s2c) {
+        constexpr int r = decltype(r_c)::value, s2 = decltype(s2c)::value;
+        if constexpr (r < NRA) {
+            if constexpr (AS) rd_tr(af[s2][r >> 1], trA[r >> 1], s2c, std::integral_constant<int, (r & 1)>{});
+            else if constexpr (s2 == 1) a4_read<r * 2048>(af[1][r], adA_k1);
+            else a4_read<r * 2048>(af[0][r], adA_k0n);
+        } else {
+            constexpr int q = r - NRA;
+            if constexpr (BS) rd_tr(bfr[s2][q >> 1], trB[q >> 1], s2c, std::integral_constant<int, (q & 1)>{});
+            else if constexpr (s2 == 1) a4_read<q * 2048>(bfr[1][q], adB_k1);
+            else a4_read<q * 2048>(bfr[0][q], adB_k0n);
+        }
+    };
     uint32_t m0A_cur = m0A, m0B_cur = m0B;                           // LDS-DMA destination of the tile being refilled (slot of tile t)
 
     // ---- prologue: tiles 0 and 1 in flight, fragments of (0, k-step 0) in registers
@@ -201,22 +276,27 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         dma_tile(jc);
         a4_m0_next();
     });
-    if (nk > 1) koff += 128;
+    advance(nk > 1);
     a4_m0_set(m0A + A4_SLOT);
     static_for<0, 16>([&](auto jc) {                                 // (nk == 1: tile 0 once more — keeps the loop's counted waits uniform)
         if constexpr (decltype(jc)::value == 8) a4_m0_set(m0B + A4_SLOT);
         dma_tile(jc);
         a4_m0_next();
     });
-    if (nk > 2) koff += 128;
+    advance(nk > 2);
     a4_wait_vm<16>();
     a4_barrier();
-    {                                                                // (0, k-step 0) sits in slot 0 = "the other slot" of the flipped addresses
+    if constexpr (AS || BS) {                                        // (0, k-step 0) from slot 0: where the transpose-read addresses point
+        adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
+        static_for<0, NRD>([&](auto rc) { rd_km(rc, std::integral_constant<int, 0>{}); });
+        adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
+        a4_wait_lgkm<0>();
+    } else {                                                         // (0, k-step 0) sits in slot 0 = "the other slot" of the flipped addresses
         adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
         static_for<0, 16>([&](auto ic) { rd_k0n(ic); });
         adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
+        a4_wait_lgkm<7>();
     }
-    a4_wait_lgkm<7>();
 
     // ---- one K-tile: 128 MFMA slots; every other instruction sits between two of them
     //   slot   0..63  MFMAs of k-step 0          64..127  MFMAs of k-step 1
@@ -229,7 +309,39 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
     //   104 / 105      vmcnt(12) + barrier #2: tile t+1 has landed for every wave (12 copies of tile t+2 issued so far stay in flight;
     //                  the last four go out behind this barrier and are covered by the next tile's wait)
     //   106..121       the 16 fragment reads of (t+1, k-step 0): A0..A7, B0, then B1..B7; lgkmcnt(7) closes the tile
+    // Contraction-major kernels (NRD = 24 or 32 reads per k-step, one per MFMA slot):
+    //   1..NRD               reads of (t, k-step 1)
+    //   NRD+1..NRD+16        the transpose-read addresses flip to the other slot (one v_xor per slot)
+    //   NRD+14 / NRD+15      lgkmcnt(0) + barrier #1
+    //   NRD+17 ..            the 16 copies of tile t+2, one every 4th (NRD = 32) / 5th (24) MFMA
+    //   114-NRD / 115-NRD    vmcnt (the copies issued so far stay in flight) + barrier #2
+    //   116-NRD..115         reads of (t+1, k-step 0); lgkmcnt(0) at 126
+    constexpr int KM_DMA0 = NRD + 17, KM_STRIDE = NRD == 32 ? 4 : 5, KM_VM = 114 - NRD, KM_RD0 = 116 - NRD;
+    constexpr int KM_INFLIGHT = (KM_VM - KM_DMA0 + KM_STRIDE - 1) / KM_STRIDE;      // copies of tile t+2 issued before the vmcnt wait
+    static_assert(!(AS || BS) || (KM_INFLIGHT == (NRD == 32 ? 9 : 10) && KM_DMA0 + 15 * KM_STRIDE < 127), "contraction-major schedule");
     for (int kt = 0; kt < nk; ++kt) {
+        if constexpr (AS || BS) {
+            static_for<0, 128>([&](auto ic) {
+                constexpr int sl = decltype(ic)::value;
+                constexpr int ks = sl >> 6, idx = sl & 63;
+                a4_mfma(acc[idx >> 3][idx & 7], bfr[ks][idx >> 3], af[ks][idx & 7]);
+                if constexpr (sl >= 1 && sl <= NRD) rd_km(std::integral_constant<int, (sl - 1)>{}, std::integral_constant<int, 1>{});
+                if constexpr (sl > NRD && sl <= NRD + 16) {
+                    constexpr int x = sl - NRD - 1;
+                    if constexpr (x < 8) { if constexpr (AS) a4_flip(trA[x]); } else { if constexpr (BS) a4_flip(trB[x - 8]); }
+                }
+                if constexpr (sl == NRD + 14) a4_wait_lgkm<0>();
+                if constexpr (sl == NRD + 15) a4_barrier();
+                if constexpr (sl == KM_DMA0 - 1) a4_m0_set(m0A_cur);
+                if constexpr (sl >= KM_DMA0 && sl <= KM_DMA0 + 15 * KM_STRIDE && (sl - KM_DMA0) % KM_STRIDE == 0) dma_tile(std::integral_constant<int, ((sl - KM_DMA0) / KM_STRIDE)>{});
+                if constexpr (sl > KM_DMA0 && sl <= KM_DMA0 + 15 * KM_STRIDE && (sl - KM_DMA0 - 1) % KM_STRIDE == 0 && (sl - KM_DMA0 - 1) / KM_STRIDE != 7 && (sl - KM_DMA0 - 1) / KM_STRIDE < 15) a4_m0_next();
+                if constexpr (sl == KM_DMA0 + 7 * KM_STRIDE + 2) a4_m0_set(m0B_cur);     // after the 8th A copy, before the first B copy
+                if constexpr (sl == KM_VM) a4_wait_vm<KM_INFLIGHT>();
+                if constexpr (sl == KM_VM + 1) a4_barrier();
+                if constexpr (sl >= KM_RD0 && sl < KM_RD0 + NRD) rd_km(std::integral_constant<int, (sl - KM_RD0)>{}, std::integral_constant<int, 0>{});
+                if constexpr (sl == 126) a4_wait_lgkm<0>();
+            });
+        } else
         static_for<0, 128>([&](auto ic) {
             constexpr int sl = decltype(ic)::value;
             constexpr int ks = sl >> 6, idx = sl & 63;
@@ -255,7 +367,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         // flip the slots; advance the source of the next copies (the last two tiles re-fetch tile nk-1: lands in a slot nobody reads)
         adA_k1 ^= A4_SLOT; adB_k1 ^= A4_SLOT; adA_k0n ^= A4_SLOT; adB_k0n ^= A4_SLOT;
         m0A_cur ^= A4_SLOT; m0B_cur ^= A4_SLOT;
-        koff += (kt + 3 < nk) ? 128u : 0u;
+        advance(kt + 3 < nk);
     }
     a4_wait_vm<0>();                                                 // the two re-fetched tiles are still landing
     a4_wait_lgkm<0>();
@@ -521,11 +633,11 @@ __global__ __launch_bounds__(256) void gemm_a4_finish_kernel(const float* __rest
 extern float* g_tail_ws;          // st_gemm_set_workspace (gemm_tiles.hip)
 extern int64_t g_tail_ws_bytes;
 
-template <bool HB, bool HR, bool OB, bool AC, bool SW>
+template <bool HB, bool HR, bool OB, bool AC, bool SW, bool AS = false, bool BS = false>
 static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
                        uint16_t* Cb, float* Cf, int64_t ldc, uint16_t* gu, int64_t ldgu, int M, int N, int K, hipStream_t s) {
     constexpr int smem = 256 * 528;                              // >= the two 64-KiB operand slots
-    auto kern = gemm_nt4_kernel<HB, HR, OB, AC, SW>;
+    auto kern = gemm_nt4_kernel<HB, HR, OB, AC, SW, 0, AS, BS>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -579,6 +691,18 @@ int st_gemm_asm4_dispatch(const uint16_t* A, int64_t lda, const uint16_t* B, int
     }
     if (accumulate) return launch_asm4<false, false, false, true, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
     return launch_asm4<false, false, false, false, false>(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, nullptr, 0, M, N, K, s);
+}
+
+// out[M,N] (bf16) = A[M,K] B[K,N], B contraction-major (the dX = dY W form of st_gemm_nn)
+int st_gemm_asm4_nn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, uint16_t* Cb, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
+    return launch_asm4<false, false, true, false, false, false, true>(A, lda, B, ldb, nullptr, nullptr, 0, Cb, nullptr, ldc, nullptr, 0, M, N, K, s);
+}
+// out_f32[M,N] (+)= A[K,M]^T B[K,N], both contraction-major (the dW = dY^T X form of st_gemm_tn)
+int st_gemm_asm4_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K, hipStream_t s) {
+    if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
+    if (accumulate) return launch_asm4<false, false, false, true, false, true, true>(A, lda, B, ldb, nullptr, nullptr, 0, nullptr, Cf, ldc, nullptr, 0, M, N, K, s);
+    return launch_asm4<false, false, false, false, false, true, true>(A, lda, B, ldb, nullptr, nullptr, 0, nullptr, Cf, ldc, nullptr, 0, M, N, K, s);
 }
 
 // gate/up projection with the SwiGLU epilogue: m_out[M, I] = silu(A gate^T) * (A up^T), gu_out (optional) = bf16 gate | up

@@ -583,8 +583,9 @@ def test_gemm_swiglu_fused_epilogue_bit_identical(ops, M_, I, K):
     assert gu2 is None and torch.equal(m2, m_ref)
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 64), (304, 520, 192), (1000, 3592, 256), (4104, 4096, 1024)])
-def test_gemm_nn_tn_contraction_major_operands(ops, shape):
+@pytest.mark.parametrize("variant", [40, 23])
+@pytest.mark.parametrize("shape", [(256, 256, 64), (304, 520, 192), (1000, 3592, 256), (4104, 4096, 1024), (520, 264, 64 * 37), (264, 8, 128), (2048, 1536, 320)])
+def test_gemm_nn_tn_contraction_major_operands(ops, shape, variant):
     """st_gemm_nn (dX = dY W with W as stored) and st_gemm_tn (dW = dY^T X) against fp32 torch and, bit for bit, against the NT
     kernel fed with explicitly transposed operands (same tile, same MFMA order): ragged edges, 1..16 K-tiles, views with a row pitch
     larger than the width (qkv / gate|up slices), with and without the tail split, accumulate on and off."""
@@ -594,12 +595,13 @@ def test_gemm_nn_tn_contraction_major_operands(ops, shape):
     w_kn = bf(rs.standard_normal((K, N)) * (1 + np.arange(N)[None, :] / N)).cuda()          # B[k][n], asymmetric
     want = a.float() @ w_kn.float()
     scale = float(want.abs().max())
+    ops.gemm_select(variant)                         # 40: the 4-wave hand-scheduled tile's contraction-major forms; 23: the 8-wave tile's
     for split in (True, False):
         ops.gemm_tail_split(split)
         try:
             out = ops.gemm_nn(a, w_kn)
             assert float((out.float() - want).abs().max()) < scale * 2 ** -7, split
-            ref = ops.gemm_nt_variant(23, a, ops.transpose(w_kn))
+            ref = ops.gemm_nt_variant(variant if M_ > 256 else 23, a, ops.transpose(w_kn))
             assert torch.equal(out, ref), split
             # dW form: A[k][m], B[k][n]; here "k" is the token index
             x_km = bf(rs.standard_normal((K, M_))).cuda()
@@ -608,16 +610,25 @@ def test_gemm_nn_tn_contraction_major_operands(ops, shape):
             ops.gemm_tn(x_km, w_kn, f, accumulate=True)
             assert float((f - want_tn - 0.5).abs().max()) < float(want_tn.abs().max()) * 1e-5 + 1e-3, split
             f2 = torch.full((M_, N), 0.5, dtype=torch.float32, device="cuda")
-            ops.gemm_nt_variant(23, ops.transpose(x_km), ops.transpose(w_kn), out_f32=f2, accumulate=True)
+            ops.gemm_nt_variant(variant, ops.transpose(x_km), ops.transpose(w_kn), out_f32=f2, accumulate=True)
             assert torch.equal(f, f2), split
             ops.gemm_tn(x_km, w_kn, f, accumulate=False)
             assert float((f - want_tn).abs().max()) < float(want_tn.abs().max()) * 1e-5 + 1e-3
         finally:
             ops.gemm_tail_split(True)
+            ops.gemm_select(40)
     # strided views: operands that are column slices of wider buffers
     wide_a = torch.zeros(M_, K + 128, dtype=torch.bfloat16, device="cuda"); wide_a[:, 64:64 + K] = a
     wide_w = torch.zeros(K, N + 256, dtype=torch.bfloat16, device="cuda"); wide_w[:, 128:128 + N] = w_kn
-    assert torch.equal(ops.gemm_nn(wide_a[:, 64:64 + K], wide_w[:, 128:128 + N]), ops.gemm_nn(a, w_kn))
+    ops.gemm_select(variant)
+    try:
+        assert torch.equal(ops.gemm_nn(wide_a[:, 64:64 + K], wide_w[:, 128:128 + N]), ops.gemm_nn(a, w_kn))
+        wide_x = torch.zeros(K, M_ + 64, dtype=torch.bfloat16, device="cuda"); wide_x[:, 32:32 + M_] = x_km
+        f3 = torch.zeros(M_, N, dtype=torch.float32, device="cuda")
+        ops.gemm_tn(wide_x[:, 32:32 + M_], wide_w[:, 128:128 + N], f3)
+        assert torch.equal(f3, f)
+    finally:
+        ops.gemm_select(40)
 
 
 # ------------------------------------------------------------------ the 4-wave tile with the hand-scheduled K loop (gemm_asm4.hip)

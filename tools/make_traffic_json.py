@@ -10,6 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fetch, write, bench_line, out = sys.argv[1:5]
 F, W = json.load(open(fetch)), json.load(open(write))
+DF, DW = (json.load(open(sys.argv[5])), json.load(open(sys.argv[6]))) if len(sys.argv) > 6 else ({}, {})     # decode probe (tools/gen_flat.py 40 64 8)
 line = json.loads(open(bench_line).read().strip().splitlines()[-1])
 
 
@@ -26,19 +27,27 @@ for k in set(F) | set(W):
     f = F.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
     w = W.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
     n = max(F.get(k, {}).get("dispatches", 0), W.get(k, {}).get("dispatches", 0))
-    if k.startswith(DECODE):
-        dec_bytes += f + w
-    elif is_train_gemm(k):
+    if is_train_gemm(k):
         tr_bytes += f + w
         tr_launch += n if not k.startswith("gemm_a4_finish_kernel") else 0
         per_kernel[k[:90]] = {"launches": n, "hbm_bytes_per_launch": (f + w) / max(n, 1)}
+dec_its = 2 * 39                                              # two generate() calls of 40 new tokens: 39 decode iterations each
+dec_kernels = {}
+for k in set(DF) | set(DW):
+    if not k.startswith(DECODE):
+        continue                                              # prefill / ViT kernels of the probe
+    b = DF.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 + DW.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+    dec_bytes += b
+    dec_kernels[k[:70]] = b / dec_its
 alg = line["roofline"].get("algorithmic_bytes_per_launch")
-its = (line.get("roofline_decode") or {}).get("iterations")
+its = dec_its if dec_bytes else None
 import bench
-res = {"kernel_source_sha16": bench.gemm_source_sha(), "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+res = {"kernel_source_sha16": bench.gemm_source_sha(), "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-include-regex <training GEMM kernels> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
        "hbm_bytes_per_launch": tr_bytes / max(tr_launch, 1), "launches": tr_launch, "algorithmic_bytes_per_launch": alg,
        "traffic_over_algorithmic": (tr_bytes / max(tr_launch, 1)) / alg if alg else None,
        "decode_hbm_bytes_per_iteration": dec_bytes / its if its else None, "decode_iterations": its,
+       "decode_command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} -- python3 tools/gen_flat.py 40 64 8   (512 live rows, 1102-token prompts)",
+       "decode_top_kernels": dict(sorted(dec_kernels.items(), key=lambda kv: -kv[1])[:6]),
        "top_kernels": dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["launches"] * kv[1]["hbm_bytes_per_launch"])[:6])}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res)[:600])

@@ -624,9 +624,10 @@ def test_gemm_nn_tn_contraction_major_operands(ops, shape, variant):
     try:
         assert torch.equal(ops.gemm_nn(wide_a[:, 64:64 + K], wide_w[:, 128:128 + N]), ops.gemm_nn(a, w_kn))
         wide_x = torch.zeros(K, M_ + 64, dtype=torch.bfloat16, device="cuda"); wide_x[:, 32:32 + M_] = x_km
-        f3 = torch.zeros(M_, N, dtype=torch.float32, device="cuda")
+        f3, f4 = torch.zeros(M_, N, dtype=torch.float32, device="cuda"), torch.zeros(M_, N, dtype=torch.float32, device="cuda")
         ops.gemm_tn(wide_x[:, 32:32 + M_], wide_w[:, 128:128 + N], f3)
-        assert torch.equal(f3, f)
+        ops.gemm_tn(x_km, w_kn, f4)
+        assert torch.equal(f3, f4)
     finally:
         ops.gemm_select(40)
 

@@ -52,5 +52,10 @@ for T in [int(a) for a in sys.argv[1:]] or [21504]:
         tl = bench(lib_)
         tot["v40"] += t40; tot["v23"] += t23; tot["lib"] += tl
         print(f"T={T} {name:14s}: v40 {fl / t40 / 1e12:6.0f}  v23 {fl / t23 / 1e12:6.0f}  hipblaslt {fl / tl / 1e12:6.0f} TF/s   ({t40 * 1e6:7.0f} us)", flush=True)
+    # dX through the weight AS STORED (st_gemm_nn, B contraction-major) against the same product through a transposed copy (NT)
+    for nm, K_, N_ in (("qkv", QKV, H), ("o", H, H), ("gu", 2 * I, H), ("down", H, I)):
+        fl = 2.0 * T * K_ * N_
+        t_nt, t_nn = bench(lambda: ops.gemm_nt(dy[nm], wT[nm])), bench(lambda: ops.gemm_nn(dy[nm], w[nm]))
+        print(f"T={T} dx_{nm:5s} NN (weights as stored) {fl / t_nn / 1e12:6.0f} TF/s   vs NT through the transposed copy {fl / t_nt / 1e12:6.0f} TF/s", flush=True)
     fl_all = sum(c[1] for c in cases)
     print(f"T={T} layer total: v40 {tot['v40'] * 1e3:.2f} ms ({fl_all / tot['v40'] / 1e12:.0f} TF/s), v23 {tot['v23'] * 1e3:.2f} ms, hipblaslt (plain products) {tot['lib'] * 1e3:.2f} ms")

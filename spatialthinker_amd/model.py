@@ -166,10 +166,6 @@ def param_layout(c: VLConfig) -> "Dict[str, Tuple[int, ...]]":
     return L
 
 
-def _needs_transpose(name: str) -> bool:
-    return name.endswith(("qkv_w", "proj_w", "gu_w", "down_w", "o_w", "fc1_w", "fc2_w")) or name in ("lm_head", "embed")
-
-
 class ParamStore:
     """Flat bf16 weights (+ optional fp32 grads, bf16 AdamW states, transposed copies)."""
 
@@ -186,7 +182,6 @@ class ParamStore:
         self.w = {n: self._view(self.flat, n) for n in self.layout}
         self.grad = self.g = None
         self.m = self.v = self.c = None
-        self.wT: Dict[str, torch.Tensor] = {}
         self.wq = None                   # MX-fp8 copies of the LM projection weights (refresh_fp8), only in fp8 mode
         if trainable:
             self.grad = torch.zeros(off, dtype=F32, device=device)
@@ -194,9 +189,6 @@ class ParamStore:
             self.m = torch.zeros(off, dtype=BF16, device=device)
             self.v = torch.zeros(off, dtype=BF16, device=device)
             self.c = torch.zeros(off, dtype=BF16, device=device)
-            for n, shape in self.layout.items():
-                if _needs_transpose(n) and not (n == "embed" and not cfg.tie_word_embeddings):
-                    self.wT[n] = torch.empty(shape[1], shape[0], dtype=BF16, device=device)
 
     def _view(self, flat, name):
         shape = self.layout[name]
@@ -204,8 +196,8 @@ class ParamStore:
         return flat[o:o + int(np.prod(shape))].view(*shape)
 
     def refresh_transposes(self):
-        for n, t in self.wT.items():
-            ops.transpose(self.w[n], out=t)
+        """Copies derived from the weights, rebuilt after every optimizer step / load.  There are no transposed copies any more: the
+        backward reads every weight AS STORED (dX = dY W through st_gemm_nn, contraction-major B); only the fp8 mode keeps copies."""
         if getattr(self, "wq", None):
             self.refresh_fp8()
 
@@ -468,29 +460,29 @@ class Qwen25VL:
         return img
 
     def _vit_backward(self, b: DeviceBatch, saved: list, d_img: torch.Tensor):
-        c, w, g, wT, v = self.cfg, self.p.w, self.p.g, self.p.wT, b.vis
+        c, w, g, v = self.cfg, self.p.w, self.p.g, b.vis
         N, Np = v["N"], v["N_pad"]
         heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
         x, rq, hq, f1, ge = saved.pop()
         df2 = torch.zeros(Np // 4, c.hidden_size, dtype=BF16, device=d_img.device)
         ops.rows_scatter_(df2, v["inverse"], d_img)
         self._dw(g["v.merger.fc2_w"], df2, ge, g["v.merger.fc2_b"])
-        dge = ops.gemm_nt(df2, wT["v.merger.fc2_w"])
+        dge = ops.gemm_nn(df2, w["v.merger.fc2_w"])
         df1 = ops.gelu_bwd(f1, dge)
         self._dw(g["v.merger.fc1_w"], df1, hq.view(Np // 4, 4 * vh), g["v.merger.fc1_b"])
-        dhq = ops.gemm_nt(df1, wT["v.merger.fc1_w"]).view(Np, vh)
+        dhq = ops.gemm_nn(df1, w["v.merger.fc1_w"]).view(Np, vh)
         dx = ops.rmsnorm_bwd(x, w["v.merger.ln_q"], rq, dhq, dw_accum=g["v.merger.ln_q"])
         for i in reversed(range(c.v_depth)):
             p = f"v.{i}."
             x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved.pop()
             self._dw(g[p + "down_w"], dx, m, g[p + "down_b"])
-            dm = ops.gemm_nt(dx, wT[p + "down_w"])
+            dm = ops.gemm_nn(dx, w[p + "down_w"])
             dgu = ops.swiglu_bwd(gu, dm)
             self._dw(g[p + "gu_w"], dgu, h2, g[p + "gu_b"])
-            dh2 = ops.gemm_nt(dgu, wT[p + "gu_w"])
+            dh2 = ops.gemm_nn(dgu, w[p + "gu_w"])
             dx1 = ops.rmsnorm_bwd(x1, w[p + "norm2"], r2, dh2, dres=dx, dw_accum=g[p + "norm2"])
             self._dw(g[p + "proj_w"], dx1, a, g[p + "proj_b"])
-            da = ops.gemm_nt(dx1, wT[p + "proj_w"])
+            da = ops.gemm_nn(dx1, w[p + "proj_w"])
             full = i in c.v_fullatt
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             dqkv = torch.zeros_like(qkv)
@@ -498,7 +490,7 @@ class Qwen25VL:
                          dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:], pairs=v["pairs_img"] if full else v["pairs_win"])
             ops.rope_apply_(dqkv, v["cos"], v["sin"], 2 * heads, hd, inverse=True)
             self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
-            dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
+            dh1 = ops.gemm_nn(dqkv, w[p + "qkv_w"])
             dx = ops.rmsnorm_bwd(x0, w[p + "norm1"], r1, dh1, dres=dx1, dw_accum=g[p + "norm1"])
         (_, pxw) = saved.pop()
         self._dw(g["v.patch_embed"], dx, pxw, None)
@@ -562,7 +554,7 @@ class Qwen25VL:
         return x2
 
     def _lm_layer_bwd(self, i: int, dx2: torch.Tensor, b: DeviceBatch, saved):
-        c, w, g, wT = self.cfg, self.p.w, self.p.g, self.p.wT
+        c, w, g = self.cfg, self.p.w, self.p.g
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
         x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved
@@ -571,20 +563,20 @@ class Qwen25VL:
             h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
             h1, _ = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps, want_rstd=False)
         self._dw(g[p + "down_w"], dx2, m, None)
-        dm = ops.gemm_nt(dx2, wT[p + "down_w"])
+        dm = ops.gemm_nn(dx2, w[p + "down_w"])
         dgu = ops.swiglu_bwd(gu, dm)
         self._dw(g[p + "gu_w"], dgu, h2, None)
-        dh2 = ops.gemm_nt(dgu, wT[p + "gu_w"])
+        dh2 = ops.gemm_nn(dgu, w[p + "gu_w"])
         dx1 = ops.rmsnorm_bwd(x1, w[p + "post_norm"], r2, dh2, dres=dx2, dw_accum=g[p + "post_norm"])
         self._dw(g[p + "o_w"], dx1, a, None)
-        da = ops.gemm_nt(dx1, wT[p + "o_w"])
+        da = ops.gemm_nn(dx1, w[p + "o_w"])
         dqkv = torch.zeros_like(qkv)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
                          self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
         ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
         self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
-        dh1 = ops.gemm_nt(dqkv, wT[p + "qkv_w"])
+        dh1 = ops.gemm_nn(dqkv, w[p + "qkv_w"])
         return ops.rmsnorm_bwd(x0, w[p + "in_norm"], r1, dh1, dres=dx1, dw_accum=g[p + "in_norm"])
 
     def _head_fwd(self, x: torch.Tensor, b: DeviceBatch, temperature: float):
@@ -658,7 +650,7 @@ class Qwen25VL:
         on_final(lo, hi): called as soon as the element range [lo, hi) of the flat gradient buffer has received its last
         contribution of THIS pass (head + final norm, then each LM layer in backward order) — the data-parallel engine starts
         that slice's all-reduce there when the pass is the last one of an optimizer step (actor.GradReducer)."""
-        c, g, wT = self.cfg, self.p.g, self.p.wT
+        c, g, w = self.cfg, self.p.g, self.p.w
         on_final = loss_kw.pop("on_final", None)
         train_vision = loss_kw.pop("train_vision", True)     # False: frozen vision tower — no ViT activations kept, no ViT backward
         off = self.p.offsets
@@ -694,7 +686,7 @@ class Qwen25VL:
         ops.logprob_bwd_(logits, b.labels, lse, grow, temperature)                       # logits buffer now holds dlogits
         head_name = "embed" if c.tie_word_embeddings else "lm_head"
         self._dw(g[head_name], logits, hn, None)
-        dhn = ops.gemm_nt(logits, wT[head_name])
+        dhn = ops.gemm_nn(logits, w[head_name])
         dxr = ops.rmsnorm_bwd(xr, self.p.w["final_norm"], rn, dhn, dw_accum=g["final_norm"])
         if on_final is not None and not c.tie_word_embeddings:      # final_norm + lm_head close the buffer (param_layout)
             on_final(off["final_norm"], self.p.numel)

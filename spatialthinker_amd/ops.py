@@ -286,6 +286,7 @@ def gemm_nn(a, b_kn, out=None):
     assert b_kn.shape[0] == K, (a.shape, b_kn.shape)
     out = torch.empty(M, N, dtype=BF16, device=a.device) if out is None else out
     _gemm_workspace(a.device)
+    _count_gemm(M, N, K, 2)
     lib().st_gemm_nn(_p(a), a.stride(0), _p(b_kn), b_kn.stride(0), _p(out), out.stride(0), M, N, K, _s())
     return out
 

@@ -7,16 +7,20 @@
 // every non-MFMA instruction (fragment read, LDS-DMA issue, M0 update, wait, barrier) sits in the shadow of a 16-cycle MFMA — at
 // most one or two "fillers" between two MFMAs (MI355X_MICROARCH.md: a 16x16x32 MFMA hides ~2 single-issue instructions).
 // Every instruction of the loop is an `asm volatile` statement: hipcc only allocates registers and keeps the statement order.
-//   * operands: LDS-DMA through the BUFFER path (`buffer_load_dwordx4 ... offen lds`): one lane-offset VGPR per operand (advanced
-//     by 128 bytes per K-tile), one SGPR offset per 1-KiB copy, the LDS destination in M0 — no per-copy address arithmetic on the
-//     VALU; rows beyond M / N are cut off by the buffer's num_records (they read as zero, nothing is clamped);
+//   * operands: LDS-DMA through the BUFFER path (`buffer_load_dwordx4 ... offen lds`): one lane-offset VGPR per 1-KiB copy (8 per
+//     operand, constant over the K loop, rows / columns past the matrix edge clamped to the last valid one), the K-tile position
+//     in an SGPR offset (row-major operands) or in the resource's base address (contraction-major ones), the LDS destination in M0
+//     — no address arithmetic on the VALU inside the loop;
 //   * LDS image [row][64 k] with the 16-byte chunk position XOR (row & 7), applied on the SOURCE address: conflict-free for the
-//     lane groups of ds_read_b128, and the lane offset does not depend on the copy index;
+//     lane groups of ds_read_b128; contraction-major operands (AS / BS: dX = dY W, dW = dY^T X read their operands as stored) use
+//     the [64 k][256 m] image of gemm_tile_kernel.h and two ds_read_b64_tr_b16 per fragment;
 //   * per K-tile and wave: 128 MFMAs, 32 ds_read_b128 (fragments of the next k-step under the MFMAs of the current one), 16 LDS-DMA
-//     issues of tile t+2 into the slot tile t has just vacated, two barriers (slot free / next tile landed), counted vmcnt so that
-//     16 copies stay in flight across the second barrier.
+//     issues of tile t+2 into the slot tile t has just vacated, spread over the rest of the tile, two barriers (slot free / next
+//     tile landed), counted vmcnt so that the copies already issued stay in flight across the second barrier.
 // Epilogue: the accumulators pass through the (idle) operand LDS so that bias / residual / C / the fp32 accumulate target move as
-// 16-byte row-contiguous vectors (same scheme as the 8-wave tile's LDS-staged epilogue in gemm_tile_kernel.h).
+// 16-byte row-contiguous vectors; interior tiles with aligned pointers (the production case) run straight-line code: 16 LDS reads in
+// flight, then the stores back to back.  (Round 3: the integer bf16 rounding + the per-row branches of the first version cost 10 us
+// of an 87-us tile — profiles/r03_notes.md; f2bf2 / pack8 are v_cvt_pk_bf16_f32 now.)
 #include "common.h"
 #include <type_traits>
 
@@ -56,13 +60,6 @@ __device__ __forceinline__ void a4_flip(uint32_t& addr) { asm volatile("v_xor_b3
 __device__ __forceinline__ void a4_m0_set(uint32_t v) { asm volatile("s_mov_b32 m0, %0" : : "s"(v) : "memory"); }
 __device__ __forceinline__ void a4_m0_next() { asm volatile("s_add_u32 m0, m0, 0x400" : : : "memory", "scc"); }
 __device__ __forceinline__ void a4_barrier() { asm volatile("s_barrier" : : : "memory"); }
-// Wave w waits 16*w cycles: the four waves of a workgroup leave a barrier together and would hand their LDS-DMA copies to the CU's one
-// texture addresser in the same cycle, 16 cycles per 1-KiB copy — the last of four then sits ~48 cycles at ITS issue while its matrix
-// pipe runs dry.  Skewed by one copy time each, the four issue streams interleave for the whole copy window (until the next barrier).
-__device__ __forceinline__ void a4_stagger(uint32_t wave) {
-    asm volatile("s_bitcmp1_b32 %0, 0\n\ts_cbranch_scc0 1f\n\ts_nop 15\n1:\n\ts_bitcmp1_b32 %0, 1\n\ts_cbranch_scc0 2f\n\ts_nop 15\n\ts_nop 15\n2:"
-                 : : "s"(wave) : "scc", "memory");
-}
 __device__ __forceinline__ void a4_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
 template <int N> __device__ __forceinline__ void a4_wait_lgkm() {          // LDS reads return in order: "at most N still outstanding"
     if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

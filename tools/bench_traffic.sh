@@ -13,11 +13,11 @@ RX='gemm_nt4_kernel|gemm_a4_finish_kernel|gemm_nt_kernel|gemm_tile_kernel<256, 2
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_bench_$c
   rm -rf $d
-  (cd /tmp && PYTHONPATH=$root timeout 900 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$RX" --output-format csv -d $d -o x -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $root/gpurun_out/bench_traffic_$c.json 2> /tmp/bench_traffic_$c.err) || tail -5 /tmp/bench_traffic_$c.err
+  (cd /tmp && PYTHONPATH=$root timeout 700 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$RX" --output-format csv -d $d -o x -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $root/gpurun_out/bench_traffic_$c.json 2> /tmp/bench_traffic_$c.err) || tail -5 /tmp/bench_traffic_$c.err
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_bench_$c.json
   rm -rf $d
   d=/tmp/pmc_dec_$c
-  (cd /tmp && PYTHONPATH=$root timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o x -- python3 $root/tools/gen_flat.py 40 64 8 > $root/gpurun_out/dec_traffic_$c.log 2>&1) || tail -5 $root/gpurun_out/dec_traffic_$c.log
+  (cd /tmp && PYTHONPATH=$root timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o x -- python3 $root/tools/gen_flat.py 40 64 8 > $root/gpurun_out/dec_traffic_$c.log 2>&1) || tail -5 $root/gpurun_out/dec_traffic_$c.log
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_dec_$c.json
   rm -rf $d
 done

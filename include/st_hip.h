@@ -293,6 +293,13 @@ int st_adamw_kahan_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, s
 int st_adamw_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, float bias_correction1, float bias_correction2_sqrt,
                   const float* grad_scale, st_stream_t stream);
+/* torch.optim.AdamW(fused=True) on FP32 master parameters with fp32 exp_avg / exp_avg_sq — the reference's default actor
+ * (worker.actor.fsdp.torch_dtype unset: fp32 parameters under MixedPrecision(param_dtype=bf16), verl/workers/fsdp_workers.py:186-189,
+ * 238-243, 284-291).  p_bf16 receives the bf16 rounding of the updated master (the working copy every kernel computes with = what
+ * FSDP's next all-gather in param_dtype yields).  grad fp32, scaled by grad_scale[0] (the clip coefficient). */
+int st_adamw_master_step(float* master, st_bf16* p_bf16, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, float bias_correction1, float bias_correction2_sqrt,
+                         const float* grad_scale, st_stream_t stream);
 /* sum of squares of an fp32 buffer into out[0] (+= if accumulate) — global grad-norm for clipping
  * (verl/workers/actor/dp_actor.py:155-167). Deterministic two-stage reduction, scratch >= 1024 floats. */
 int st_sumsq_f32(const float* x, int64_t n, float* scratch, float* out, int accumulate, st_stream_t stream);

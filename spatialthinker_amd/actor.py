@@ -379,7 +379,12 @@ class PolicyEngine:
         # frozen parameters have grad None in the reference, so its optimizers skip them entirely (no decay either): the ViT
         # slice leads the flat buffer (model.param_layout), the update starts behind it
         lo = st.offsets["embed"] if h.freeze_vision_tower else 0
-        if h.optim_strategy == "adamw_bf16":
+        if st.master is not None:                               # fp32 master weights + fp32 moments: torch.optim.AdamW(fused) on the master
+            if h.optim_strategy != "adamw":
+                raise NotImplementedError("fp32 master weights are built for optim.strategy=adamw (the reference's default pair)")
+            ops.adamw_master_step_(st.master[lo:], st.flat[lo:], st.grad[lo:], st.m[lo:], st.v[lo:], t=self.opt_steps, lr=self.current_lr(),
+                                   betas=h.betas, eps=h.eps, weight_decay=h.weight_decay, grad_scale=self._coef)
+        elif h.optim_strategy == "adamw_bf16":
             ops.adamw_kahan_step_(st.flat[lo:], st.grad[lo:], st.m[lo:], st.v[lo:], st.c[lo:], t=self.opt_steps, lr=self.current_lr(),
                                   betas=h.betas, eps=h.eps, weight_decay=h.weight_decay, grad_scale=self._coef)
         elif h.optim_strategy == "adamw":

@@ -200,6 +200,35 @@ __global__ __launch_bounds__(256) void adamw_plain_kernel(uint16_t* __restrict__
     }
 }
 
+// fp32 master weights (the reference's default actor: worker.actor.fsdp.torch_dtype unset -> fp32 parameters under FSDP
+// MixedPrecision(param_dtype=bf16), torch.optim.AdamW(fused=True) on the fp32 shards, verl/workers/fsdp_workers.py:186-189,284-291):
+// the same fused-AdamW arithmetic on fp32 p / exp_avg / exp_avg_sq, and the bf16 working copy the kernels compute with is re-rounded
+// from the master in the same pass (what FSDP's next all-gather in param_dtype would produce).  28 B read + 14 B written per parameter.
+__global__ __launch_bounds__(256) void adamw_master_kernel(float* __restrict__ p, uint16_t* __restrict__ pw, const float* __restrict__ grad,
+                                                          float* __restrict__ m, float* __restrict__ v, int64_t n, double lr, double b1,
+                                                          double b2, double wd, double eps, float bc1, float bc2_sqrt,
+                                                          const float* __restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (int64_t)gridDim.x * blockDim.x) {
+        float4 p4 = reinterpret_cast<float4*>(p)[idx], m4 = reinterpret_cast<float4*>(m)[idx], v4 = reinterpret_cast<float4*>(v)[idx];
+        const float4 g4 = reinterpret_cast<const float4*>(grad)[idx];
+        adamw_plain_math(p4.x, g4.x * gs, m4.x, v4.x, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_plain_math(p4.y, g4.y * gs, m4.y, v4.y, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_plain_math(p4.z, g4.z * gs, m4.z, v4.z, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_plain_math(p4.w, g4.w * gs, m4.w, v4.w, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        reinterpret_cast<float4*>(p)[idx] = p4; reinterpret_cast<float4*>(m)[idx] = m4; reinterpret_cast<float4*>(v)[idx] = v4;
+        reinterpret_cast<uint2*>(pw)[idx] = make_uint2(f2bf2(p4.x, p4.y), f2bf2(p4.z, p4.w));
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+            float pf = p[i], mf = m[i], vf = v[i];
+            adamw_plain_math(pf, grad[i] * gs, mf, vf, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+            p[i] = pf; m[i] = mf; v[i] = vf; pw[i] = f2bf(pf);
+        }
+    }
+}
+
 // deterministic sum of squares: stage 1 -> scratch[blocks], stage 2 (one block) -> out
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ scratch) {
     double acc = 0.0;
@@ -566,6 +595,23 @@ int st_adamw_step(st_bf16* p, const float* grad, st_bf16* m, st_bf16* v, int64_t
     int blocks = st_cdiv(n / 8 + 1, 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(adamw_plain_kernel, dim3(blocks), dim3(256), 0, s, p, grad, m, v, n, lr, beta1, beta2, weight_decay, eps,
+                       bias_correction1, bias_correction2_sqrt, grad_scale);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_adamw_master_step(float* master, st_bf16* p_bf16, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, float bias_correction1, float bias_correction2_sqrt,
+                         const float* grad_scale, st_stream_t stream) {
+    if (!master || !p_bf16 || !grad || !m || !v || n < 0 || (((uintptr_t)master | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) ||
+        (((uintptr_t)p_bf16) & 7))
+        return ST_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_ADAMW, s, 42.0 * (double)n);
+    int blocks = st_cdiv(n / 4 + 1, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(adamw_master_kernel, dim3(blocks), dim3(256), 0, s, master, p_bf16, grad, m, v, n, lr, beta1, beta2, weight_decay, eps,
                        bias_correction1, bias_correction2_sqrt, grad_scale);
     ST_CHECK_LAUNCH();
     return 0;

@@ -183,12 +183,23 @@ class ParamStore:
         self.grad = self.g = None
         self.m = self.v = self.c = None
         self.wq = None                   # MX-fp8 copies of the LM projection weights (refresh_fp8), only in fp8 mode
+        self.master = None               # fp32 master weights (enable_fp32_master), None = the bf16 weights ARE the parameters
         if trainable:
             self.grad = torch.zeros(off, dtype=F32, device=device)
             self.g = {n: self._view(self.grad, n) for n in self.layout}
             self.m = torch.zeros(off, dtype=BF16, device=device)
             self.v = torch.zeros(off, dtype=BF16, device=device)
             self.c = torch.zeros(off, dtype=BF16, device=device)
+
+    def enable_fp32_master(self):
+        """The reference's default actor (worker.actor.fsdp.torch_dtype unset, verl/workers/fsdp_workers.py:186-189): fp32 parameters and
+        fp32 AdamW moments; `flat` stays the bf16 working copy every kernel computes with (= FSDP's param_dtype=bf16 all-gather) and is
+        re-rounded from the master by st_adamw_master_step.  12 bytes per parameter of state instead of 6 (bf16 m / v / Kahan)."""
+        assert self.trainable
+        self.master = self.flat.float()
+        self.m = torch.zeros(self.numel, dtype=F32, device=self.device)
+        self.v = torch.zeros(self.numel, dtype=F32, device=self.device)
+        self.c = None
 
     def _view(self, flat, name):
         shape = self.layout[name]
@@ -217,8 +228,8 @@ class ParamStore:
         views = self.w if target is None else {n: self._view(target, n) for n in self.layout}
 
         def put(name, t):
-            t = t.to(dtype=BF16, device=self.device)
             dst = views[name]
+            t = t.to(dtype=dst.dtype, device=self.device)
             if dst.shape == t.shape:
                 dst.copy_(t)
             elif dst.dim() == 2:
@@ -256,6 +267,8 @@ class ParamStore:
         if not c.tie_word_embeddings:
             put("lm_head", sd["lm_head.weight"])
         if self.trainable and target is None:
+            if getattr(self, "master", None) is not None:        # fp32 master mode: the master takes the checkpoint's own precision
+                self.load_hf_state_dict(sd, target=self.master)
             self.refresh_transposes()
 
     def export_hf(self, source: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:

@@ -509,6 +509,15 @@ def adamw_step_(p, grad_f32, m, v, *, t: int, lr, betas=(0.9, 0.999), eps=1e-8, 
                         _p(grad_scale), _s())
 
 
+def adamw_master_step_(master_f32, p_bf16, grad_f32, m_f32, v_f32, *, t: int, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=None):
+    """torch.optim.AdamW(fused=True) on fp32 master weights and fp32 moments; p_bf16 = bf16 rounding of the new master (st_adamw_master_step)."""
+    _chk(master_f32, F32, "master"); _chk(p_bf16, BF16, "p"); _chk(grad_f32, F32, "grad"); _chk(m_f32, F32, "m"); _chk(v_f32, F32, "v")
+    bc1 = 1.0 - betas[0] ** t
+    bc2_sqrt = (1.0 - betas[1] ** t) ** 0.5
+    lib().st_adamw_master_step(_p(master_f32), _p(p_bf16), _p(grad_f32), _p(m_f32), _p(v_f32), p_bf16.numel(), lr, betas[0], betas[1], eps,
+                               weight_decay, bc1, bc2_sqrt, _p(grad_scale), _s())
+
+
 def sumsq(x_f32, out=None, accumulate=False):
     scratch = torch.empty(1024, dtype=F32, device=x_f32.device)
     o = torch.zeros(1, dtype=F32, device=x_f32.device) if out is None else out

@@ -281,12 +281,12 @@ def test_training_gemms_at_bench_rows_vs_fp32(ops, measured):
     want = m.float() @ wd.float().t()
     e5 = _check_bf16(ops.gemm_nt(m, wd, residual=res), want + res.float(), float(want.abs().max()), "down+residual")
     del want
-    # ---- dX of gate/up through the transposed copy (N = 3584, K = 37888) and dW of gate/up through st_gemm_tn (fp32 accumulate)
+    # ---- dX of gate/up through the weight AS STORED (st_gemm_nn: N = 3584, K = 37888; what the backward runs since round 3) and dW of
+    # gate/up through st_gemm_tn (fp32 accumulate)
     dy = _randn_bf16((T, 2 * I), 0.1, 18)
-    wT = ops.transpose(w)
     want = dy.float() @ w.float()
-    e6 = _check_bf16(ops.gemm_nt(dy, wT), want, float(want.abs().max()), "dX gate_up")
-    del want, wT
+    e6 = _check_bf16(ops.gemm_nn(dy, w), want, float(want.abs().max()), "dX gate_up")
+    del want
     acc = torch.full((2 * I, H), 0.5, dtype=torch.float32, device="cuda")
     ops.gemm_tn(dy, x, acc, accumulate=True)
     want = dy.float().t() @ x.float()

@@ -53,6 +53,53 @@ def test_plain_adamw_matches_torch_fused_adamw():
             assert far == 0 and exact >= 0.999, (t, name, far, exact)
 
 
+def test_fp32_master_adamw_matches_torch_fused_adamw_on_fp32_parameters(measured):
+    """st_adamw_master_step vs torch.optim.AdamW(fused=True) on FP32 parameters — the reference's default actor (torch_dtype unset:
+    fp32 shards under MixedPrecision(param_dtype=bf16), fsdp_workers.py:186-189, 284-291).  Five steps with weight decay and a clip
+    coefficient: master / exp_avg / exp_avg_sq within a few fp32 ulps of torch's (same operation order; the residue is fma
+    contraction), and the bf16 working copy is exactly the rounding of the master."""
+    from spatialthinker_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = (1 << 20) + 3                                             # not a multiple of 4: the scalar tail
+    p0 = torch.randn(n, device="cuda", generator=g) * 0.05
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, fused=True)
+    master, pw = p0.clone(), p0.bfloat16()
+    m, v = torch.zeros_like(p0), torch.zeros_like(p0)
+    scale = torch.tensor([0.37], device="cuda")
+    worst = 0.0
+    for t in range(1, 6):
+        grad = torch.randn(n, device="cuda", generator=g) * (0.02 * t)
+        p_ref.grad = grad * scale
+        opt.step()
+        ops.adamw_master_step_(master, pw, grad, m, v, t=t, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=scale)
+        st = opt.state[p_ref]
+        for name, got, want in (("p", master, p_ref.data), ("m", m, st["exp_avg"]), ("v", v, st["exp_avg_sq"])):
+            rel = float(((got - want).abs() / (want.abs() + 1e-12 * float(want.abs().max()) + 1e-30)).max())
+            frac = float((got == want).float().mean())
+            print(f"step {t} {name}: bit-identical {frac:.5f}, max relative difference {rel:.3g}")
+            worst = max(worst, float((got - want).abs().max() / want.abs().max()))
+            assert float((got - want).abs().max()) <= 4 * 2.0 ** -24 * float(want.abs().max()), (t, name)
+        assert torch.equal(pw, master.bfloat16())
+    measured("adamw_master_vs_torch_fused_max_abs_over_scale", worst)
+
+
+def test_fp32_master_mode_runs_through_update_policy(setup):
+    """ParamStore.enable_fp32_master(): update_policy updates the master, the bf16 working copy follows it exactly, and the master keeps
+    the bits below the bf16 grid (what it is for)."""
+    z, cfg, params = setup
+    eng = _engine(cfg, params, optim_strategy="adamw")
+    eng.store.enable_fp32_master()
+    eng.sched_steps = 1
+    m0 = eng.store.master.clone()
+    eng.update_policy(_data(z, np.random.RandomState(5)), 1.0)
+    st = eng.store
+    assert st.m.dtype == torch.float32 and st.v.dtype == torch.float32 and st.c is None
+    assert torch.equal(st.flat, st.master.bfloat16())
+    assert float((st.master != m0).float().mean()) > 0.5                        # the update reached the master ...
+    assert float((st.master != st.flat.float()).float().mean()) > 0.5          # ... which keeps the bits below the bf16 grid
+
+
 def test_strategy_adamw_runs_through_update_policy(setup):
     z, cfg, params = setup
     eng = _engine(cfg, params, optim_strategy="adamw")

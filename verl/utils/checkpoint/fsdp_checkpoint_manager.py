@@ -105,7 +105,7 @@ def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
         shapes = store.export_hf()                                   # HF name -> view with the parameter's shape
         for buf, key in ((store.m, "exp_avg"), (store.v, "exp_avg_sq"), (store.c, "compensation")):
             have = {n: st[key] for n, st in state.items() if key in st}
-            if have:                                                 # parameters without state (frozen tower) keep zeros
+            if have and buf is not None:                             # parameters without state (frozen tower) keep zeros; no Kahan buffer in fp32-master mode
                 full = {n: have[n] if n in have else torch.zeros(tuple(t.shape)) for n, t in shapes.items()}
                 store.load_hf_state_dict(full, target=buf)
         steps = [int(float(st["step"])) for st in state.values() if "step" in st]

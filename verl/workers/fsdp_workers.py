@@ -81,12 +81,19 @@ class FSDPWorker:
             if a.optim.strategy not in ("adamw_bf16", "adamw"):
                 raise NotImplementedError(f"Optimizer {a.optim.strategy} not supported.")
             dt = (a.fsdp.torch_dtype or "fp32").lower()
-            if dt not in ("bf16", "bfloat16"):
+            if dt not in ("bf16", "bfloat16", "fp32", "float32", "float"):
+                raise NotImplementedError(f"worker.actor.fsdp.torch_dtype={a.fsdp.torch_dtype!r}: bf16 or fp32")
+            master = dt not in ("bf16", "bfloat16")
+            if master and a.optim.strategy != "adamw":
                 raise NotImplementedError(
-                    f"worker.actor.fsdp.torch_dtype={a.fsdp.torch_dtype!r}: this engine trains bf16 weights (pass worker.actor.fsdp.torch_dtype=bf16 "
-                    "as every shipped STVQA script does, scripts/spatialthinker_7b_grpo.sh:25); fp32 master weights (the reference's "
-                    "default when torch_dtype is unset, fsdp_workers.py:186-189) are not built")
+                    "worker.actor.fsdp.torch_dtype=fp32 (the reference's default when unset, fsdp_workers.py:186-189) keeps fp32 master "
+                    "weights with torch.optim.AdamW (optim.strategy=adamw, the reference's default pair); AnyPrecisionAdamW on fp32 "
+                    "parameters (strategy=adamw_bf16 without torch_dtype=bf16) is not built — every shipped STVQA script passes "
+                    "torch_dtype=bf16 with adamw_bf16 (scripts/spatialthinker_7b_grpo.sh:25)")
             cfg, store, special = load_model(mc.model_path, trainable=True)
+            if master:
+                store.enable_fp32_master()
+                self.print_rank0("Actor parameters: fp32 master weights + fp32 AdamW moments, bf16 compute copy (MixedPrecision param_dtype).")
             if mc.freeze_vision_tower:
                 self.print_rank0("Vision tower is set to not trainable.")
             hyper = ActorHyper(micro_batch_size_per_device_for_update=a.micro_batch_size_per_device_for_update,
@@ -105,6 +112,8 @@ class FSDPWorker:
             self.flops_counter = FlopsCounter(cfg)
             if self.world_size > 1:                          # sync_module_states: rank 0's weights everywhere (fsdp_workers.py:261-263)
                 dist.broadcast(store.flat, src=0)
+                if store.master is not None:
+                    dist.broadcast(store.master, src=0)
                 store.refresh_transposes()
         if self._is_rollout:
             self.generator = Generator(self.actor.model)
@@ -205,8 +214,10 @@ class FSDPWorker:
             save_hf(st, os.path.join(path, "huggingface"), tokenizer=getattr(self, "tokenizer", None), processor=getattr(self, "processor", None))
             opt = {"m": st.m.cpu(), "v": st.v.cpu(), "opt_steps": self.actor.opt_steps, "sched_steps": self.actor.sched_steps,
                    "gen_calls": getattr(self, "_gen_calls", 0), "strategy": self.actor.h.optim_strategy}
-            if self.actor.h.optim_strategy == "adamw_bf16":
+            if st.c is not None and self.actor.h.optim_strategy == "adamw_bf16":
                 opt["c"] = st.c.cpu()
+            if st.master is not None:
+                opt["master"] = st.master.cpu()
             torch.save(opt, os.path.join(path, "optim_world_size_1_rank_0.pt"))
         if self.world_size > 1:
             dist.barrier()
@@ -235,8 +246,10 @@ class FSDPWorker:
         st.version = getattr(st, "version", 0) + 1
         opt = torch.load(os.path.join(path, "optim_world_size_1_rank_0.pt"), map_location="cpu")
         st.m.copy_(opt["m"]); st.v.copy_(opt["v"])
-        if "c" in opt:
+        if "c" in opt and st.c is not None:
             st.c.copy_(opt["c"])
+        if st.master is not None:
+            st.master.copy_(opt["master"]) if "master" in opt else st.master.copy_(st.flat)
         self.actor.opt_steps, self.actor.sched_steps = opt["opt_steps"], opt["sched_steps"]
         self._gen_calls = opt.get("gen_calls", 0)                     # the rollout seed stream continues where it stopped
         if self.world_size > 1:

@@ -204,6 +204,19 @@ __global__ __launch_bounds__(256) void adamw_plain_kernel(uint16_t* __restrict__
 // MixedPrecision(param_dtype=bf16), torch.optim.AdamW(fused=True) on the fp32 shards, verl/workers/fsdp_workers.py:186-189,284-291):
 // the same fused-AdamW arithmetic on fp32 p / exp_avg / exp_avg_sq, and the bf16 working copy the kernels compute with is re-rounded
 // from the master in the same pass (what FSDP's next all-gather in param_dtype would produce).  28 B read + 14 B written per parameter.
+// On fp32 moments the last bit of the exp_avg update is visible (the bf16 kernels above round it away): torch's fused kernel forms
+// beta1 * exp_avg + (1 - beta1) * grad with the python-double betas, i.e. in double, rounded once (measured against
+// torch.optim.AdamW(fused=True) on this image: exp_avg / exp_avg_sq bit-identical, tests/test_gpu_train_options.py).
+__device__ __forceinline__ void adamw_master_math(float& p, float g, float& m, float& v, double lr, double b1, double b2, double wd,
+                                                 double eps, float bc1, float bc2_sqrt) {
+    if (wd != 0.0) p = (float)((double)p - lr * wd * (double)p);
+    m = (float)(b1 * (double)m + (1.0 - b1) * (double)g);
+    v = (float)(b2 * (double)v + (1.0 - b2) * (double)g * (double)g);
+    const float step_size = (float)(lr / (double)bc1);
+    const float denom = (float)((double)(__fsqrt_rn(v) / bc2_sqrt) + eps);
+    p -= step_size * m / denom;
+}
+
 __global__ __launch_bounds__(256) void adamw_master_kernel(float* __restrict__ p, uint16_t* __restrict__ pw, const float* __restrict__ grad,
                                                           float* __restrict__ m, float* __restrict__ v, int64_t n, double lr, double b1,
                                                           double b2, double wd, double eps, float bc1, float bc2_sqrt,
@@ -213,17 +226,17 @@ __global__ __launch_bounds__(256) void adamw_master_kernel(float* __restrict__ p
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (int64_t)gridDim.x * blockDim.x) {
         float4 p4 = reinterpret_cast<float4*>(p)[idx], m4 = reinterpret_cast<float4*>(m)[idx], v4 = reinterpret_cast<float4*>(v)[idx];
         const float4 g4 = reinterpret_cast<const float4*>(grad)[idx];
-        adamw_plain_math(p4.x, g4.x * gs, m4.x, v4.x, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
-        adamw_plain_math(p4.y, g4.y * gs, m4.y, v4.y, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
-        adamw_plain_math(p4.z, g4.z * gs, m4.z, v4.z, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
-        adamw_plain_math(p4.w, g4.w * gs, m4.w, v4.w, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_master_math(p4.x, g4.x * gs, m4.x, v4.x, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_master_math(p4.y, g4.y * gs, m4.y, v4.y, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_master_math(p4.z, g4.z * gs, m4.z, v4.z, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+        adamw_master_math(p4.w, g4.w * gs, m4.w, v4.w, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
         reinterpret_cast<float4*>(p)[idx] = p4; reinterpret_cast<float4*>(m)[idx] = m4; reinterpret_cast<float4*>(v)[idx] = v4;
         reinterpret_cast<uint2*>(pw)[idx] = make_uint2(f2bf2(p4.x, p4.y), f2bf2(p4.z, p4.w));
     }
     if (blockIdx.x == 0) {
         for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
             float pf = p[i], mf = m[i], vf = v[i];
-            adamw_plain_math(pf, grad[i] * gs, mf, vf, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
+            adamw_master_math(pf, grad[i] * gs, mf, vf, lr, b1, b2, wd, eps, bc1, bc2_sqrt);
             p[i] = pf; m[i] = mf; v[i] = vf; pw[i] = f2bf(pf);
         }
     }

@@ -56,8 +56,8 @@ def test_plain_adamw_matches_torch_fused_adamw():
 def test_fp32_master_adamw_matches_torch_fused_adamw_on_fp32_parameters(measured):
     """st_adamw_master_step vs torch.optim.AdamW(fused=True) on FP32 parameters — the reference's default actor (torch_dtype unset:
     fp32 shards under MixedPrecision(param_dtype=bf16), fsdp_workers.py:186-189, 284-291).  Five steps with weight decay and a clip
-    coefficient: master / exp_avg / exp_avg_sq within a few fp32 ulps of torch's (same operation order; the residue is fma
-    contraction), and the bf16 working copy is exactly the rounding of the master."""
+    coefficient: exp_avg / exp_avg_sq bit-identical to torch's, the parameters bit-identical for 97-99 % of the elements and one fp32
+    ulp apart for the rest (the final division's rounding), and the bf16 working copy exactly the rounding of the master."""
     from spatialthinker_amd import ops
     g = torch.Generator(device="cuda").manual_seed(5)
     n = (1 << 20) + 3                                             # not a multiple of 4: the scalar tail
@@ -79,7 +79,10 @@ def test_fp32_master_adamw_matches_torch_fused_adamw_on_fp32_parameters(measured
             frac = float((got == want).float().mean())
             print(f"step {t} {name}: bit-identical {frac:.5f}, max relative difference {rel:.3g}")
             worst = max(worst, float((got - want).abs().max() / want.abs().max()))
-            assert float((got - want).abs().max()) <= 4 * 2.0 ** -24 * float(want.abs().max()), (t, name)
+            if name != "p":
+                assert torch.equal(got, want), (t, name)              # exp_avg / exp_avg_sq: bit-identical (measured over 5 steps)
+            else:                                                     # parameters: 98.8 % -> 96.9 % bit-identical over 5 steps, the rest one ulp
+                assert frac >= 0.95 and float((got - want).abs().max()) <= 4 * 2.0 ** -24 * float(want.abs().max()), (t, frac)
         assert torch.equal(pw, master.bfloat16())
     measured("adamw_master_vs_torch_fused_max_abs_over_scale", worst)
 

@@ -536,7 +536,7 @@ def main():
     # whole by the generator (roofline_decode).
     PROF_STRIDE = 13
     classes = {  # class id: (kernel names, bound, peak per second, unit scale, unit)
-        ops.K_GEMM: ("st_gemm_nt family: gemm_tile_kernel<256,256> / gemm_nt_kernel<128,128> (bf16 MFMA 16x16x32, LDS-DMA staged)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_GEMM: ("st_gemm_nt / st_gemm_nn / st_gemm_tn / st_gemm_swiglu: gemm_nt4_kernel (256x256x64, 4 waves x 128x128, hand-scheduled K loop; gemm_asm4.hip), gemm_nt_kernel<128,128> below 128 tiles (bf16 MFMA 16x16x32, LDS-DMA staged)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
         ops.K_ATTN_FWD: ("attn_fwd128_kernel<causal> (shared-prefix segments, MFMA 32x32x16)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
         ops.K_ATTN_BWD: ("attn_bwd128_dq/kv/reduce kernels", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
         ops.K_VIT_ATTN: ("attn_fwd/bwd kernels, head dim 80 (ViT windows + full attention)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),

@@ -55,6 +55,34 @@ def test_main_runs_two_grpo_steps(tmp_path):
     assert f"Load from checkpoint: {ck}" in p2.stdout
 
 
+def test_reference_default_dtype_pair_fp32_master_weights(tmp_path):
+    """worker.actor.fsdp.torch_dtype left UNSET + optim.strategy=adamw — the reference's own defaults (fsdp_workers.py:186-189, actor/config.py:41):
+    fp32 master weights and moments behind the bf16 compute copy.  Two steps through the CLI, a checkpoint that carries the master, a
+    resume; and the pair the engine does not build (adamw_bf16 on fp32 parameters) is rejected, not silently run in bf16."""
+    base = [sys.executable, "-m", "verl.trainer.main", "data.train_files=synthetic:stvqa@train", "data.val_files=", "data.rollout_batch_size=4",
+            "data.max_prompt_length=64", "data.max_response_length=16", "worker.actor.model.model_path=random:tiny",
+            "worker.actor.global_batch_size=2", "worker.actor.micro_batch_size_per_device_for_update=4",
+            "worker.actor.micro_batch_size_per_device_for_experience=8", "worker.rollout.n=4", "worker.reward.score_function=spatial_sgg",
+            "trainer.total_episodes=1", "trainer.n_gpus_per_node=1", "trainer.val_before_train=false", "trainer.val_freq=-1", "trainer.logger=['console']"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = base + ["worker.actor.optim.strategy=adamw", "trainer.max_steps=2", f"trainer.save_checkpoint_path={tmp_path}/ckpt"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "fp32 master weights" in p.stdout
+    assert len([l for l in p.stdout.splitlines() if l.startswith("step ") and "actor/pg_loss" in l]) == 2
+    import torch
+    last = (tmp_path / "ckpt" / "latest_global_step.txt").read_text()
+    opt = torch.load(tmp_path / "ckpt" / f"global_step_{last}" / "actor" / "optim_world_size_1_rank_0.pt", map_location="cpu")
+    assert opt["master"].dtype == torch.float32 and opt["m"].dtype == torch.float32 and "c" not in opt
+    ck = tmp_path / "ckpt" / f"global_step_{last}"
+    p2 = subprocess.run(base + ["worker.actor.optim.strategy=adamw", f"trainer.max_steps={int(last) + 1}", f"trainer.load_checkpoint_path={ck}"],
+                        cwd=ROOT, env=dict(env, ST_SKIP_FINAL_SAVE="1"), capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stdout[-3000:] + p2.stderr[-3000:]
+    p3 = subprocess.run(base + ["worker.actor.optim.strategy=adamw_bf16", "trainer.max_steps=1"], cwd=ROOT, env=dict(env, ST_SKIP_FINAL_SAVE="1"),
+                        capture_output=True, text=True, timeout=600)
+    assert p3.returncode != 0 and "NotImplementedError" in p3.stderr and "torch_dtype=bf16" in p3.stderr
+
+
 def test_config1_3b_vanilla_grpo_r1v_2x4_224px(tmp_path):
     """BASELINE config #1's shape on the GPU engine: Qwen2.5-VL-3B dimensions (tied embeddings), vanilla GRPO with the `r1v` reward,
     2 prompts x G=4, one 224x224 image (256 patches -> 64 image tokens) + 700 text tokens per prompt

@@ -272,23 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
     const int kvh = h / (n_q / n_kv);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
-    // Which 32-row block of the query tile a wave owns.  Decode items have 7 (per-sample keys) or 56 (shared prompt keys) query rows,
-    // so one or two waves of the four compute while the others only copy — and wave w of EVERY workgroup sits on SIMD w, so the two
-    // workgroups resident on a CU put their busy waves on the same SIMD (3.3 us per 64-key tile = two 1.5-us waves back to back on
-    // one SIMD, three SIMDs idle).  The non-causal instantiation therefore rotates the assignment by the workgroup's wave-slot number
-    // (HW_ID.WAVE_ID of wave 0; co-resident workgroups differ in it): slot 0 -> blocks start at wave 0, slot 1 -> at wave 2.
-    int wrow = wave;
-    if constexpr (!CAUSAL) {
-        __shared__ int rot_s;
-        if (threadIdx.x == 0) {
-            uint32_t hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            rot_s = (int)(((((hwid & 1u) << 1) | ((hwid >> 1) & 1u)) ^ (hwid >> 2)) & 3u);
-        }
-        __syncthreads();
-        wrow = __builtin_amdgcn_readfirstlane((wave + 4 - rot_s) & 3);
-    }
-    const int q_idx = q_base + wrow * 32 + qc;
+    const int q_idx = q_base + wave * 32 + qc;
     const bool q_ok = q_idx < Lq;
     // An item without keys (decode: the chunks of a sample's cache beyond its current length — three of four items of the generated
     // partials for most of a rollout) leaves lse = -inf, which is all st_attn_merge looks at, and is gone before it touches Q: the
@@ -397,8 +381,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < n_tiles) stage_any(t + 1, smem + ((t + 1) & 1) * F2_STAGE);
-        if (causal_t && kt0 > q_base + wrow * 32 + 31) continue;        // tile entirely above this wave's diagonal
-        if (q_base + wrow * 32 >= Lq) continue;                         // decode: most waves of a tile hold no query row at all
+        if (causal_t && kt0 > q_base + wave * 32 + 31) continue;        // tile entirely above this wave's diagonal
+        if (q_base + wave * 32 >= Lq) continue;                         // decode: most waves of a tile hold no query row at all
         const char* ks = smem + (t & 1) * F2_STAGE;
         const uint32_t vaddr = smem_lds + (t & 1) * F2_STAGE + F2_V_OFF + v_lane_off;
         uint2 va[8], vb[8];
@@ -417,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
             }
         }
         // mask only where the tile meets the diagonal or the end of the keys (wave-uniform test)
-        if ((kt0 + KV_TILE > Lc) || (causal_t && kt0 + KV_TILE - 1 > q_base + wrow * 32)) {
+        if ((kt0 + KV_TILE > Lc) || (causal_t && kt0 + KV_TILE - 1 > q_base + wave * 32)) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

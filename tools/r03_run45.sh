@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r03_gputests_45.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r03_gputests_45.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -434,6 +434,48 @@ class Qwen25VL:
                            None if pk.logit_distinct is None else t(pk.logit_distinct, I32), pairs=_seg_pairs(pk))
 
     # ---------------------------------------------------------------- vision tower
+    # ViT attention has head dim 80.  Its own kernels (attn_fwd_kernel<80>: register-staged, ~90 TF/s) are fine for the 64-token
+    # windows; the full-attention blocks (whole images: 1344 patches at the STVQA shape, 4096 at 896 px) go through the D = 128 kernels
+    # (LDS-DMA staged, MFMA 32x32x16, ~600 TF/s) on heads zero-padded to 128: the pad contributes 0 to q.k and its V columns are 0, so
+    # the first 80 output dims are the same attention, computed at 1.6x the flops and ~6x the rate.  VIT_PAD_MIN_SEQ: shortest
+    # sequence for which the two pad copies pay.
+    VIT_PAD_MIN_SEQ = 512
+
+    def _vit_pad(self, x3: torch.Tensor) -> torch.Tensor:
+        """(Np, k, heads, 80) view -> contiguous (Np, k*heads*128) with zero pad"""
+        Np, k, heads, hd = x3.shape
+        out = torch.zeros(Np, k, heads, 128, dtype=BF16, device=x3.device)
+        out[..., :hd] = x3
+        return out.view(Np, k * heads * 128)
+
+    def _vit_attn_fwd(self, qkv, cu, mx, a, pairs):
+        c = self.cfg
+        heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
+        if hd < 128 and mx >= self.VIT_PAD_MIN_SEQ:
+            Np, W = qkv.shape[0], heads * 128
+            qp = self._vit_pad(qkv.view(Np, 3, heads, hd))
+            op, lse = ops.attn_fwd(qp[:, :W], qp[:, W:2 * W], qp[:, 2 * W:], cu, mx, heads, heads, 128, self.v_scale, False,
+                                   pairs=None if pairs is None else pairs * hd / 128.0)
+            a.view(Np, heads, hd).copy_(op.view(Np, heads, 128)[..., :hd])
+            return lse
+        _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a, pairs=pairs)
+        return lse
+
+    def _vit_attn_bwd(self, qkv, a, da, lse, cu, mx, dqkv, pairs):
+        c = self.cfg
+        heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
+        if hd < 128 and mx >= self.VIT_PAD_MIN_SEQ:
+            Np, W = qkv.shape[0], heads * 128
+            qp = self._vit_pad(qkv.view(Np, 3, heads, hd))
+            ap, dap = self._vit_pad(a.view(Np, 1, heads, hd)), self._vit_pad(da.view(Np, 1, heads, hd))
+            dp = torch.zeros(Np, 3 * W, dtype=BF16, device=qkv.device)
+            ops.attn_bwd(qp[:, :W], qp[:, W:2 * W], qp[:, 2 * W:], ap, dap, lse, cu, mx, heads, heads, 128, self.v_scale, False,
+                         dp[:, :W], dp[:, W:2 * W], dp[:, 2 * W:], pairs=None if pairs is None else pairs * hd / 128.0)
+            dqkv.view(Np, 3, heads, hd).copy_(dp.view(Np, 3, heads, 128)[..., :hd])
+            return
+        ops.attn_bwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], a, da, lse, cu, mx, heads, heads, hd, self.v_scale, False,
+                     dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:], pairs=pairs)
+
     def _vit_forward(self, b: DeviceBatch, save: Optional[list]):
         c, w, v = self.cfg, self.p.w, b.vis
         N, Np = v["N"], v["N_pad"]
@@ -452,8 +494,7 @@ class Qwen25VL:
             full = i in c.v_fullatt
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             a = torch.zeros(Np, vh, dtype=BF16, device=x.device)
-            _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a,
-                                  pairs=v["pairs_img"] if full else v["pairs_win"])
+            lse = self._vit_attn_fwd(qkv, cu, mx, a, v["pairs_img"] if full else v["pairs_win"])
             x1 = ops.gemm_nt(a, w[p + "proj_w"], bias=w[p + "proj_b"], residual=x)
             h2, r2 = ops.rmsnorm_fwd(x1, w[p + "norm2"], 1e-6)
             gu = ops.gemm_nt(h2, w[p + "gu_w"], bias=w[p + "gu_b"])
@@ -499,8 +540,7 @@ class Qwen25VL:
             full = i in c.v_fullatt
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             dqkv = torch.zeros_like(qkv)
-            ops.attn_bwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], a, da, lse, cu, mx, heads, heads, hd, self.v_scale, False,
-                         dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:], pairs=v["pairs_img"] if full else v["pairs_win"])
+            self._vit_attn_bwd(qkv, a, da, lse, cu, mx, dqkv, v["pairs_img"] if full else v["pairs_win"])
             ops.rope_apply_(dqkv, v["cos"], v["sin"], 2 * heads, hd, inverse=True)
             self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
             dh1 = ops.gemm_nn(dqkv, w[p + "qkv_w"])

@@ -403,6 +403,50 @@ def _attn_case(rs, lens, n_q, n_kv, D):
     return qkv, cu
 
 
+def test_vit_full_attention_through_the_d128_kernels_on_padded_heads(ops, measured):
+    """Qwen25VL._vit_attn_fwd / _vit_attn_bwd: head dim 80 zero-padded to 128 so that whole-image ViT attention (1344 patches at the STVQA
+    shape) runs on the D = 128 kernels.  Forward output and dq / dk / dv against the fp32 dense reference (same bounds as the D = 80
+    kernels' own tests) and against the D = 80 kernels."""
+    import types
+    from spatialthinker_amd.model import Qwen25VL
+    heads, hd, lens = 16, 80, [1344, 700]
+    rs = np.random.RandomState(80)
+    qkv_h, cu = _attn_case(rs, lens, heads, heads, hd)
+    T = qkv_h.shape[0]
+    qkv = qkv_h.cuda()
+    me = types.SimpleNamespace(cfg=types.SimpleNamespace(v_heads=heads, v_head_dim=hd, v_hidden=heads * hd), v_scale=hd ** -0.5,
+                               VIT_PAD_MIN_SEQ=Qwen25VL.VIT_PAD_MIN_SEQ, _vit_pad=lambda x: Qwen25VL._vit_pad(None, x))
+    a = torch.zeros(T, heads * hd, dtype=torch.bfloat16, device="cuda")
+    lse = Qwen25VL._vit_attn_fwd(me, qkv, dev(cu), max(lens), a, None)
+    xf = qkv_h.float()
+    W = heads * hd
+    want = Q.dense_attention(xf[:, :W].reshape(T, heads, hd), xf[:, W:2 * W].reshape(T, heads, hd), xf[:, 2 * W:].reshape(T, heads, hd), cu, False).reshape(T, W)
+    err = float(np.abs(a.float().cpu().numpy() - want.numpy()).max())
+    a80, lse80 = ops.attn_fwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dev(cu), max(lens), heads, heads, hd, hd ** -0.5, False)
+    measured("vit_padded_d128_fwd_abs", err)
+    assert err < 1.05e-2, err
+    assert float((a.float() - a80.float()).abs().max()) < 1.6e-2 and float((lse - lse80).abs().max()) < 2e-3
+    do = bf(rs.standard_normal((T, W)) * 0.5).cuda()
+    dqkv, dqkv80 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    Qwen25VL._vit_attn_bwd(me, qkv, a, do, lse, dev(cu), max(lens), dqkv, None)
+    ops.attn_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], a80, do, lse80, dev(cu), max(lens), heads, heads, hd, hd ** -0.5, False,
+                 dqkv80[:, :W], dqkv80[:, W:2 * W], dqkv80[:, 2 * W:])
+    # fp32 autograd reference
+    qf = xf.clone().cuda().requires_grad_(True)
+    qq, kk, vv = qf[:, :W].reshape(T, heads, hd), qf[:, W:2 * W].reshape(T, heads, hd), qf[:, 2 * W:].reshape(T, heads, hd)
+    outs = []
+    for b0, b1 in zip(cu[:-1], cu[1:]):
+        p_ = torch.softmax(torch.einsum("qhd,khd->hqk", qq[b0:b1], kk[b0:b1]) * hd ** -0.5, -1)
+        outs.append(torch.einsum("hqk,khd->qhd", p_, vv[b0:b1]).reshape(b1 - b0, W))
+    (torch.cat(outs) * do.float()).sum().backward()
+    ref = qf.grad
+    for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, 3 * W))):
+        e_pad = float((dqkv[:, sl].float() - ref[:, sl]).abs().max() / ref[:, sl].abs().max())
+        e_80 = float((dqkv80[:, sl].float() - ref[:, sl]).abs().max() / ref[:, sl].abs().max())
+        measured(f"vit_padded_d128_{name}_rel", e_pad)
+        assert e_pad < 8.0e-3 and e_80 < 8.0e-3, (name, e_pad, e_80)
+
+
 @pytest.mark.parametrize("lens,n_q,n_kv,D,causal", [
     ([5], 2, 1, 128, True), ([130, 64, 1, 257], 4, 2, 128, True), ([200, 77], 7, 1, 128, True),
     ([64, 64, 16, 48], 4, 4, 80, False), ([300], 2, 2, 80, False), ([100, 33], 2, 1, 128, False),

@@ -434,12 +434,13 @@ class Qwen25VL:
                            None if pk.logit_distinct is None else t(pk.logit_distinct, I32), pairs=_seg_pairs(pk))
 
     # ---------------------------------------------------------------- vision tower
-    # ViT attention has head dim 80.  Its own kernels (attn_fwd_kernel<80>: register-staged, ~90 TF/s) are fine for the 64-token
-    # windows; the full-attention blocks (whole images: 1344 patches at the STVQA shape, 4096 at 896 px) go through the D = 128 kernels
-    # (LDS-DMA staged, MFMA 32x32x16, ~600 TF/s) on heads zero-padded to 128: the pad contributes 0 to q.k and its V columns are 0, so
-    # the first 80 output dims are the same attention, computed at 1.6x the flops and ~6x the rate.  VIT_PAD_MIN_SEQ: shortest
-    # sequence for which the two pad copies pay.
-    VIT_PAD_MIN_SEQ = 512
+    # ViT attention has head dim 80.  Whole-image blocks (1344 patches at the STVQA shape, 4096 at 896 px) can run on the D = 128 kernels
+    # (LDS-DMA staged, MFMA 32x32x16) with heads zero-padded to 128: the pad contributes 0 to q.k and its V columns are 0, so the first 80
+    # output dims are the same attention at 1.6x the flops.  Measured incl. the pad / slice copies (tools/vit_attn_ab.py, TF/s on the
+    # D = 80 flops): backward 131-144 -> 222-372 at 1024..4096 patches; forward 321 -> 320 at 1344, 353 -> 468 at 4096, slower at 1024.
+    # Hence two thresholds; forward and backward may use different kernels (lse and O agree within the kernels' own bf16 noise).
+    VIT_PAD_MIN_SEQ = 2048          # forward
+    VIT_PAD_MIN_SEQ_BWD = 512       # backward
 
     def _vit_pad(self, x3: torch.Tensor) -> torch.Tensor:
         """(Np, k, heads, 80) view -> contiguous (Np, k*heads*128) with zero pad"""
@@ -464,7 +465,7 @@ class Qwen25VL:
     def _vit_attn_bwd(self, qkv, a, da, lse, cu, mx, dqkv, pairs):
         c = self.cfg
         heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
-        if hd < 128 and mx >= self.VIT_PAD_MIN_SEQ:
+        if hd < 128 and mx >= self.VIT_PAD_MIN_SEQ_BWD:
             Np, W = qkv.shape[0], heads * 128
             qp = self._vit_pad(qkv.view(Np, 3, heads, hd))
             ap, dap = self._vit_pad(a.view(Np, 1, heads, hd)), self._vit_pad(da.view(Np, 1, heads, hd))

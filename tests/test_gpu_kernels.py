@@ -415,7 +415,7 @@ def test_vit_full_attention_through_the_d128_kernels_on_padded_heads(ops, measur
     T = qkv_h.shape[0]
     qkv = qkv_h.cuda()
     me = types.SimpleNamespace(cfg=types.SimpleNamespace(v_heads=heads, v_head_dim=hd, v_hidden=heads * hd), v_scale=hd ** -0.5,
-                               VIT_PAD_MIN_SEQ=Qwen25VL.VIT_PAD_MIN_SEQ, _vit_pad=lambda x: Qwen25VL._vit_pad(None, x))
+                               VIT_PAD_MIN_SEQ=512, VIT_PAD_MIN_SEQ_BWD=512, _vit_pad=lambda x: Qwen25VL._vit_pad(None, x))
     a = torch.zeros(T, heads * hd, dtype=torch.bfloat16, device="cuda")
     lse = Qwen25VL._vit_attn_fwd(me, qkv, dev(cu), max(lens), a, None)
     xf = qkv_h.float()

@@ -2,7 +2,7 @@
 # HBM traffic of the bench's dominant kernels, rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE separately; kernel trace + counters only):
 #   training GEMM class: `bench.py --steps 1 --warmup 0 --no-cpu-baseline` with counter collection restricted to the GEMM kernels
 #       (--kernel-include-regex; counters on every kernel of the run serialise ~600k launches and take > 30 min per pass);
-#   decode iteration: tools/gen_flat.py (64 prompts x 8 rollouts, 512 live rows, 40 iterations, twice), every kernel.
+#   decode iteration: tools/gen_flat.py 6 64 8 (64 prompts x 8 rollouts, 512 live rows, 5 decode iterations, twice), every kernel.
 # Summarised per kernel, then profiles-ready JSON (tools/make_traffic_json.py).  Run from the repo root on the GPU box; the program
 # sits directly after `--`.
 cd /tmp && export TMPDIR=/tmp
@@ -17,8 +17,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_bench_$c.json
   rm -rf $d
   d=/tmp/pmc_dec_$c
-  (cd /tmp && PYTHONPATH=$root timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o x -- python3 $root/tools/gen_flat.py 40 64 8 > $root/gpurun_out/dec_traffic_$c.log 2>&1) || tail -5 $root/gpurun_out/dec_traffic_$c.log
+  rm -rf $d
+  timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o x -- python3 tools/gen_flat.py 6 64 8 > gpurun_out/dec_traffic_$c.log 2>&1 || tail -5 gpurun_out/dec_traffic_$c.log
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_dec_$c.json
   rm -rf $d
 done
-python3 tools/make_traffic_json.py gpurun_out/pmc_bench_FETCH_SIZE.json gpurun_out/pmc_bench_WRITE_SIZE.json gpurun_out/bench_traffic_FETCH_SIZE.json gpurun_out/r03_gemm_traffic.json gpurun_out/pmc_dec_FETCH_SIZE.json gpurun_out/pmc_dec_WRITE_SIZE.json
+python3 tools/make_traffic_json.py gpurun_out/pmc_bench_FETCH_SIZE.json gpurun_out/pmc_bench_WRITE_SIZE.json gpurun_out/bench_traffic_FETCH_SIZE.json gpurun_out/r03_gemm_traffic.json gpurun_out/pmc_dec_FETCH_SIZE.json gpurun_out/pmc_dec_WRITE_SIZE.json 10

@@ -31,7 +31,7 @@ for k in set(F) | set(W):
         tr_bytes += f + w
         tr_launch += n if not k.startswith("gemm_a4_finish_kernel") else 0
         per_kernel[k[:90]] = {"launches": n, "hbm_bytes_per_launch": (f + w) / max(n, 1)}
-dec_its = 2 * 39                                              # two generate() calls of 40 new tokens: 39 decode iterations each
+dec_its = int(sys.argv[7]) if len(sys.argv) > 7 else 10        # decode iterations of the probe (tools/gen_flat.py 6 64 8: two calls x 5 iterations)
 dec_kernels = {}
 for k in set(DF) | set(DW):
     if not k.startswith(DECODE):
@@ -46,7 +46,7 @@ res = {"kernel_source_sha16": bench.gemm_source_sha(), "command": "rocprofv3 --k
        "hbm_bytes_per_launch": tr_bytes / max(tr_launch, 1), "launches": tr_launch, "algorithmic_bytes_per_launch": alg,
        "traffic_over_algorithmic": (tr_bytes / max(tr_launch, 1)) / alg if alg else None,
        "decode_hbm_bytes_per_iteration": dec_bytes / its if its else None, "decode_iterations": its,
-       "decode_command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} -- python3 tools/gen_flat.py 40 64 8   (512 live rows, 1102-token prompts)",
+       "decode_command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} -- python3 tools/gen_flat.py 6 64 8   (from the repo root; 512 live rows, 1102-token prompts, 2 x 5 decode iterations)",
        "decode_top_kernels": dict(sorted(dec_kernels.items(), key=lambda kv: -kv[1])[:6]),
        "top_kernels": dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["launches"] * kv[1]["hbm_bytes_per_launch"])[:6])}
 json.dump(res, open(out, "w"), indent=1)

@@ -615,7 +615,10 @@ def main():
                    "achieved": bw / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": max(bw / PEAK_HBM, tf / PEAK_BF16),
                    "hbm": {"achieved_GBps": bw / 1e9, "peak_GBps": PEAK_HBM / 1e9, "frac": bw / PEAK_HBM},
                    "mfma": {"achieved_TFLOPs": tf / 1e12, "peak_TFLOPs": PEAK_BF16 / 1e12, "frac": tf / PEAK_BF16},
-                   "traffic": dec_traffic, "iterations": st["decode_steps"], "ms_per_iteration": st["decode_s"] / st["decode_steps"] * 1e3,
+                   "traffic": dec_traffic,
+                   "traffic_source": ("profiles/r03_gemm_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per iteration of a 512-row decode phase "
+                                      "(tools/gen_flat.py 6 64 8); this run's mean live rows are below that") if dec_traffic else None,
+                   "iterations": st["decode_steps"], "ms_per_iteration": st["decode_s"] / st["decode_steps"] * 1e3,
                    "mean_rows_per_iteration": st["decode_row_steps"] / st["decode_steps"],
                    "algorithmic_bytes": "every LM weight once per iteration + K/V of the live context (prompt K/V once per prompt)",
                    "algorithmic_flops": "2 flop per LM weight and row + 4*D flop per (query head, cached key)"}

@@ -57,6 +57,8 @@ def parse():
                     help="max_response_length of the synthetic batch (scripts/spatialthinker_7b_grpo.sh:34: 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
+    ap.add_argument("--master-fp32", action="store_true", help="the reference's default actor dtype pair: fp32 master weights + fp32 AdamW moments "
+                    "(worker.actor.fsdp.torch_dtype unset, optim.strategy=adamw) instead of the shipped scripts' bf16 + AnyPrecisionAdamW")
     ap.add_argument("--fuse-micro-batches", type=int, default=None, help="reference micro-batches per forward/backward pass (default: engine default)")
     ap.add_argument("--no-recompute-light", action="store_true", help="keep the RMSNorm / SwiGLU outputs for the backward instead of recomputing them (+50 %% activation memory per packed token)")
     ap.add_argument("--tokens-grad", type=int, default=None, help="packed-token budget of an update pass (default: engine default, ST_TOKENS_GRAD)")
@@ -435,9 +437,11 @@ def main():
     micro = 4
     n_opt = 4 if B % (4 * micro) == 0 else 1
     hyper = ActorHyper(micro_batch_size_per_device_for_update=micro, micro_batch_size_per_device_for_experience=a.experience_micro_batch,
-                       global_batch_size_per_device=B // n_opt)
+                       global_batch_size_per_device=B // n_opt, **({"optim_strategy": "adamw"} if a.master_fp32 else {}))
     actor_store = ParamStore(cfg, trainable=True)
     actor_store.init_random(seed=7)
+    if a.master_fp32:
+        actor_store.enable_fp32_master()
     ref_store = ParamStore(cfg, trainable=False)
     ref_store.flat.copy_(actor_store.flat)
     actor = PolicyEngine(cfg, actor_store, hyper)

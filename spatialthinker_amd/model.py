@@ -24,6 +24,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -358,6 +360,7 @@ class Qwen25VL:
         self.scale = D ** -0.5
         self.v_scale = cfg.v_head_dim ** -0.5
         self.recompute_light = False     # see _lm_layer_fwd
+        self.unfused_swiglu_with_grad = os.environ.get("ST_SWIGLU_UNFUSED_GRAD", "1") != "0"      # see _lm_layer_fwd
         self.fp8 = False                 # config #5: the LM's four projection GEMMs run forward in MX-fp8 (enable_fp8)
 
     def enable_fp8(self, on: bool = True):
@@ -595,7 +598,14 @@ class Qwen25VL:
             if save is None:
                 gu = None
         else:
-            gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)  # SwiGLU in the epilogue; gate|up kept only for backward
+            if save is not None and self.unfused_swiglu_with_grad and h2.shape[0] > 256:
+                # with gradients the backward needs gate|up, and a GEMM epilogue that stores m AND gate|up (192 KiB per tile instead of
+                # 128) costs more than the stand-alone SwiGLU pass over the kept gate|up (tools/swiglu_ab.py, T = 21504: 4.45-4.54 ms
+                # fused vs 3.90-4.05 + 0.42); bit-identical either way (tests/test_gpu_kernels.py)
+                gu = ops.gemm_nt(h2, w[p + "gu_w"])
+                m = ops.swiglu_fwd(gu)
+            else:
+                gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)  # SwiGLU in the epilogue (no-grad passes: m only)
         x2 = self._linear(m, p + "down_w", residual=x1)
         if save is not None:
             # h1, h2 (RMSNorm outputs) and m (SwiGLU output) are cheap row-wise functions of tensors that are kept anyway: with

@@ -60,9 +60,11 @@ class VLConfig:
 
 
 def rms_norm(x, w, eps):
-    """HF :65-79.  fp32 here, so the `.to(input_dtype)` round-trip is the identity."""
-    var = x.pow(2).mean(-1, keepdim=True)
-    return w * (x * torch.rsqrt(var + eps))
+    """HF :65-79: statistics in fp32, `.to(input_dtype)` before the weight.  For fp32 inputs (the oracle proper) both casts are the
+    identity; with bf16 tensors on a GPU the same code is the "plain torch bf16 evaluation" yardstick of tests/test_gpu_depth.py."""
+    xf = x.to(torch.float32)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    return w * (xf * torch.rsqrt(var + eps)).to(x.dtype)
 
 
 def rotate_half(x):
@@ -106,7 +108,7 @@ def dense_attention(q, k, v, cu_seqlens, causal: bool):
         if causal:
             L = b - a
             s = s.masked_fill(torch.ones(L, L, dtype=torch.bool, device=s.device).triu(1), float("-inf"))
-        out[a:b] = torch.matmul(torch.softmax(s, dim=-1), vs).transpose(0, 1)
+        out[a:b] = torch.matmul(torch.softmax(s, dim=-1, dtype=torch.float32).to(vs.dtype), vs).transpose(0, 1)   # HF eager: fp32 softmax
     return out
 
 
@@ -118,7 +120,7 @@ def vision_tower(p: Dict[str, torch.Tensor], cfg: VLConfig, pixel_values: torch.
     unit = cfg.v_merge ** 2
     N = pixel_values.shape[0]
     w_pe = p[pre + "patch_embed.proj.weight"].reshape(cfg.v_hidden, -1)           # Conv3d k=s => GEMM (:99-122)
-    x = pixel_values.to(torch.float32) @ w_pe.t()
+    x = pixel_values.to(w_pe.dtype) @ w_pe.t()                                      # HF :118 casts the pixels to the weight dtype
     if taps is not None:
         taps["patch_embed"] = x.detach().clone()
     win_idx, cu_win = P.vision_window_index(grid_thw, merge_size=cfg.v_merge, window_size=cfg.v_window,
@@ -131,7 +133,7 @@ def vision_tower(p: Dict[str, torch.Tensor], cfg: VLConfig, pixel_values: torch.
     rot = (pos.to(torch.float32)[:, :, None] * inv_freq[None, None, :]).flatten(1)  # (N, hd/2)
     rot = rot.reshape(N // unit, unit, -1)[win_idx_t].reshape(N, -1)
     emb = torch.cat((rot, rot), dim=-1)
-    cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]
+    cos, sin = emb.cos()[:, None, :].to(x.device, x.dtype), emb.sin()[:, None, :].to(x.device, x.dtype)
     cu_full = P.vision_cu_seqlens(grid_thw)
     for i in range(cfg.v_depth):
         x = vit_block(p, cfg, i, x, cos, sin, cu_full if i in cfg.v_fullatt else cu_win)
@@ -180,6 +182,7 @@ def forward_logits(p: Dict[str, torch.Tensor], cfg: VLConfig, input_ids: torch.T
         x = x.clone()
         x[mask] = img.to(x.dtype)                                                   # masked_scatter :1209-1215
     cos, sin = mrope_cos_sin(position_ids, cfg.head_dim, cfg.rope_theta, cfg.mrope_section)
+    cos, sin = cos.to(x.dtype), sin.to(x.dtype)                                     # HF :536-538 (identity for the fp32 oracle)
     for i in range(cfg.num_layers):
         x = lm_layer(p, cfg, i, x, cos, sin, cu_seqlens)
         if taps is not None:
@@ -296,10 +299,10 @@ def response_log_probs(p, cfg: VLConfig, input_ids_2d, attention_mask_2d, positi
     ids = input_ids_2d.reshape(-1)[flat_idx]
     pos = position_ids_3d.permute(1, 0, 2).reshape(3, -1)[:, flat_idx]            # (B,3,S)->(3,B*S)
     lens = valid.sum(-1)
-    cu = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    cu = torch.cat([lens.new_zeros(1), lens.cumsum(0)])
     logits = forward_logits(p, cfg, ids, pos, cu, pixel_values, grid_thw) / temperature
     labels = torch.roll(ids, -1)
-    logp = torch.log_softmax(logits, dim=-1).gather(-1, labels[:, None])[:, 0]
-    full = torch.zeros(B * S, dtype=logp.dtype)
+    logp = torch.log_softmax(logits.to(torch.float32), dim=-1).gather(-1, labels[:, None])[:, 0]
+    full = torch.zeros(B * S, dtype=logp.dtype, device=logp.device)
     full[flat_idx] = logp
     return full.reshape(B, S)[:, -response_length - 1:-1]

@@ -597,8 +597,79 @@ def gen_dataset():
     save("dataset", **out)
 
 
+
+# ------------------------------------------------------------------ 8. the actor update loop (dp_actor.update_policy on a toy LM)
+def gen_update_loop():
+    """The reference's DataParallelPPOActor.update_policy (verl/workers/actor/dp_actor.py:155-167, 212-292) run HERE on CPU around
+    tests/golden/toy_lm.ToyLM, with torch.optim.SGD and the reference's get_constant_schedule_with_warmup stepped once per call as
+    fsdp_workers.py:453-455 does.  Four consecutive calls: lr = 0 on the first (scheduler quirk), warm-up on the second, clipping active,
+    and an infinite advantage in the fourth (non-finite gradient norm: the optimizer step is skipped).  Stand-ins (recorded here, none of
+    them computes anything): ray / tensordict are stubbed for the import, the batch is a duck-typed DataProto (select / split by rows).
+    No flash-attn in this container, so log_probs_from_logits takes the reference's torch fallback, which returns +cross-entropy
+    (SURVEY.md 0.7); the test's logp_fn uses the same quantity — the loop is agnostic to it."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    stub("ray", ObjectRef=object, get=lambda x: x)
+    stub("ray.experimental")
+    stub("ray.experimental.tqdm_ray", tqdm=lambda it, **kw: it)
+    stub("tensordict", TensorDict=dict)
+    stub("tensordict.tensorclass", NonTensorData=object)
+    from verl.utils.torch_functional import get_constant_schedule_with_warmup
+    from verl.workers.actor.dp_actor import DataParallelPPOActor
+    import toy_lm
+
+    class Proto:
+        def __init__(self, batch, meta):
+            self.batch, self.non_tensor_batch, self.meta_info = batch, {}, meta
+
+        def select(self, keys, nt_keys):
+            return Proto({k: self.batch[k] for k in keys}, self.meta_info)
+
+        def split(self, n):
+            N = next(iter(self.batch.values())).shape[0]
+            return [Proto({k: v[i:i + n] for k, v in self.batch.items()}, self.meta_info) for i in range(0, N, n)]
+
+    cfg = types.SimpleNamespace(global_batch_size_per_device=4, micro_batch_size_per_device_for_update=2, ppo_epochs=1, padding_free=False,
+                                ulysses_sequence_parallel_size=1, use_kl_loss=True, disable_kl=False, kl_penalty="low_var_kl", kl_coef=0.05,
+                                clip_ratio_low=0.2, clip_ratio_high=0.3, clip_ratio_dual=3.0, max_grad_norm=0.05, use_torch_compile=False)
+    params = toy_lm.make_params()
+    model = toy_lm.ToyLM(params)
+    opt = torch.optim.SGD(model.parameters(), lr=0.2)
+    sched = get_constant_schedule_with_warmup(opt, num_warmup_steps=2)
+    actor = DataParallelPPOActor(cfg, model, opt)
+    ids, mask, P, R = toy_lm.make_data()
+    T = 0.8
+    rs = np.random.RandomState(9)
+    with torch.no_grad():
+        lg = toy_lm.logits_fn({k: torch.from_numpy(v) for k, v in params.items()}, torch.from_numpy(ids))[:, -R - 1:-1] / T
+        lp0 = torch.nn.functional.cross_entropy(lg.reshape(-1, toy_lm.V), torch.from_numpy(ids[:, -R:]).reshape(-1), reduction="none").view(-1, R).numpy()
+    old = (lp0 + 0.25 * rs.standard_normal(lp0.shape)).astype(np.float32)
+    ref = (lp0 + 0.3 * rs.standard_normal(lp0.shape)).astype(np.float32)
+    adv = (rs.standard_normal((ids.shape[0], 1)).astype(np.float32) * 2.0).repeat(R, 1) * mask[:, -R:]
+    out = dict(input_ids=ids, attention_mask=mask, old_log_probs=old, ref_log_probs=ref, advantages=adv, temperature=np.float32(T),
+               R=np.int64(R), lr=np.float32(0.2), warmup=np.int64(2))
+    out.update({"p0_" + k: v for k, v in params.items()})
+    t = torch.from_numpy
+    for call in range(4):
+        a = adv.copy()
+        if call == 3:
+            a[5, 0] = np.inf
+        pos = np.broadcast_to(np.arange(ids.shape[1]), ids.shape).copy()
+        data = Proto(dict(responses=t(ids[:, -R:].copy()), input_ids=t(ids), attention_mask=t(mask), position_ids=t(pos), old_log_probs=t(old),
+                          advantages=t(a), ref_log_probs=t(ref)), {"temperature": T})
+        met = actor.update_policy(data)
+        sched.step()
+        for k, v in met.items():
+            out[f"c{call}_" + k.replace("/", "_")] = np.asarray(v, dtype=np.float64)
+        out[f"c{call}_lr"] = np.float64(sched.get_last_lr()[0])
+        for k, v in model.state_dict().items():
+            out[f"c{call}_p_" + k] = v.detach().numpy().copy()
+    save("update_loop", **out)
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset", "generate"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset", "generate", "loop"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -615,3 +686,5 @@ if __name__ == "__main__":
         gen_dataset()
     if "generate" in which:
         gen_generate()
+    if "loop" in which:
+        gen_update_loop()

@@ -162,6 +162,54 @@ def dry_run(a):
         dist.destroy_process_group()
 
 
+def preflight(rank: int, world: int, local: int, need_gb: float, timeout_s: float = 120.0):
+    """Before the first RCCL collective of an N-GPU run: everything that would otherwise show up as a HANG is checked and turned into a
+    message + non-zero exit — enough visible devices, peer access between this rank's GPU and every other one (xGMI / PCIe P2P: RCCL's
+    direct transports), enough free HBM on this rank for the replica design (weights + fp32 grads + AdamW state + frozen reference),
+    and one tiny all-reduce under a watchdog (a rank that never arrives, a wedged transport).  Rank 0 prints one summary line
+    (RCCL version, free GB per rank).  The watchdog ends the PROCESS (os._exit) — it never re-execs anything: a process that has touched
+    the GPU must not exec (the launcher's torchrun parent then tears the other ranks down)."""
+    import threading
+    problems = []
+    n_dev = torch.cuda.device_count()
+    if n_dev < world:
+        problems.append(f"{world} ranks but only {n_dev} visible GPUs")
+    else:
+        no_peer = [j for j in range(world) if j != local and not torch.cuda.can_device_access_peer(local, j)]
+        if no_peer:
+            problems.append(f"GPU {local} has no peer access to GPUs {no_peer} (RCCL would fall back to host staging or hang)")
+    free_b, total_b = torch.cuda.mem_get_info()
+    if free_b / 2 ** 30 < need_gb:
+        problems.append(f"only {free_b / 2 ** 30:.0f} GB free of {total_b / 2 ** 30:.0f} GB on GPU {local}, the workload needs ~{need_gb:.0f} GB")
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout_s):
+            sys.stderr.write(f"[bench preflight] rank {rank}: the first all-reduce did not complete within {timeout_s:.0f} s "
+                             f"(a rank missing or an RCCL transport wedged) — aborting\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    flag = torch.tensor([float(len(problems) > 0), free_b / 2 ** 30], device="cuda", dtype=torch.float64)
+    gathered = [torch.zeros_like(flag) for _ in range(world)]
+    dist.all_gather(gathered, flag)
+    torch.cuda.synchronize()
+    done.set()
+    bad = [i for i, g in enumerate(gathered) if float(g[0]) > 0]
+    if problems:
+        sys.stderr.write(f"[bench preflight] rank {rank}: " + "; ".join(problems) + "\n")
+    if rank == 0:
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = "unknown"
+        sys.stderr.write(f"[bench preflight] RCCL {ver}, {world} ranks, free GB per rank: {[round(float(g[1]), 1) for g in gathered]}"
+                         + (f", FAILED on ranks {bad}" if bad else ", ok") + "\n")
+    if bad:
+        dist.destroy_process_group()
+        raise SystemExit(4)
+
+
 # ------------------------------------------------------------------ synthetic STVQA-shaped data
 def synth_prompts(cfg, n_prompts, rs, P, grid, text_before=200, text_after=564):
     from spatialthinker_amd import indexing as ix
@@ -216,14 +264,14 @@ def cpu_baseline():
     a BOUNDED SAMPLE of ~25 s in two legs, each timing WHOLE passes over a 4-layer model (not one layer multiplied out):
       leg 1 = BASELINE config #1 (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image = 256 patches = 64 image tokens, 700 text
               tokens, 512-token responses): a 4-LM-layer / 4-ViT-block model on 1 of the 8 sequences — no-grad pass (old / ref),
-              forward + backward (update), final norm + tied lm_head + log-softmax on the response rows, 16 KV-cache decode steps of
-              the 4 layers for the 8 rollouts, AdamW-Kahan on 2M parameters; scaled by layers (36 / 4, 32 / 4), sequences (8 / 1),
+              forward + backward (update), final norm + tied lm_head + log-softmax on the response rows, 6 KV-cache decode steps of
+              the 4 layers for the 8 rollouts, AnyPrecisionAdamW's torch ops on 16M bf16 parameters; every component is the MEDIAN of 3
+              runs after a warm-up; scaled by layers (36 / 4, 32 / 4), sequences (8 / 1),
               decode steps (512 / 16) and parameters to the full step;
       leg 2 = truncated BASELINE config #3 (7B widths): a no-grad pass of 4 LM layers over one 1614-token STVQA-shaped sequence, so
               the CPU number exists at the GPU line's own widths (reported as forward tokens/s per layer-normalised pass)."""
     from oracle import positions as OP
     from oracle import qwen25vl as Q
-    from oracle import rl_math as M
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:                                                    # honour the container's CPU quota (cgroup v2)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -253,11 +301,20 @@ def cpu_baseline():
             p["model.language_model.norm.weight"] = torch.ones(H)
         return p
 
-    def timed(fn, reps=1):
-        best = 1e30
+    REPS = 3
+    spread = {}
+
+    def timed(fn, name, reps=REPS, warmup=1):
+        """median of `reps` runs after `warmup` untimed ones (round 3's single-rep timings moved 2x between boxes: first-touch page
+        faults and the thread pool's start-up landed inside the one timed run); the min / max of the reps go into `spread`"""
+        for _ in range(warmup):
+            fn()
+        ts = []
         for _ in range(reps):
-            t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
-        return best
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        spread[name] = [ts[0], ts[-1]]
+        return ts[len(ts) // 2]
 
     # ---------------------------------------------------------------- leg 1: config #1 (3B widths)
     L_LM, L_VIT, G, n_prompt, P_txt, n_img_tok, R = 36, 32, 4, 2, 700, 64, 512
@@ -292,10 +349,10 @@ def cpu_baseline():
 
     with torch.no_grad():
         Q.lm_layer(p, c, 0, x[:S], cos[:S], sin[:S], [0, S])                          # warm-up: thread pool, allocator
-        t_lm_f = timed(lambda: lm_pass(x))
+        t_lm_f = timed(lambda: lm_pass(x), "lm_4_layers_fwd")
     grad_on(lm_names, True)
     xg = x.clone().requires_grad_(True)
-    t_lm_fb = timed(lambda: lm_pass(xg).sum().backward())
+    t_lm_fb = timed(lambda: lm_pass(xg).sum().backward(), "lm_4_layers_fwd_bwd")
     grad_on(lm_names, False)
     # ViT: the reference runs the tower per sequence (one 16x16-patch image each)
     grid = np.asarray([[1, 16, 16]] * NSEQ)
@@ -310,10 +367,10 @@ def cpu_baseline():
         return xx
     vit_names = [k for k in p if k.startswith("model.visual.blocks.")]
     with torch.no_grad():
-        t_vit_f = timed(lambda: vit_pass(xv))
+        t_vit_f = timed(lambda: vit_pass(xv), "vit_4_blocks_fwd")
     grad_on(vit_names, True)
     xvg = xv.clone().requires_grad_(True)
-    t_vit_fb = timed(lambda: vit_pass(xvg).sum().backward())
+    t_vit_fb = timed(lambda: vit_pass(xvg).sum().backward(), "vit_4_blocks_fwd_bwd")
     grad_on(vit_names, False)
     # final norm + tied lm_head + log-softmax on the response rows (dp_actor.py:126-153)
     rows = NSEQ * R
@@ -321,14 +378,14 @@ def cpu_baseline():
     lab = torch.randint(0, V, (rows,), generator=gen)
     head_fn = lambda xx: torch.log_softmax(Q.lm_head(p, c, xx), -1).gather(-1, lab[:, None]).sum()
     with torch.no_grad():
-        t_head_f = timed(lambda: head_fn(xr))
+        t_head_f = timed(lambda: head_fn(xr), "head_fwd")
     emb = p["model.language_model.embed_tokens.weight"]
     emb.requires_grad_(True)
     xrg = xr.clone().requires_grad_(True)
-    t_head_fb = timed(lambda: head_fn(xrg).backward())
+    t_head_fb = timed(lambda: head_fn(xrg).backward(), "head_fwd_bwd")
     emb.requires_grad_(False); emb.grad = None
     # generation: KV-cache decode of the 4 layers, all 8 rollouts of the step in one batch, 16 tokens at a ~1000-token context
-    Bd, ctx, n_dec = n_prompt * G, P_txt + n_img_tok + R // 2, 16
+    Bd, ctx, n_dec = n_prompt * G, P_txt + n_img_tok + R // 2, 6
     kc = [torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen) for _ in range(LS)]
     vc = [torch.randn(Bd, ctx + n_dec, c.num_kv_heads, D, generator=gen) for _ in range(LS)]
     xd = torch.randn(Bd, H, generator=gen) * 0.1
@@ -342,15 +399,31 @@ def cpu_baseline():
                 h = Q.lm_layer_decode(p, c, i, h, cd, sd, kc[i], vc[i], ln)
             ln = ln + 1
     with torch.no_grad():
-        t_dec = timed(dec) / n_dec                           # per decode step of 4 layers
-        t_dec_head = timed(lambda: Q.lm_head(p, c, xd).argmax(-1))
-    # AdamW (AnyPrecisionAdamW with bf16 states + Kahan, the oracle's numpy restatement) on 2M parameters
-    n_par = 1 << 21
-    rs = np.random.RandomState(0)
-    opt = M.AdamWKahanBF16(scalar_mode="cpu")
-    pa, ga = rs.standard_normal(n_par).astype(np.float32) * 0.02, rs.standard_normal(n_par).astype(np.float32) * 1e-3
-    pa = opt.step(pa, ga)
-    t_adam = timed(lambda: opt.step(pa, ga))
+        t_dec = timed(dec, "decode_step_4_layers") / n_dec   # per decode step of 4 layers
+        spread["decode_step_4_layers"] = [v / n_dec for v in spread["decode_step_4_layers"]]
+        t_dec_head = timed(lambda: Q.lm_head(p, c, xd).argmax(-1), "decode_head_step")
+    # AdamW: AnyPrecisionAdamW's arithmetic (verl/utils/torch_functional.py:253-329: decoupled decay, bf16 exp_avg / exp_avg_sq, Kahan
+    # compensation buffer) as torch ops on bf16 CPU tensors — what the reference's optimizer would execute on the host — over 16M
+    # parameters (round 3 timed the oracle's numpy bf16 EMULATION here, 10 % of the CPU step for an artefact of the checker)
+    n_par = 1 << 24
+    pa = (torch.randn(n_par, generator=gen) * 0.02).bfloat16()
+    ga = (torch.randn(n_par, generator=gen) * 1e-3).bfloat16()
+    ma, va, ca = torch.zeros_like(pa), torch.zeros_like(pa), torch.zeros_like(pa)
+    step_t = torch.tensor(0.0)
+
+    def adam():
+        b1, b2, lr, wd, eps = 0.9, 0.999, 1e-6, 1e-2, 1e-8
+        step_t.add_(1)
+        pa.mul_(1 - lr * wd)
+        ma.mul_(b1).add_(ga, alpha=1 - b1)
+        va.mul_(b2).addcmul_(ga, ga, value=1 - b2)
+        step_size = lr / (1 - b1 ** step_t)
+        denom = (va.sqrt() / (1 - b2 ** step_t) ** 0.5).add_(eps)
+        ca.addcdiv_(ma, denom, value=-float(step_size))
+        prev = pa.clone()
+        pa.add_(ca)
+        ca.add_(prev.sub_(pa))
+    t_adam = timed(adam, "adamw_16M_params")
     n_params_3b = 3.75e9
     seq_scale, lm_scale, vit_scale = (n_prompt * G) / NSEQ, L_LM / LS, L_VIT / LS
     fwd = seq_scale * (lm_scale * t_lm_f + vit_scale * t_vit_f + t_head_f)             # one no-grad pass over the 8 sequences
@@ -373,20 +446,21 @@ def cpu_baseline():
             xx = Q.lm_layer(p7, c7, i, xx, cos7, sin7, [0, S7])
         return xx
     with torch.no_grad():
-        t7 = timed(lambda: lm7(x7))
+        t7 = timed(lambda: lm7(x7), "cfg3_7b_widths_4_layers_fwd_1614_tokens", reps=2)
     del p7
     fwd7_per_sample = t7 * 28 / LS                            # the 28 LM layers of one 1614-token sample (ViT + head excluded)
     return {"value": n_prompt * G / step_s, "unit": "samples/s (full GRPO step: gen + old + ref + update + AdamW)", "cores": threads, "kind": "port",
             "sample": f"leg 1 = config #1 shape (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image -> 64 image tokens, 700 text tokens, 512-token "
                       f"responses), fp32 torch oracle, whole passes over a {LS}-LM-layer / {LS}-ViT-block model on {NSEQ} of the 8 sequences ({T} tokens): "
                       f"no-grad pass, forward+backward, final norm + tied lm_head + log-softmax on {rows} response rows, {n_dec} KV-cache decode steps "
-                      f"of the {LS} layers for the 8 rollouts, AdamW-Kahan on 2M parameters; scaled by layers ({L_LM}/{LS}, {L_VIT}/{LS}), sequences "
+                      f"of the {LS} layers for the 8 rollouts, AnyPrecisionAdamW's torch op sequence on 16M bf16 parameters; every component = median of {REPS} runs after a warm-up; scaled by layers ({L_LM}/{LS}, {L_VIT}/{LS}), sequences "
                       f"(8/{NSEQ}), 512 decode steps, 3.75B parameters.  leg 2 = truncated config #3: no-grad pass of {LS} LM layers at 7B widths over "
                       f"one {S7}-token sequence",
             "timing_s": {"gen": gen_s, "old": fwd, "ref": fwd, "update_actor": fb, "adamw": adam_s},
             "measured_s": {"lm_4_layers_fwd": t_lm_f, "lm_4_layers_fwd_bwd": t_lm_fb, "vit_4_blocks_fwd": t_vit_f, "vit_4_blocks_fwd_bwd": t_vit_fb,
                            "head_fwd": t_head_f, "head_fwd_bwd": t_head_fb, "decode_step_4_layers": t_dec, "decode_head_step": t_dec_head,
-                           "adamw_2M_params": t_adam, "cfg3_7b_widths_4_layers_fwd_1614_tokens": t7},
+                           "adamw_16M_params": t_adam, "cfg3_7b_widths_4_layers_fwd_1614_tokens": t7},
+            "reps": REPS, "statistic": "median after one warm-up run", "spread_min_max_s": spread,
             "value_excl_generation_and_adamw": n_prompt * G / (2 * fwd + fb),
             "config3_truncated": {"widths": "Qwen2.5-VL-7B", "forward_s_per_sample_28_lm_layers": fwd7_per_sample,
                                   "forward_samples_per_s": 1.0 / fwd7_per_sample,
@@ -407,7 +481,9 @@ def main():
     assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=600))
+        preflight(rank, world, local, need_gb={"7b": 215.0, "3b": 120.0}.get(a.model, 1.0))
     from spatialthinker_amd import ops
     from spatialthinker_amd.actor import ActorHyper, PolicyEngine
     from spatialthinker_amd.model import ParamStore, VLConfig
@@ -554,6 +630,8 @@ def main():
     gen.stats = {k: 0 for k in gen.stats}
     ops.gemm_bytes.update(on=True, bytes=0.0, launches=0)
     torch.cuda.synchronize()
+    if actor.grad_reducer() is not None:
+        actor._exchange_stats_at_start = actor.grad_reducer().stats()          # the warm-up steps' exchanges are not part of the timed region
     if world > 1:
         dist.barrier()
     t_start = time.perf_counter()
@@ -570,11 +648,18 @@ def main():
         ops.prof_disable(k)
         prof[k] = (seen, n_launch, ms, units)
     phase_max = dict(phase)
+    red = actor.grad_reducer()
+    xs = red.stats() if red is not None else None
+    xs0 = getattr(actor, "_exchange_stats_at_start", None)
+    if xs is not None and xs0 is not None:
+        xs = {k: xs[k] - xs0[k] for k in xs}
+    exch = [xs["allreduce_s"], xs["allreduce_exposed_s"]] if xs else [0.0, 0.0]
     if world > 1:
-        t = torch.tensor([elapsed] + [phase[k] for k in phase], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed] + [phase[k] for k in phase] + exch, device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
         phase_max = {k: float(t[1 + i].item()) for i, k in enumerate(phase)}
+        exch = [float(t[-2].item()), float(t[-1].item())]
     if rank == 0:
         samples = B * world * a.steps
         actor_t = phase["old"] + phase["ref"] + phase["update_actor"]
@@ -639,6 +724,13 @@ def main():
                        "global_batch": B * world, "seq_len": P + R, "parallelism": f"dp{world}"},
             "timing_s": {k: v / a.steps for k, v in phase.items()},
             "timing_s_max_over_ranks": {k: v / a.steps for k, v in phase_max.items()},
+            # gradient exchange per step (max over ranks; device events on the compute stream, actor.GradReducer): the whole exchange from the
+            # first layer slice sent during the last backward pass to the averaged gradients, and the part of it NOT hidden behind the
+            # backward (the compute stream's wait inside finish()); 0 at N = 1 (no process group, no exchange)
+            "allreduce_s": exch[0] / a.steps, "allreduce_exposed_s": exch[1] / a.steps,
+            "grad_exchange": ({"mode": red.mode, "payload": red.payload, "exchanges_per_step": xs["exchanges"] / a.steps,
+                               "early_fraction": xs["early_fraction"] / max(1, xs["exchanges"]), "bytes_per_exchange": actor_store.grad.numel() * (4 if red.payload == "fp32" else 2),
+                               "staging_allocations": red.pool.allocations, "staging_gb": red.pool.allocated_bytes / 2 ** 30} if red is not None else None),
             "perf_throughput_tokens_per_s_per_gpu": tokens_total[0] / elapsed,
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,

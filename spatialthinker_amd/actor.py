@@ -51,6 +51,31 @@ class ActorHyper:
     freeze_vision_tower: bool = False       # fsdp_workers.py:226-232: the ViT gets no gradient and no optimizer update
 
 
+class _StagePool:
+    """Staging buffers of the gradient exchange, allocated once and recycled (round 4).  Round 3's reducer allocated a zero-filled send
+    buffer + a receive buffer per 512-MB bucket (direct schedule) or a bf16 copy per bucket (bf16 payload) on EVERY optimizer step — tens
+    of GB of caching-allocator traffic per step at 7B next to a pool already at ~220 GB reserved.  A buffer goes back to the pool when the
+    collective that used it has been waited for; take() hands out a free buffer of the right size / dtype or allocates one (only during
+    the first optimizer step: the slices of a step are the same every time)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[tuple, list] = defaultdict(list)
+        self.allocated_bytes = 0
+        self.allocations = 0
+
+    def take(self, numel: int, dtype) -> torch.Tensor:
+        lst = self.free[(numel, dtype)]
+        if lst:
+            return lst.pop()
+        self.allocations += 1
+        self.allocated_bytes += numel * torch.empty((), dtype=dtype).element_size()
+        return torch.empty(numel, dtype=dtype, device=self.device)
+
+    def give(self, buf: torch.Tensor):
+        self.free[(buf.numel(), buf.dtype)].append(buf)
+
+
 class GradReducer:
     """Sum-exchange of the flat fp32 gradient buffer in slices, some of them early.
 
@@ -69,8 +94,14 @@ class GradReducer:
                         all-gather returns the reduced shards.  Each byte crosses a link once per phase: 2 x (W-1)/W of the
                         bucket in total per GPU, spread over W-1 links in parallel.
     payload "bf16" (ActorHyper.grad_exchange_dtype; the reference's FSDP knob is `mp_reduce_dtype`, fp32 by default) sends bf16-rounded
-    contributions and bf16-rounded sums (half the bytes); sums are still formed in fp32.  The AdamW kernels round the gradient to bf16
-    anyway (the dtype the reference's optimizer sees), so only the clip-norm and the pre-sum rounding differ."""
+    contributions (half the bytes).  Where the sum is formed depends on the mode: "reduce_scatter" upcasts the received shards and adds
+    them in fp32 (then rounds the sum to bf16 for the all-gather); "allreduce" hands the bf16 buffer to RCCL, which accumulates IN bf16 —
+    the same arithmetic as FSDP's reduce_dtype=bf16.  The AdamW kernels round the gradient to bf16 anyway (the dtype the reference's
+    optimizer sees), so only the clip-norm and the rounding before / inside the sum differ.
+
+    Timing (round 4, bench.py `allreduce_s` / `allreduce_exposed_s`): device events on the compute stream bracket (a) the whole exchange —
+    first slice sent .. gradients final — and (b) the part of it the compute stream spends inside finish() (what the overlap did NOT
+    hide); stats() reads the events of the steps finished so far."""
 
     def __init__(self, grad: torch.Tensor, world: int, group=None, bucket_elems: int = 1 << 27, mode: str = "allreduce", payload: str = "fp32"):
         assert mode in ("allreduce", "reduce_scatter") and payload in ("fp32", "bf16"), (mode, payload)
@@ -83,16 +114,44 @@ class GradReducer:
         # the post-processing of the direct schedule (shard sums, all-gathers) runs on a side stream so that a collective still in
         # flight never stalls the backward kernels queued on the compute stream
         self.side = torch.cuda.Stream(device=grad.device) if grad.is_cuda else None
+        self.pool = _StagePool(grad.device)
+        self._t_first = None              # event (CUDA) / perf_counter (CPU) of the first slice sent in the current exchange
+        self._timers: list = []           # (first, finish_begin, finish_end) per finished exchange, not yet read
+        self.totals = {"exchanges": 0, "allreduce_s": 0.0, "allreduce_exposed_s": 0.0, "early_fraction": 0.0}
+
+    def _mark(self):
+        if self.grad.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def stats(self) -> Dict[str, float]:
+        """Totals over the exchanges finished so far (synchronises on their events)."""
+        for first, b, e, early in self._timers:
+            if self.grad.is_cuda:
+                e.synchronize()
+                tot, exp = first.elapsed_time(e) * 1e-3, b.elapsed_time(e) * 1e-3
+            else:
+                tot, exp = e - first, e - b
+            self.totals["exchanges"] += 1
+            self.totals["allreduce_s"] += tot
+            self.totals["allreduce_exposed_s"] += exp
+            self.totals["early_fraction"] += early
+        self._timers = []
+        return dict(self.totals)
 
     # ---- plain all-reduce
     def _send_allreduce(self, lo: int, hi: int):
         for o in range(lo, hi, self.bucket):
             sl = self.grad[o:min(hi, o + self.bucket)]
             if self.payload == "bf16":
-                buf = sl.to(torch.bfloat16)
-                self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), sl, buf))
+                buf = self.pool.take(sl.numel(), torch.bfloat16)
+                buf.copy_(sl)                                            # fp32 -> bf16 into the recycled staging buffer
+                self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), sl, buf, (buf,)))
             else:
-                self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, None))
+                self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, None, ()))
 
     # ---- direct reduce-scatter + all-gather
     def _ctx(self):
@@ -109,9 +168,11 @@ class GradReducer:
                 e = min(hi, o + self.bucket)
                 n = e - o
                 per = -(-n // W)
-                send = torch.zeros(W * per, dtype=dt, device=self.grad.device)
+                send = self.pool.take(W * per, dt)
                 send[:n].copy_(self.grad[o:e])
-                recv = torch.empty_like(send)
+                if W * per > n:
+                    send[n:].zero_()                                    # the ragged tail of the last shard (recycled buffer: stale data)
+                recv = self.pool.take(W * per, dt)
                 work = dist.all_to_all_single(recv, send, group=self.pg, async_op=True)      # recv[j*per:(j+1)*per] = rank j's shard for me
                 self.pending.append((o, e, per, send, recv, work))
 
@@ -121,12 +182,18 @@ class GradReducer:
         with self._ctx():
             for (o, e, per, send, recv, work) in self.pending:
                 work.wait()
-                acc = recv.view(W, per)[0].float()
+                acc = self.pool.take(per, torch.float32)
+                acc.copy_(recv.view(W, per)[0])
                 for j in range(1, W):                                   # rank order: the same fp32 sum on every rank
-                    acc = acc + recv.view(W, per)[j].float()
-                mine = acc.to(send.dtype)
+                    acc.add_(recv.view(W, per)[j])
+                staged = [send, recv, acc]
+                mine = acc
+                if send.dtype != torch.float32:
+                    mine = self.pool.take(per, send.dtype)
+                    mine.copy_(acc)
+                    staged.append(mine)
                 full = send                                             # reuse as the gather target
-                self.works.append((dist.all_gather_into_tensor(full, mine, group=self.pg, async_op=True), self.grad[o:e], full))
+                self.works.append((dist.all_gather_into_tensor(full, mine, group=self.pg, async_op=True), self.grad[o:e], full, tuple(staged)))
         self.pending = []
 
     def _send(self, lo: int, hi: int):
@@ -143,11 +210,17 @@ class GradReducer:
             assert hi <= a or lo >= b, f"gradient slice [{lo},{hi}) announced twice (overlaps [{a},{b}))"
         self.sent.append((lo, hi))
         self.early_elems += hi - lo
+        if self._t_first is None:
+            self._t_first = self._mark()
         if self.mode == "reduce_scatter" and self.pending:
             self._drain_direct()                                        # earlier slices: sum + all-gather while backward continues
         self._send(lo, hi)
 
     def finish(self):
+        t_begin = self._mark()
+        if self._t_first is None:
+            self._t_first = t_begin
+        early = self.early_elems / max(1, self.grad.numel())
         pos = 0
         for a, b in sorted(self.sent):
             if a > pos:
@@ -158,14 +231,18 @@ class GradReducer:
         if self.pending:
             self._drain_direct()
         with self._ctx():
-            for w, dst, buf in self.works:
+            for w, dst, buf, staged in self.works:
                 w.wait()
                 if dst is not None:
                     dst.copy_(buf[:dst.numel()])                        # bf16 payload / gathered shards back into the fp32 buffer
+                for b_ in staged:                                       # the next user's copy is ordered behind this one on the same stream
+                    self.pool.give(b_)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         self.sent, self.works, self.early_elems = [], [], 0
         self.grad.mul_(1.0 / self.world)                          # FSDP reduce-scatter averages over ranks
+        self._timers.append((self._t_first, t_begin, self._mark(), early))
+        self._t_first = None
 
 
 def release_cached_blocks():

@@ -14,6 +14,7 @@
 // Roofline: MFMA-bound, 2*M*N*K flop per launch.
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define BM 128
 #define BN 128
@@ -328,9 +329,22 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
 // production tile of the training-shape GEMMs: 40 = 4 waves x 128x128 with the hand-scheduled K loop (gemm_asm4.hip; round 3: in the
 // bench 1248 vs 1185 TF/s for the GEMM class, 16.1 vs 15.7 samples/s), 23 = 8 waves x 64x128 (mid-tile barrier, LDS-staged epilogue).
 // ST_GEMM_VARIANT / st_gemm_select override it (A/B runs).
-int g_train_variant = [] { const char* e = getenv("ST_GEMM_VARIANT"); return e ? atoi(e) : 40; }();
+static bool train_variant_ok(int v) { return v == 23 || v == 40 || v == 6 || v == 8 || v == 31; }
+// the environment override goes through the same whitelist as st_gemm_select: anything else (in particular the debug variants 41-47,
+// timing experiments with WRONG results, reachable only through st_gemm_nt_variant) falls back to the production tile with a notice
+int g_train_variant = [] {
+    const char* e = getenv("ST_GEMM_VARIANT");
+    if (!e) return 40;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || !train_variant_ok((int)v)) {
+        fprintf(stderr, "[st_hip] ST_GEMM_VARIANT=%s is not a production tile (23, 40, 6, 8, 31): using 40\n", e);
+        return 40;
+    }
+    return (int)v;
+}();
 extern "C" int st_gemm_select(int variant) {
-    if (variant != 23 && variant != 40 && variant != 6 && variant != 8 && variant != 31) return ST_EINVAL;
+    if (!train_variant_ok(variant)) return ST_EINVAL;
     g_train_variant = variant;
     return 0;
 }
@@ -349,8 +363,11 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     // tile choice (tools/gemm_shapes.py on MI355X, all 12 fwd/dX/dW shapes of a 7B layer): the 256x256 tile (8 waves, 128 KiB LDS,
     // 128 flop/B of L2 traffic) wins or ties from ~0.5 workgroups per CU upwards (dW of the 3584x3584 projection, 196 tiles:
     // 1098 vs 926 TF); only smaller problems fill the chip better with 128x128 tiles at 2 workgroups/CU.
-    if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 128)
-        return st_gemm_tile_dispatch(g_train_variant, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);
+    if ((int64_t)st_cdiv(M, 256) * st_cdiv(N, 256) >= 128) {
+        // the 4-wave tile addresses an operand tile through 32-bit buffer offsets: row pitches of 2^22 elements and more take the 8-wave tile
+        const int v = (g_train_variant == 40 && (lda >= (1 << 22) || ldb >= (1 << 22))) ? 23 : g_train_variant;
+        return st_gemm_tile_dispatch(v, A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, accumulate, M, N, K, s);
+    }
 #define GO(HB, HR, OB, OF, AC) return launch_gemm<HB, HR, OB, OF, AC>(A, lda, B, ldb, bias, residual, ldr, out_bf16, out_f32, ldc, M, N, K, s)
     if (out_bf16) {
         if (hb && hr) GO(true, true, true, false, false);

@@ -198,6 +198,9 @@ class ParamStore:
         fp32 AdamW moments; `flat` stays the bf16 working copy every kernel computes with (= FSDP's param_dtype=bf16 all-gather) and is
         re-rounded from the master by st_adamw_master_step.  12 bytes per parameter of state instead of 6 (bf16 m / v / Kahan)."""
         assert self.trainable
+        # NOTE: built from the bf16 working copy; a caller that wants the master to carry a checkpoint's own fp32 values enables the
+        # master FIRST and loads afterwards (load_hf_state_dict then fills the master from the fp32 tensors and rounds `flat` from
+        # it) — pretrained.load_model(master_fp32=True) and FSDPWorker.init_model do
         self.master = self.flat.float()
         self.m = torch.zeros(self.numel, dtype=F32, device=self.device)
         self.v = torch.zeros(self.numel, dtype=F32, device=self.device)

@@ -62,11 +62,15 @@ def hf_config_dict(cfg: VLConfig, special: Dict[str, int]) -> dict:
     }
 
 
-def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7) -> Tuple[VLConfig, ParamStore, Dict[str, int]]:
+def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7, master_fp32: bool = False) -> Tuple[VLConfig, ParamStore, Dict[str, int]]:
+    """master_fp32: enable the fp32 master BEFORE the weights are loaded, so that an fp32 checkpoint's own values reach the master (the
+    reference keeps them: fp32 shards under MixedPrecision(param_dtype=bf16)); enabling it afterwards would start from bf16-rounded weights."""
     if model_path.startswith("random:"):
         cfg, special = synthetic_config(model_path)
         store = ParamStore(cfg, device=device, trainable=trainable)
         store.init_random(seed=seed)
+        if master_fp32:
+            store.enable_fp32_master()
         store.hf_config, store.generation_config, store.source_dir = hf_config_dict(cfg, special), {"eos_token_id": special["eos"], "pad_token_id": special["pad"]}, None
         return cfg, store, special
     model_path = resolve_model_path(model_path)
@@ -74,6 +78,8 @@ def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7) -
         hf = json.load(f)
     cfg = VLConfig.from_hf_dict(hf)
     store = ParamStore(cfg, device=device, trainable=trainable)
+    if master_fp32:
+        store.enable_fp32_master()
     from safetensors.torch import load_file
     sd: Dict[str, torch.Tensor] = {}
     for shard in sorted(glob.glob(os.path.join(model_path, "*.safetensors"))):

@@ -181,3 +181,48 @@ def test_update_policy_announces_layer_slices_only_on_the_last_pass_of_each_opti
         assert len(a[r]["steps"]) == 2
         for g in a[r]["steps"]:
             torch.testing.assert_close(g, torch.full_like(g, 2 * (1 + 2) / 2.0))     # two passes x (1 + 2) summed over ranks / world
+
+
+def _pool_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spatialthinker_amd.actor import GradReducer
+    n = 300_007
+    res = {}
+    for mode, payload in (("reduce_scatter", "fp32"), ("reduce_scatter", "bf16"), ("allreduce", "bf16"), ("allreduce", "fp32")):
+        grad = torch.randn(n, generator=torch.Generator().manual_seed(300 + rank))
+        red = GradReducer(grad, world, None, bucket_elems=100_000, mode=mode, payload=payload)
+        allocs = []
+        for step in range(3):                                 # three optimizer steps on one reducer: slices early + the remainder
+            grad.copy_(torch.randn(n, generator=torch.Generator().manual_seed(300 + rank + 10 * step)))
+            red.ready(200_000, n)
+            red.ready(100_000, 200_000)
+            red.finish()
+            allocs.append((red.pool.allocations, red.pool.allocated_bytes))
+        st = red.stats()
+        res[(mode, payload)] = dict(allocs=allocs, stats=st, grad=grad.clone(), free=sum(len(v) for v in red.pool.free.values()))
+    torch.save(res, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_staging_buffers_are_allocated_once_and_exchange_timing_is_reported(tmp_path):
+    """Round-4 hardening of the N > 1 path: the staging buffers of the direct / bf16 exchanges come from a pool that stops growing after
+    the first optimizer step (no allocator traffic per step), every buffer is back in the pool after finish(), and stats() reports one
+    exchange per finish() with exposed <= total time."""
+    world = 2
+    mp.spawn(_pool_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f"p{r}.pt", weights_only=False)
+        for (mode, payload), v in res.items():
+            a = v["allocs"]
+            assert a[1] == a[0] and a[2] == a[0], (mode, payload, a)                 # steps 2 and 3 allocate nothing
+            if mode == "allreduce" and payload == "fp32":
+                assert a[0] == (0, 0)                                                # in-place all-reduce: no staging at all
+            else:
+                assert a[0][0] > 0 and v["free"] == a[0][0]                          # every staging buffer went back to the pool
+            st = v["stats"]
+            assert st["exchanges"] == 3 and 0.0 <= st["allreduce_exposed_s"] <= st["allreduce_s"] + 1e-9
+            assert abs(st["early_fraction"] / 3 - 200_007 / 300_007) < 1e-6
+            want = sum(torch.randn(300_007, generator=torch.Generator().manual_seed(300 + q + 20)) for q in range(world)) / world
+            tol = dict(rtol=1e-6, atol=1e-7) if payload == "fp32" else dict(rtol=2e-2, atol=2e-2)
+            torch.testing.assert_close(v["grad"], want, **tol)

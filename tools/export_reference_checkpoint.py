@@ -35,8 +35,9 @@ def main(src: str, out: str, world: int):
             for hf_name, t in store.export_hf(views).items():
                 per.setdefault(hf_name, {"step": torch.tensor(float(opt["opt_steps"]))})[key] = t
         optim_state, steps, sched = per, int(opt["opt_steps"]), int(opt["sched_steps"])
-    export_reference_layout(sd, optim_state, out, world, opt_steps=steps, sched_steps=sched)
-    print(f"wrote {world} x (model, optim, extra_state) shard files to {out}")
+    keep_optim = os.environ.get("ST_EXPORT_OPTIM", "0") == "1"      # name-keyed optimizer files: this build's own format (the reference cannot load them)
+    export_reference_layout(sd, optim_state, out, world, opt_steps=steps, sched_steps=sched, write_optim=keep_optim)
+    print(f"wrote {world} x (model, extra_state{', optim' if keep_optim else ''}) shard files to {out} (transformers-4.49 parameter names, no rng entry)")
 
 
 if __name__ == "__main__":

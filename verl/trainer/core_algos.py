@@ -72,8 +72,9 @@ class _PolicyLoss(torch.autograd.Function):
                                clip_low=lo, clip_high=hi, clip_dual=dual, kl_kind="kl", kl_coef=0.0, grad_accum=1.0)
         ctx.save_for_backward(g.view(log_probs.shape).to(log_probs.device))
         m = met.to(log_probs.device)
-        ctx.mark_non_differentiable(m[1], m[2], m[3])
-        return m[0].clone(), m[1].clone(), m[2].clone(), m[3].clone()
+        outs = [m[i].clone() for i in range(4)]
+        ctx.mark_non_differentiable(*outs[1:])               # on the tensors actually returned: the three statistics carry no grad_fn
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_loss, *_):

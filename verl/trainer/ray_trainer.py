@@ -338,9 +338,12 @@ class RayPPOTrainer:
         self.actor_rollout_wg.load_checkpoint(os.path.join(p, "actor"))
         dl = os.path.join(p, "dataloader.pt")
         if os.path.exists(dl):
-            st = torch.load(dl, weights_only=False)
-            self.kl_ctrl.kl_coef = st.get("kl_coef", self.kl_ctrl.kl_coef)
-            self.train_dataloader.load_state_dict(st["dataloader"] if "dataloader" in st else st)      # round-2 files nested it
+            try:
+                st = torch.load(dl, weights_only=False)
+                self.kl_ctrl.kl_coef = st.get("kl_coef", self.kl_ctrl.kl_coef)
+                self.train_dataloader.load_state_dict(st["dataloader"] if "dataloader" in st else st)      # round-2 files nested it
+            except Exception as e:           # a reference run's dataloader.pt (StatefulDataLoader snapshot) or an unreadable file: go on
+                print(f"Dataloader state at {dl} is not usable here ({type(e).__name__}: {e}); the data order starts from scratch.")
         else:
             print(f"No dataloader state found at {dl}, will start from scratch.")
 

@@ -1,19 +1,28 @@
 """Interop with the reference's on-disk checkpoint layout (verl/utils/checkpoint/fsdp_checkpoint_manager.py:52-131):
 
     <ckpt>/actor/model_world_size_{W}_rank_{r}.pt         FSDP SHARDED_STATE_DICT: {hf_param_name: DTensor Shard(0) on mesh ("fsdp",)}
-    <ckpt>/actor/optim_world_size_{W}_rank_{r}.pt         sharded optimizer state: {"state": {name: {step, exp_avg, exp_avg_sq,
-                                                           compensation}}, "param_groups": [...]}
-    <ckpt>/actor/extra_state_world_size_{W}_rank_{r}.pt   {"lr_scheduler": LambdaLR.state_dict(), "rng": {...}}
+    <ckpt>/actor/optim_world_size_{W}_rank_{r}.pt         the rank's RAW `optimizer.state_dict()` (:95-96 — FSDP.optim_state_dict is never
+                                                           called): {"state": {0: {step, exp_avg, exp_avg_sq, compensation}, 1: ...},
+                                                           "param_groups": [{"params": [0, 1, ...], ...}]} — INTEGER keys, one entry per
+                                                           FSDP FlatParameter, each tensor the rank-local 1-D shard of that flat parameter
+    <ckpt>/actor/extra_state_world_size_{W}_rank_{r}.pt   {"lr_scheduler": LambdaLR.state_dict(), "rng": {cpu, cuda, numpy, random}}
     <ckpt>/actor/huggingface/                             config + generation config + tokenizer / processor files
 
 This engine keeps full replicas, so its native checkpoint is ONE HF-loadable directory + ONE optimizer file
 (verl/workers/fsdp_workers.py save_checkpoint).  To let a run checkpointed by the reference continue here (and vice versa):
-  * load_reference_checkpoint  — reads all W shard files (unpickling DTensors needs no process group), concatenates the local
-    shards along their placement dimension, maps transformers-4.49 names to the 5.x names, and fills the ParamStore's weights, the
-    AdamW moments / Kahan compensation, the optimizer step and the scheduler position;
-  * export_reference_layout    — writes this engine's state as W rank files of DTensor shards (what scripts/model_merger.py :37-164
-    and FSDPCheckpointManager.load_checkpoint :52-81 expect).  DTensor construction needs a process group of W ranks: a stand-alone
-    process builds them on torch's in-process "fake" backend, one rank at a time (tools/export_reference_checkpoint.py).
+  * load_reference_checkpoint  — reads all W model shard files (unpickling DTensors needs no process group), concatenates the local
+    shards along their placement dimension, maps transformers-4.49 names to the 5.x names, fills the ParamStore's weights and the
+    scheduler position.  OPTIMIZER STATE: the reference's files hold flat-parameter shards keyed by integer (see above); mapping them
+    back to parameters needs the FSDP wrap policy and flattening order of the run that wrote them, which this loader does not
+    reconstruct — such files are recognised, reported, and the AdamW moments / Kahan buffers / step counter start from zero (a
+    resumed run re-warms its moments over the next ~1/(1-beta2) steps; it never crashes and never mixes up tensors).  Name-keyed
+    optimizer files (what export_reference_layout(write_optim=True) writes: this build's own round-trip format) load bit for bit;
+  * export_reference_layout    — writes this engine's weights as W rank files of DTensor shards under the transformers-4.49 names
+    (`visual.*`, `model.*`: what FSDPCheckpointManager.load_checkpoint :52-81 and scripts/model_merger.py :37-164 expect), plus the
+    scheduler position.  No "rng" entry is written (the reference restores it only `if "rng" in extra_state`; an empty one would
+    raise KeyError('cpu')) and, by default, no optimizer files: the reference's Optimizer.load_state_dict accepts only its own
+    integer-keyed flat-shard layout.  DTensor construction needs a process group of W ranks: a stand-alone process builds them on
+    torch's in-process "fake" backend, one rank at a time (tools/export_reference_checkpoint.py).
 The CUDA RNG state of the reference ("rng") has no counterpart: this engine's sampler is counter-based (seed, row, step)."""
 from __future__ import annotations
 
@@ -90,16 +99,47 @@ def normalise_hf_names(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
+def denormalise_hf_names(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The inverse of normalise_hf_names: 5.x / ParamStore names -> the transformers-4.49 names a reference run loads."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("model.visual."):
+            k = k[len("model."):]
+        elif k.startswith("model.language_model."):
+            k = "model." + k[len("model.language_model."):]
+        out[k] = v
+    return out
+
+
 def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
     """Fill `store` (ParamStore) — and, when given, the PolicyEngine's optimizer / scheduler counters — from a checkpoint directory in
-    the reference's layout.  Returns {"world_size", "opt_steps", "sched_steps"}."""
+    the reference's layout.  Returns {"world_size", "opt_steps", "sched_steps", "optimizer"}; "optimizer" is "loaded", "reset" (files
+    in the reference's own flat-shard layout, or unreadable: state starts from zero, with a printed notice) or "absent"."""
     W = find_reference_world_size(path)
     if not W:
         raise FileNotFoundError(f"{path} holds no reference-layout checkpoint (model_world_size_W_rank_r.pt)")
     store.load_hf_state_dict(normalise_hf_names(read_reference_shards(path, "model", W)))
-    info = {"world_size": W, "opt_steps": 0, "sched_steps": 0}
+    info = {"world_size": W, "opt_steps": 0, "sched_steps": 0, "optimizer": "absent"}
     opt_file = os.path.join(path, f"optim_world_size_{W}_rank_0.pt")
     if store.trainable and os.path.exists(opt_file):
+        try:
+            probe = torch.load(opt_file, map_location="cpu", weights_only=False)
+            keys = list((probe.get("state") or {}).keys()) if isinstance(probe, dict) else None
+        except Exception as e:                                        # a file this torch cannot unpickle must not end the run
+            keys, probe = None, None
+            print(f"[checkpoint] cannot read {opt_file} ({type(e).__name__}: {e}); the optimizer state starts from zero")
+        if keys is None or any(not isinstance(k, str) for k in keys):
+            if keys is not None:
+                print(f"[checkpoint] {opt_file} holds the reference's raw per-rank optimizer.state_dict() ({len(keys)} flat-parameter shards keyed "
+                      f"by integer); they are not unflattened here — weights and scheduler position are restored, AdamW moments / Kahan buffers / "
+                      f"step counter start from zero")
+            info["optimizer"] = "reset"
+            for buf in (store.m, store.v, store.c):
+                if buf is not None:
+                    buf.zero_()
+        else:
+            info["optimizer"] = "loaded"
+    if info["optimizer"] == "loaded":
         opt = read_reference_shards(path, "optim", W)
         state = normalise_hf_names(opt.get("state", {}))
         shapes = store.export_hf()                                   # HF name -> view with the parameter's shape
@@ -113,7 +153,7 @@ def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
     extra_file = os.path.join(path, f"extra_state_world_size_{W}_rank_0.pt")
     if os.path.exists(extra_file):
         extra = read_reference_shards(path, "extra_state", W)
-        sched = extra.get("lr_scheduler") or {}
+        sched = (extra.get("lr_scheduler") if isinstance(extra, dict) else None) or {}
         info["sched_steps"] = int(sched.get("last_epoch", 0))
     if engine is not None:
         engine.opt_steps, engine.sched_steps = info["opt_steps"], info["sched_steps"]
@@ -122,9 +162,18 @@ def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
 
 
 def export_reference_layout(hf_state: Dict[str, torch.Tensor], optim_state: Optional[Dict[str, Dict[str, torch.Tensor]]], out_dir: str,
-                            world_size: int, opt_steps: int = 0, sched_steps: int = 0, base_lr: float = 1e-6, hyper: Optional[dict] = None) -> None:
+                            world_size: int, opt_steps: int = 0, sched_steps: int = 0, base_lr: float = 1e-6, hyper: Optional[dict] = None,
+                            write_optim: bool = False, names: str = "hf4") -> None:
     """Write full tensors as the reference's per-rank DTensor shards.  Must run in a process WITHOUT an initialised process group
-    (it brings up torch's "fake" backend once per rank to build the device mesh)."""
+    (it brings up torch's "fake" backend once per rank to build the device mesh).
+    names: "hf4" (default) renames to the transformers-4.49 parameter names a reference run expects; "asis" keeps the given names.
+    write_optim: also write NAME-keyed optimizer files — this build's own round-trip format (load_reference_checkpoint reads them back
+    bit for bit); the reference cannot load them, so they are off by default (a reference run resumed from the export starts its
+    optimizer fresh, exactly as it would from a HF checkpoint)."""
+    if names == "hf4":
+        hf_state = denormalise_hf_names(hf_state)
+        if optim_state is not None:
+            optim_state = denormalise_hf_names(optim_state)
     import torch.distributed as dist
     from torch.distributed.device_mesh import DeviceMesh
     from torch.distributed.tensor import DTensor, Shard
@@ -146,13 +195,14 @@ def export_reference_layout(hf_state: Dict[str, torch.Tensor], optim_state: Opti
             mesh = DeviceMesh("cpu", torch.arange(W), mesh_dim_names=("fsdp",))
             torch.save({k: shard(v.detach().cpu().contiguous(), mesh, r) for k, v in hf_state.items()},
                        os.path.join(out_dir, f"model_world_size_{W}_rank_{r}.pt"))
-            if optim_state is not None:
+            if optim_state is not None and write_optim:
                 st = {n: {k: (shard(t.detach().cpu().contiguous(), mesh, r) if torch.is_tensor(t) and t.dim() > 0 else torch.tensor(float(opt_steps)))
                           for k, t in d.items()} for n, d in optim_state.items()}
                 groups = [dict({"lr": base_lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 1e-2}, **(hyper or {}), params=list(optim_state.keys()))]
                 torch.save({"state": st, "param_groups": groups}, os.path.join(out_dir, f"optim_world_size_{W}_rank_{r}.pt"))
             sched = {"last_epoch": int(sched_steps), "_step_count": int(sched_steps) + 1, "base_lrs": [base_lr], "_last_lr": [base_lr],
                      "lr_lambdas": [None]}
-            torch.save({"lr_scheduler": sched, "rng": {}}, os.path.join(out_dir, f"extra_state_world_size_{W}_rank_{r}.pt"))
+            # no "rng" key: FSDPCheckpointManager restores it only when present (:80-81), and an empty dict there raises KeyError('cpu')
+            torch.save({"lr_scheduler": sched}, os.path.join(out_dir, f"extra_state_world_size_{W}_rank_{r}.pt"))
         finally:
             dist.destroy_process_group()

@@ -68,6 +68,9 @@ class ResumableDataLoader:
                 "batches_yielded": self.batches_yielded, "batch_size": self.batch_size, "num_rows": len(self.dataset)}
 
     def load_state_dict(self, state: Dict[str, Any]) -> None:
+        if not isinstance(state, dict) or "generator_state" not in state:
+            # e.g. the reference's dataloader.pt: a torchdata StatefulDataLoader snapshot (worker / sampler-iterator internals)
+            raise ValueError("not a state of this loader (no `generator_state`): written by another dataloader implementation")
         if state.get("batch_size", self.batch_size) != self.batch_size or state.get("num_rows", len(self.dataset)) != len(self.dataset):
             raise ValueError("dataloader state was saved for a different dataset size or rollout_batch_size")
         self.gen.set_state(state["generator_state"])

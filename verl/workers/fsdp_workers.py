@@ -90,9 +90,8 @@ class FSDPWorker:
                     "weights with torch.optim.AdamW (optim.strategy=adamw, the reference's default pair); AnyPrecisionAdamW on fp32 "
                     "parameters (strategy=adamw_bf16 without torch_dtype=bf16) is not built — every shipped STVQA script passes "
                     "torch_dtype=bf16 with adamw_bf16 (scripts/spatialthinker_7b_grpo.sh:25)")
-            cfg, store, special = load_model(mc.model_path, trainable=True)
+            cfg, store, special = load_model(mc.model_path, trainable=True, master_fp32=master)      # master first: it takes the checkpoint's own fp32 values
             if master:
-                store.enable_fp32_master()
                 self.print_rank0("Actor parameters: fp32 master weights + fp32 AdamW moments, bf16 compute copy (MixedPrecision param_dtype).")
             if mc.freeze_vision_tower:
                 self.print_rank0("Vision tower is set to not trainable.")
@@ -231,8 +230,8 @@ class FSDPWorker:
             # a run checkpointed by the REFERENCE (model_/optim_/extra_state_world_size_W_rank_r.pt, fsdp_checkpoint_manager.py:83-131):
             # every rank reassembles the full weights / optimizer state from all W shard files (whatever this run's world size is)
             info = load_reference_checkpoint(self.actor.store, path, engine=self.actor)
-            self.print_rank0(f"Loaded a reference-layout checkpoint written by {info['world_size']} ranks: optimizer step "
-                             f"{info['opt_steps']}, scheduler step {info['sched_steps']}.")
+            self.print_rank0(f"Loaded a reference-layout checkpoint written by {info['world_size']} ranks: optimizer state {info['optimizer']}, "
+                             f"optimizer step {info['opt_steps']}, scheduler step {info['sched_steps']}.")
             if self.world_size > 1:
                 dist.barrier()
             return

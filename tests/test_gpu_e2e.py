@@ -127,3 +127,41 @@ def test_bench_through_api_prints_the_contract_line():
     assert line["steps"] == 2 and line["value"] > 0 and line["config"]["through_api"] is True
     assert line["prompt_cache_hit"] == 1.0
     assert set(line["timing_s"]) == {"gen", "reward", "old", "ref", "adv", "update_actor"} and line["timing_s"]["update_actor"] > 0
+
+
+def test_main_with_a_real_tokenizer_and_processor(tmp_path):
+    """f-1 end to end: `python -m verl.trainer.main worker.actor.model.model_path=<dir>` where <dir> is a real HF directory (tiny
+    Qwen2.5-VL weights written by save_hf + a PreTrainedTokenizerFast + a Qwen2VLImageProcessor, tests/golden/tiny_hf.py) and the data
+    is the committed STVQA-shaped parquet with real PNG bytes: AutoTokenizer, the Qwen2_5_VLProcessor loader, pretrained.load_model(<dir>),
+    RLHFDataset (chat template -> processor -> pixel_values / image_grid_thw -> M-RoPE ids), rollout, tokenizer.decode -> spatial_sgg,
+    log-probs, update, validation, and a checkpoint that carries the tokenizer / processor files — none of the `random:` branches."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import tiny_hf
+    model_dir = tiny_hf.build_model_dir(str(tmp_path / "model"))
+    data = os.path.join(ROOT, "tests", "golden", "stvqa_tiny")
+    cmd = [sys.executable, "-m", "verl.trainer.main", f"data.train_files={data}@train", f"data.val_files={data}@val", "data.val_batch_size=8",
+           "data.prompt_key=problem", "data.answer_key=answer_option_text", "data.image_key=images", "data.rollout_batch_size=2",
+           "data.max_prompt_length=160", "data.max_response_length=16", f"data.min_pixels={4 * 28 * 28}", f"data.max_pixels={64 * 28 * 28}",
+           f"worker.actor.model.model_path={model_dir}", "worker.actor.global_batch_size=2", "worker.actor.micro_batch_size_per_device_for_update=4",
+           "worker.actor.micro_batch_size_per_device_for_experience=8", "worker.actor.optim.strategy=adamw_bf16", "worker.actor.fsdp.torch_dtype=bf16",
+           "worker.actor.padding_free=true", "worker.rollout.n=4", "worker.reward.score_function=spatial_sgg", "algorithm.use_kl_loss=true",
+           "algorithm.kl_penalty=low_var_kl", "algorithm.kl_coef=1.0e-2", "trainer.max_steps=2", "trainer.total_episodes=2", "trainer.n_gpus_per_node=1",
+           "trainer.val_before_train=true", "trainer.val_generations_to_log=1", "trainer.logger=['console']", f"trainer.save_checkpoint_path={tmp_path}/ckpt"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("step ") and "actor/pg_loss" in l]
+    assert len(lines) == 2, p.stdout[-2000:]
+    for key in ("actor/pg_loss", "actor/kl_loss", "actor/grad_norm", "reward/overall", "reward/format", "timing_s/gen", "timing_s/update_actor",
+                "prompt_length/mean", "response_length/mean"):
+        assert key in lines[-1], key
+    assert "val/reward_score" in p.stdout and "[val generation @ step" in p.stdout
+    import re
+    pl = float(re.search(r"prompt_length/mean:([0-9.eE+]+)", lines[-1]).group(1))
+    assert 60 < pl < 160, lines[-1]                                    # the chat-templated, image-expanded prompts (~80-90 byte tokens)
+    last = (tmp_path / "ckpt" / "latest_global_step.txt").read_text()
+    hf = tmp_path / "ckpt" / f"global_step_{last}" / "actor" / "huggingface"
+    for f in ("model.safetensors", "config.json", "tokenizer.json", "tokenizer_config.json"):
+        assert os.path.exists(hf / f), f                               # the checkpoint is itself a loadable model directory
+    assert os.path.exists(hf / "processor_config.json") or os.path.exists(hf / "preprocessor_config.json")
+    from verl.utils.tokenizer import get_processor, get_tokenizer
+    assert get_tokenizer(str(hf)).eos_token_id == 1014 and get_processor(str(hf)).__class__.__name__ == "Qwen2_5_VLProcessor"

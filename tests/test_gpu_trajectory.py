@@ -126,7 +126,7 @@ def test_three_update_actor_calls_follow_the_oracle_trajectory(measured):
         assert (wn > MAX_NORM).any() or call > 0                      # clipping is active somewhere in the run
     measured("trajectory_metric_max_abs", worst["metric"])
     measured("trajectory_grad_norm_max_rel", worst["norm"])
-    assert worst["metric"] <= 0.05 and worst["norm"] <= 0.15          # first bounds; tightened to 1.3x the measured values
+    assert worst["metric"] <= 0.0147 and worst["norm"] <= 0.0074       # measured 0.0113 (abs, losses of magnitude 0.3 .. 7.7) and 0.0057 (relative)
 
     final = store.export_hf()
     comp = store.export_hf({n: store._view(store.c, n) for n in store.layout})           # the Kahan compensation buffers, HF names
@@ -147,7 +147,12 @@ def test_three_update_actor_calls_follow_the_oracle_trajectory(measured):
         rels.append((float((da - db).norm() / (db.norm() + 1e-20)), name))
         eff.append(float(((a + ca) - (b + cb)).abs().max() / rms))
     rels.sort(reverse=True)
-    print("accumulated update (p + c - w_initial), relative L2 error engine vs oracle, worst tensors:", rels[:5])
+    # a key bias shifts every score of a query by the same amount, which the softmax ignores: the TRUE gradient of k_proj.bias (and of the
+    # k third of the ViT's fused qkv bias) is zero, what both sides accumulate there is rounding noise — reported, not bounded
+    noise = lambda n: n.endswith(("k_proj.bias", "attn.qkv.bias"))
+    print("accumulated update (p + c - w_initial), relative L2 error engine vs oracle; zero-gradient (key-bias) tensors:", [r for r in rels if noise(r[1])][:3])
+    rels = [r for r in rels if not noise(r[1])]
+    print("... worst of the other tensors:", rels[:6])
     print(f"weights: max distance {ulp_max:.2f} bf16 ulps (at max(|w|, rms)), bit-identical fraction min {min(same):.4f} mean {np.mean(same):.4f}; "
           f"fraction of weights the oracle moved: mean {np.mean(moved):.3f}; max |d(p + c)| / rms(w) {max(eff):.2e}")
     measured("trajectory_weight_max_ulps", ulp_max)
@@ -155,4 +160,6 @@ def test_three_update_actor_calls_follow_the_oracle_trajectory(measured):
     measured("trajectory_update_rel_l2_worst", rels[0][0])
     measured("trajectory_update_rel_l2_median", float(np.median([r for r, _ in rels])))
     assert np.mean(moved) > 0.3                                       # the run is long enough to move a good part of the weights off their start
-    assert ulp_max <= 8 and np.mean(same) >= 0.50 and rels[0][0] <= 0.60   # first bounds; tightened to 1.3x the measured values
+    # measured on MI355X: max distance 2.0 ulps, 96.2 % of all weights bit-identical to the oracle's after the 8 optimizer steps, median
+    # relative error of the accumulated update 2.5 %
+    assert ulp_max <= 3.0 and np.mean(same) >= 0.94 and float(np.median([r for r, _ in rels])) <= 0.033 and rels[0][0] <= 0.25

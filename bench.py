@@ -55,6 +55,14 @@ def parse():
                                                   "448x448 / 896x896 -> 256 / 1024 / 4096 patches, with 700 text tokens)")
     ap.add_argument("--response-cap", type=int, default=2048,
                     help="max_response_length of the synthetic batch (scripts/spatialthinker_7b_grpo.sh:34: 2048)")
+    ap.add_argument("--prompt-tokens", type=int, default=None,
+                    help="valid tokens per prompt (text + image tokens + 2 vision markers) instead of the STVQA-shaped ~1102")
+    ap.add_argument("--responses-at-cap", action="store_true", help="every response runs to --response-cap (default: lengths ~ N(512, 128))")
+    ap.add_argument("--worst-case", action="store_true",
+                    help="the shipped scripts' worst-case shape (scripts/spatialthinker_7b_grpo.sh:23,33-34 + config.yaml:11,27-29): 128 prompts/GPU, "
+                         "6144-token prompts, every response at the 2048 cap, ONE untimed-warm-up-free step, then an update_policy over a "
+                         "micro-batch of 4 UNRELATED 8192-token rows; reports peak allocated / reserved memory, rollout chunks and passes per step, "
+                         "and exits non-zero with a message (never an OOM traceback) if it does not fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--master-fp32", action="store_true", help="the reference's default actor dtype pair: fp32 master weights + fp32 AdamW moments "
@@ -468,9 +476,41 @@ def cpu_baseline():
                                           "plus generation"}}
 
 
+def unrelated_rows_probe(actor, cfg, rs, P, grid, tb, ta, R, eos_id, temperature):
+    """update_policy over ONE micro-batch of 4 rows that share nothing (4 different prompts + images, each with one response at the cap:
+    4 x (P + R) packed tokens with gradients) — the case `_plan_passes` cannot split (a reference micro-batch is never cut) and shared-prompt
+    packing cannot shrink.  Returns the peak memory of that call."""
+    import dataclasses
+    from verl.workers.rollout import assemble_rollout_batch
+    ids, mask, pos, pix, grids = synth_prompts(cfg, 4, rs, P, grid, tb, ta)
+    resp = torch.from_numpy(rs.randint(0, min(cfg.image_token_id, cfg.vocab_size) - 16, (4, R)).astype(np.int64))
+    out = assemble_rollout_batch(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), resp, 1, eos_id)
+    rmask = out["response_mask"]
+    data = dict(input_ids=out["input_ids"], attention_mask=out["attention_mask"], position_ids=out["position_ids"], responses=out["responses"],
+                multi_modal_inputs=np.array([{"pixel_values": p, "image_grid_thw": g} for p, g in zip(pix, grids)], dtype=object),
+                old_log_probs=torch.full((4, R), -11.9), ref_log_probs=torch.full((4, R), -11.9),
+                advantages=torch.from_numpy(rs.standard_normal((4, 1)).astype(np.float32)).repeat(1, R) * rmask)
+    h0 = actor.h
+    actor.h = dataclasses.replace(h0, global_batch_size_per_device=4, micro_batch_size_per_device_for_update=4)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    try:
+        met = actor.update_policy(data, temperature)
+        torch.cuda.synchronize()
+    finally:
+        actor.h = h0
+    return {"rows": 4, "packed_tokens_with_grad": int(out["attention_mask"].sum()), "passes": len(actor.last_plan.get("update", [])),
+            "seconds": time.perf_counter() - t0, "grad_norm": met["actor/grad_norm"], "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30}
+
+
 # ------------------------------------------------------------------ main
 def main():
     a = parse()
+    if a.worst_case:
+        a.prompts_per_gpu, a.prompt_tokens, a.responses_at_cap, a.response_cap = 128, 6144, True, 2048
+        a.steps, a.warmup, a.no_cpu_baseline = 1, 0, True
     if a.through_api:
         return through_api(a)
     maybe_spawn(a)
@@ -506,6 +546,9 @@ def main():
         w_px, h_px = (int(v) for v in a.image.lower().split("x"))
         grid, (tb, ta) = (1, h_px // cfg.v_patch, w_px // cfg.v_patch), (200, 498)
     n_img = grid[1] * grid[2] // 4
+    if a.prompt_tokens and not tiny:
+        ta = a.prompt_tokens - n_img - 2 - tb
+        assert ta > 0, "--prompt-tokens is smaller than the image + 200 leading text tokens"
     P = (tb + ta + 2 + n_img + 63) // 64 * 64
     R = 64 if tiny else a.response_cap
     G, npr = a.rollouts, a.prompts_per_gpu
@@ -546,6 +589,8 @@ def main():
     for _ in range(a.warmup + a.steps):
         batch_in = synth_prompts(cfg, npr, rs, P, grid, tb, ta)
         lens_in = np.clip(rs.normal(16 if tiny else 512, 4 if tiny else 128, B), 4 if tiny else 64, R).astype(np.int64)
+        if a.responses_at_cap:
+            lens_in = np.full(B, R, dtype=np.int64)
         staged.append((batch_in, lens_in))
 
     def one_step(step_idx, timed):
@@ -635,8 +680,24 @@ def main():
     if world > 1:
         dist.barrier()
     t_start = time.perf_counter()
-    for s in range(a.steps):
-        one_step(a.warmup + s, True)
+    probe = None
+    try:
+        for s in range(a.steps):
+            one_step(a.warmup + s, True)
+        torch.cuda.synchronize()
+        update_passes = len(actor.last_plan.get("update", []))
+        if a.worst_case:
+            probe = unrelated_rows_probe(actor, cfg, rs, P, grid, tb, ta, R, eos_id, temperature)
+    except (torch.OutOfMemoryError, RuntimeError) as e:
+        if not a.worst_case and not isinstance(e, torch.OutOfMemoryError):
+            raise
+        msg = f"{type(e).__name__}: {str(e).splitlines()[0][:400]}"
+        sys.stderr.write(f"[bench] the workload does not fit this GPU: {msg}\n")
+        if rank == 0:
+            print(json.dumps({"metric": "GRPO samples/sec (G=8 rollouts/prompt) Qwen2.5-VL-7B at 1/2/4/8 MI355X", "value": None, "error": msg,
+                              "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
+                              "config": {"workload": f"{name}, G={G}, {npr} prompts/GPU, prompt {tb + ta + 2 + n_img} tokens, max_response_length {R}"}}))
+        raise SystemExit(5)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -735,8 +796,11 @@ def main():
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
             "reserved_gb_after_each_step": reserved_trace,
-            "passes_per_step": {"update": len(actor.last_plan.get("update", [])), "old": len(actor.last_plan.get("experience", [])),
+            "passes_per_step": {"update": update_passes, "old": len(actor.last_plan.get("experience", [])),
                                 "ref": len(ref.last_plan.get("experience", []))},
+            "rollout_prompt_chunks": len(getattr(gen, "last_chunks", [(0, npr)])), "prompt_cache_hit": bool(actor.last_prompt_cache_hit),
+            "prompt_tokens": tb + ta + 2 + n_img, "responses_at_cap": bool(a.responses_at_cap),
+            **({"worst_case": True, "unrelated_rows_probe": probe} if a.worst_case else {}),
             "actor_mfu": (flops["old"] + flops["ref"] + flops["update"]) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "actor_mfu_reference_flops": flops.get("reference_formulation", 0.0) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "roofline": main_roof,

@@ -238,6 +238,11 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
                        [pre_beg, pre_end) of k_pre / v_pre, visited before the own range — lets ONE launch cover the shared-prompt
                        partials (keys in the prompt cache, own range empty) and the per-sample partials (prefix empty) */,
                        st_stream_t stream);
+/* Which kernel st_attn_fwd_ranges uses for decode-shaped launches (n_q == n_kv, items of <= 64 query rows, D = 128): 1 = the persistent
+ * one-workgroup-per-CU kernel (attn_decode128_kernel: the tiles of all of a workgroup's items stream through one 4-slot LDS ring, 3 tiles
+ * in flight per CU; default), 0 = one workgroup per item (attn_fwd128_kernel<false>; also the path of wider items).  Same arithmetic:
+ * bit-identical partials (tests/test_gpu_kernels.py).  The environment variable ST_DECODE_ATTN=items sets the initial value to 0. */
+int st_decode_attn_select(int persistent);
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
 int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows,

@@ -475,6 +475,316 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
 
 
 // =============================================================================================
+// Decode attention, PERSISTENT (round 4).  The one-item-per-workgroup kernel above keeps one 32-KiB K/V tile in flight per workgroup
+// (two workgroups per CU: 64 KiB per CU) and pays ~5 us of prologue per item; decode items are short (a 576-key chunk of a prompt for
+// the 56 query rows of a rollout group, or a <= 512-key chunk of one sample's own cache for its 7 query rows), so the launch ran at
+// ~3.5-4 TB/s with most of its time spent waiting for ONE tile (profiles/r03_decode_pmc.md).  Here ONE workgroup per CU walks a
+// static list of items (w = blockIdx.x, += gridDim.x; w = item * heads + head) and streams the tiles of ALL its items through a
+// single ring in the CU's whole LDS: 4 K/V slots of 32 KiB (3 tiles = 96 KiB in flight per CU while one is consumed) + 2 Q buffers
+// of 16 KiB.  The producer side (all four waves issue their share of every LDS-DMA copy) runs up to 3 tiles and one item ahead of
+// the consumer, so the first tiles — and the Q rows — of the next item are already landing while the current item is finished:
+// no per-item prologue, no empty workgroups (items without keys are skipped by the walk, their lse set to -inf as st_attn_merge expects).
+// Waits are counted: every wave keeps, for the units it has issued and not yet consumed, the number of copies per unit (8 per K/V
+// tile, +4 when the unit also carries the item's Q rows) and waits with s_waitcnt vmcnt(copies issued AFTER the unit it is about to read).
+// Same arithmetic as attn_fwd128_kernel<false> tile for tile (same S^T / softmax / PV sequence): bit-identical partials.
+// Needs max_q <= 64 query rows per item (two row blocks); larger groups (G = 16 rollouts x 7 heads) stay on the kernel above.
+// =============================================================================================
+#define DEC_SLOTS 4
+#define DEC_QBYTES 16384
+#define DEC_LDS_BYTES (DEC_SLOTS * F2_STAGE + 2 * DEC_QBYTES)
+
+template <int N> __device__ __forceinline__ void dec_wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+}
+__device__ __forceinline__ void dec_wait_vm_dyn(int n) {
+    switch (n) {
+        case 0: dec_wait_vm<0>(); break;    case 4: dec_wait_vm<4>(); break;    case 8: dec_wait_vm<8>(); break;
+        case 12: dec_wait_vm<12>(); break;  case 16: dec_wait_vm<16>(); break;  case 20: dec_wait_vm<20>(); break;
+        case 24: dec_wait_vm<24>(); break;  case 28: dec_wait_vm<28>(); break;  case 32: dec_wait_vm<32>(); break;
+        case 36: dec_wait_vm<36>(); break;
+        default: dec_wait_vm<0>(); break;
+    }
+}
+
+struct DecItem {          // one (item, head) of the launch; every field is wave-uniform
+    int seq, h, s0, Lq, sk, L, pb, Lp, n_pre, n_tiles, orow;
+};
+struct DecArgs {          // the launch arguments the helpers need (passed by value: stays in SGPRs)
+    const uint16_t *q, *k, *v, *k_pre, *v_pre;
+    int64_t ldq, ldk, ldv, ldkp, ldvp;
+    const int32_t *q_beg, *q_end, *k_beg, *k_end, *o_beg, *pre_beg, *pre_end;
+    float* lse;
+    int qgroup, T, n_heads, W, G;
+};
+
+// (free functions, not lambdas: closures that capture other closures ended up in scratch memory, and a scratch access is a VMEM
+// operation — it would sit in the same in-order queue as the counted LDS-DMA copies and drain it at every use)
+__device__ __forceinline__ void dec_load_item(const DecArgs& a, int w, DecItem& it) {
+    const int seq = __builtin_amdgcn_readfirstlane(w / a.n_heads);
+    it.seq = seq; it.h = __builtin_amdgcn_readfirstlane(w - seq * a.n_heads);
+    it.s0 = __builtin_amdgcn_readfirstlane(a.q_beg[seq]);
+    it.Lq = __builtin_amdgcn_readfirstlane(a.q_end[seq]) - it.s0;
+    it.sk = __builtin_amdgcn_readfirstlane(a.k_beg[seq]);
+    it.L = max(0, __builtin_amdgcn_readfirstlane(a.k_end[seq]) - it.sk);
+    it.pb = a.pre_beg ? __builtin_amdgcn_readfirstlane(a.pre_beg[seq]) : 0;
+    it.Lp = a.pre_beg ? max(0, __builtin_amdgcn_readfirstlane(a.pre_end[seq]) - it.pb) : 0;
+    it.n_pre = (it.Lp + KV_TILE - 1) / KV_TILE;
+    it.n_tiles = it.Lq > 0 ? it.n_pre + (it.L + KV_TILE - 1) / KV_TILE : 0;
+    it.orow = a.o_beg ? __builtin_amdgcn_readfirstlane(a.o_beg[seq]) : it.s0;
+}
+// next item WITH keys at or after work index w (stride G); items without keys get lse = -inf when `mark` (producer walk only)
+__device__ __forceinline__ bool dec_next_item(const DecArgs& a, int& w, DecItem& it, bool mark) {
+    while (w < a.W) {
+        dec_load_item(a, w, it);
+        w += a.G;
+        if (it.n_tiles > 0) return true;
+        if (mark && (int)threadIdx.x < it.Lq) a.lse[(int64_t)it.h * a.T + it.orow + threadIdx.x] = -INFINITY;
+    }
+    return false;
+}
+// LDS-DMA staging (the copy shapes of attn_fwd128_kernel: K = 4 rows x 16 chunks per instruction, V = 2 sub-tiles of [8 keys][32 d])
+__device__ __forceinline__ void dec_stage_kv(const DecArgs& a, const DecItem& it, int t, char* dst, int wave, int lane, const uint32_t (&koff)[4],
+                                             const uint32_t (&voff)[4]) {
+    constexpr int D = 128;
+    const bool pre = t < it.n_pre;
+    const int kt0 = (pre ? t : t - it.n_pre) * KV_TILE;
+    const int kvh = it.h;                                         // decode launches pass n_q == n_kv: the head IS the KV head
+    if (!pre && kt0 + KV_TILE <= it.L) {                          // full tile of the own keys: uniform base + lane-constant offsets
+        const char* kt = reinterpret_cast<const char*>(a.k + kvh * D + (int64_t)(it.sk + kt0) * a.ldk);
+        const char* vt = reinterpret_cast<const char*>(a.v + kvh * D + (int64_t)(it.sk + kt0) * a.ldv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st_glds16(kt + koff[j], dst + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st_glds16(vt + voff[j], dst + F2_V_OFF + (wave * 4 + j) * 1024);
+        return;
+    }
+    const int row0 = pre ? it.pb : it.sk, Lc = pre ? it.Lp : it.L;
+    const uint16_t* kb_ = (pre ? a.k_pre : a.k) + kvh * D;
+    const uint16_t* vb_ = (pre ? a.v_pre : a.v) + kvh * D;
+    const int64_t ldk_ = pre ? a.ldkp : a.ldk, ldv_ = pre ? a.ldvp : a.ldv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int inst = wave * 4 + j;
+        const int row = inst * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (row & 15);
+        int key = kt0 + row; key = key < Lc ? key : Lc - 1;
+        st_glds16(kb_ + (int64_t)(row0 + key) * ldk_ + c * 8, dst + inst * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int inst = wave * 4 + j;
+        const int u = 2 * inst + (lane >> 5), slot = lane & 31;
+        int key = kt0 + (u >> 2) * 8 + (slot >> 2); key = key < Lc ? key : Lc - 1;
+        st_glds16(vb_ + (int64_t)(row0 + key) * ldv_ + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
+    }
+}
+// the item's Q rows as a 64-row K-shaped image (chunk position = chunk ^ (row & 15)): rows beyond Lq repeat the last one
+__device__ __forceinline__ void dec_stage_q(const DecArgs& a, const DecItem& it, char* dst, int wave, int lane) {
+    constexpr int D = 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int inst = wave * 4 + j;
+        const int row = inst * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (row & 15);
+        const int64_t R = it.s0 + min(row, it.Lq - 1);
+        const uint16_t* qp = a.qgroup > 0 ? a.q + (R / a.qgroup) * a.ldq + ((int64_t)it.h * a.qgroup + R % a.qgroup) * D
+                                          : a.q + R * a.ldq + (int64_t)it.h * D;
+        st_glds16(qp + c * 8, dst + inst * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_decode128_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+                                                               const uint16_t* __restrict__ k, int64_t ldk,
+                                                               const uint16_t* __restrict__ v, int64_t ldv,
+                                                               const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end,
+                                                               const int32_t* __restrict__ k_beg, const int32_t* __restrict__ k_end,
+                                                               const int32_t* __restrict__ o_beg, int qgroup, int T, int n_items, int n_heads,
+                                                               float scale_log2, uint16_t* __restrict__ out, int64_t ldo,
+                                                               float* __restrict__ lse, const int32_t* __restrict__ pre_beg,
+                                                               const int32_t* __restrict__ pre_end,
+                                                               const uint16_t* __restrict__ k_pre, int64_t ldk_pre,
+                                                               const uint16_t* __restrict__ v_pre, int64_t ldv_pre) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    char* const qbuf = dsm + DEC_SLOTS * F2_STAGE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qc = lane & 31, half = lane >> 5;
+    DecArgs a;
+    a.q = q; a.k = k; a.v = v; a.k_pre = k_pre ? k_pre : k; a.v_pre = v_pre ? v_pre : v;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldkp = k_pre ? ldk_pre : ldk; a.ldvp = v_pre ? ldv_pre : ldv;
+    a.q_beg = q_beg; a.q_end = q_end; a.k_beg = k_beg; a.k_end = k_end; a.o_beg = o_beg; a.pre_beg = pre_beg; a.pre_end = pre_end;
+    a.lse = lse; a.qgroup = qgroup; a.T = T; a.n_heads = n_heads; a.W = n_items * n_heads; a.G = gridDim.x;
+
+    uint32_t koff[4], voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int inst = wave * 4 + j;
+        const int row = inst * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+        koff[j] = (uint32_t)(row * (int)ldk + c * 8) * 2u;
+        const int u = 2 * inst + (lane >> 5), slot = lane & 31;
+        voff[j] = (uint32_t)(((u >> 2) * 8 + (slot >> 2)) * (int)ldv + (u & 3) * 32 + (slot & 3) * 8) * 2u;
+    }
+
+    // ---- producer / consumer state
+    int p_w = blockIdx.x, c_w = blockIdx.x;
+    DecItem pit, cit;
+    bool p_open = dec_next_item(a, p_w, pit, true);
+    bool c_open = dec_next_item(a, c_w, cit, false);
+    int p_tile = 0, p_seq = 0, c_tile = 0, c_seq = 0;
+    int produced = 0, consumed = 0;
+    uint64_t fifo = 0;                                             // copies per unit (8 bits each), oldest unit in the low byte
+    // one stream unit = one K/V tile (8 copies per wave) + the item's Q rows in front of its first tile (4 more); the producer
+    // stays within the item after the consumer's (the Q double buffer) and within DEC_SLOTS - 1 units of it (the K/V ring)
+#define DEC_PRODUCE_WHILE(LIMIT)                                                                                                     \
+    while (produced - consumed < (LIMIT) && p_open && p_seq <= c_seq + 1) {                                                         \
+        int cnt_ = 8;                                                                                                               \
+        if (p_tile == 0) { dec_stage_q(a, pit, qbuf + (p_seq & 1) * DEC_QBYTES, wave, lane); cnt_ = 12; }                           \
+        dec_stage_kv(a, pit, p_tile, dsm + (produced & (DEC_SLOTS - 1)) * F2_STAGE, wave, lane, koff, voff);                        \
+        fifo |= (uint64_t)cnt_ << (8 * (produced - consumed));                                                                      \
+        ++produced;                                                                                                                 \
+        if (++p_tile == pit.n_tiles) { p_open = dec_next_item(a, p_w, pit, true); p_tile = 0; ++p_seq; }                            \
+    }
+    DEC_PRODUCE_WHILE(DEC_SLOTS - 1)
+
+    const int k_row_off = qc * 256, k_swz = qc & 15;
+    const int v_lane_off = (4 * half + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)dsm;
+    bf16x8 qf[8];
+    f32x16 o[4];
+    float m_i = -INFINITY, l_i = 0.f;
+
+    while (c_open) {
+        // copies this wave issued AFTER the unit it is about to read may stay in flight
+        int after = 0;
+        for (int i = 1; i < produced - consumed; ++i) after += (int)((fifo >> (8 * i)) & 0xff);
+        dec_wait_vm_dyn(after);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        fifo >>= 8;
+        const int slot = consumed & (DEC_SLOTS - 1);
+        ++consumed;                                                // unit p may enter slot p & 3 once unit p - 4 has been read: p <= c + 3
+        DEC_PRODUCE_WHILE(DEC_SLOTS - 1)
+        const bool active = wave * 32 < cit.Lq;                    // decode: most waves of an item hold no query row at all
+        const int q_idx = wave * 32 + qc;
+        const bool q_ok = q_idx < cit.Lq;
+        if (c_tile == 0 && active) {
+            const char* qp = qbuf + (c_seq & 1) * DEC_QBYTES + (wave * 32 + qc) * 256;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) qf[s2] = *reinterpret_cast<const bf16x8*>(qp + (((2 * s2 + half) ^ k_swz) << 4));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+            m_i = -INFINITY; l_i = 0.f;
+        }
+        if (active) {
+            const bool pre = c_tile < cit.n_pre;
+            const int kt0 = (pre ? c_tile : c_tile - cit.n_pre) * KV_TILE, Lc = pre ? cit.Lp : cit.L;
+            const char* ks = dsm + slot * F2_STAGE;
+            const uint32_t vaddr = smem_lds + slot * F2_STAGE + F2_V_OFF + v_lane_off;
+            uint2 va[8], vb[8];
+            tr_issue8(va, vaddr);
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                const char* kp = ks + kb * 32 * 256 + k_row_off;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (((2 * s2 + half) ^ k_swz) << 4));
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s2], sacc[kb], 0, 0, 0);
+                }
+            }
+            if (kt0 + KV_TILE > Lc) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        sacc[kb][r] = key < Lc ? sacc[kb][r] : -INFINITY;
+                    }
+            }
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+            mx = st_half_max(mx) * scale_log2;
+            const float m_new = fmaxf(m_i, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], scale_log2, -m_use));
+                    sacc[kb][r] = pr;
+                    rs += pr;
+                }
+            rs = st_half_sum(rs);
+            l_i = l_i * alpha + rs;
+            m_i = m_new;
+            if (!__all(alpha == 1.f)) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+            }
+#define DEC_PV_STEP(KS2, VF)                                                                                                         \
+            {                                                                                                                       \
+                constexpr int kb_ = (KS2) >> 1, rb_ = ((KS2) & 1) * 8;                                                              \
+                uint4 pw;                                                                                                           \
+                pw.x = st_pk_bf16(sacc[kb_][rb_ + 0], sacc[kb_][rb_ + 1]);                                                          \
+                pw.y = st_pk_bf16(sacc[kb_][rb_ + 2], sacc[kb_][rb_ + 3]);                                                          \
+                pw.z = st_pk_bf16(sacc[kb_][rb_ + 4], sacc[kb_][rb_ + 5]);                                                          \
+                pw.w = st_pk_bf16(sacc[kb_][rb_ + 6], sacc[kb_][rb_ + 7]);                                                          \
+                const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pw);                                                                  \
+                _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                       \
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(VF[2 * b], VF[2 * b + 1]), pf, o[b], 0, 0, 0);           \
+            }
+            tr_wait8(va);  tr_issue8(vb, vaddr + 4096);   DEC_PV_STEP(0, va)
+            tr_wait8(vb);  tr_issue8(va, vaddr + 8192);   DEC_PV_STEP(1, vb)
+            tr_wait8(va);  tr_issue8(vb, vaddr + 12288);  DEC_PV_STEP(2, va)
+            tr_wait8(vb);                                 DEC_PV_STEP(3, vb)
+#undef DEC_PV_STEP
+        }
+        if (++c_tile == cit.n_tiles) {                            // item finished: normalise and store, then move on
+            if (active && q_ok) {
+                const float inv_l = l_i > 0.f ? 1.f / l_i : 0.f;
+                const int64_t orow = cit.orow + q_idx;
+                uint16_t* op = out + orow * ldo + (int64_t)cit.h * D;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; ++g2) {
+                        const int d = b * 32 + 8 * g2 + 4 * half;
+                        uint2 wv;
+                        wv.x = st_pk_bf16(o[b][4 * g2 + 0] * inv_l, o[b][4 * g2 + 1] * inv_l);
+                        wv.y = st_pk_bf16(o[b][4 * g2 + 2] * inv_l, o[b][4 * g2 + 3] * inv_l);
+                        *reinterpret_cast<uint2*>(op + d) = wv;
+                    }
+                if (half == 0) lse[(int64_t)cit.h * T + orow] = l_i > 0.f ? (m_i + log2f(l_i)) * LN2 : -INFINITY;
+            }
+            c_open = dec_next_item(a, c_w, cit, false);
+            c_tile = 0; ++c_seq;
+        }
+    }
+#undef DEC_PRODUCE_WHILE
+}
+
+
+// =============================================================================================
 // Backward.  Two deterministic kernels (no atomics):
 //   attn_bwd_dq_kernel  — same decomposition as the forward (128 q rows x one head per workgroup); per KV
 //                         tile recomputes S^T, forms dP^T = V dO^T, dS^T = P^T o (dP^T - delta) * scale and
@@ -1293,11 +1603,37 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                            scale, causal, out, ldo, lse, max_seqlen, D == 128 ? ST_K_ATTN_FWD : ST_K_VIT_ATTN, stream);
 }
 
+static int g_decode_attn_persistent = [] { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'i') ? 0 : 1; }();
+int st_decode_attn_select(int persistent) {
+    if (persistent != 0 && persistent != 1) return ST_EINVAL;
+    g_decode_attn_persistent = persistent;
+    return 0;
+}
+
 int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
                        const int32_t* o_beg, int q_group, int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out,
                        int64_t ldo, float* lse, int max_q, const int32_t* pre_beg, const int32_t* pre_end, const st_bf16* k_pre,
                        int64_t ldk_pre, const st_bf16* v_pre, int64_t ldv_pre, st_stream_t stream) {
+    // decode launches (n_q == n_kv heads, items of <= 64 query rows): the persistent one-workgroup-per-CU kernel; ST_DECODE_ATTN=items
+    // keeps the one-item-per-workgroup kernel (A/B runs, and the only path for wider items: G = 16 rollouts x 7 heads)
+    if (g_decode_attn_persistent && D == 128 && n_q == n_kv && max_q <= 64 && q && k && v && q_beg && q_end && k_beg && k_end && out && lse && n_seq > 0 && T_out > 0 &&
+        n_q > 0 && !(ldq & 7) && !(ldk & 7) && !(ldv & 7) && !(ldo & 3) && max_q > 0 && (k_pre == nullptr) == (v_pre == nullptr) &&
+        (!k_pre || (pre_beg && !(ldk_pre & 7) && !(ldv_pre & 7)))) {
+        hipStream_t s = (hipStream_t)stream;
+        static bool configured = false;
+        if (!configured) {
+            hipFuncSetAttribute((const void*)attn_decode128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_BYTES);
+            configured = true;
+        }
+        const int64_t W = (int64_t)n_seq * n_q;
+        const int grid = (int)(W < st_num_cus() ? W : st_num_cus());
+        StProfScope ps(ST_K_DECODE_ATTN, s, 0.0);
+        hipLaunchKernelGGL(attn_decode128_kernel, dim3(grid), dim3(256), DEC_LDS_BYTES, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg,
+                           q_group, T_out, n_seq, n_q, scale * LOG2E, out, ldo, lse, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre);
+        ST_CHECK_LAUNCH();
+        return 0;
+    }
     return attn_fwd_launch(q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, q_group, n_seq, T_out, n_q, n_kv, D, scale, 0, out, ldo,
                            lse, max_q, ST_K_DECODE_ATTN, stream, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre);
 }

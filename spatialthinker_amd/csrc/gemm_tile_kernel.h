@@ -194,7 +194,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         if (tail.mode == 2) bid = tail.full_blocks + blockIdx.x;
         else if (bid >= tail.full_blocks) { piece = bid - tail.full_blocks; bid = tail.full_blocks + piece / tail.split; }
     }
-    {
+    // Split-K slab launches (decode shapes, grid.y = K-slices): tiles AND K-slices share ONE XCD-contiguous order (round 4).  With the
+    // per-slice map below every XCD owned the same tile range in EVERY K-slice, i.e. it read the whole activation operand: 8 x 19 MB
+    // per down-projection at 512 rows, 3x the weights' own traffic (profiles/r03_decode_pmc.md).  Here the work items are numbered
+    // K-slice-major and each XCD takes a contiguous run of them, so an XCD touches one or two K-slices of A and both row tiles of a
+    // weight tile still meet in its L2.
+    int kslice = blockIdx.y;
+    bool flat = false;
+    if constexpr (!SWIGLU) flat = gridDim.y > 1 && tail.mode == 0 && piece < 0;
+    if (flat) {
+        const int Wt = nb * (int)gridDim.y, Lb = (int)blockIdx.y * nb + (int)blockIdx.x;
+        const int xcd = Lb & 7, idx = Lb >> 3, q = Wt >> 3, r = Wt & 7;
+        const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        kslice = item / nb;
+        bid = item - kslice * nb;
+    } else {
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // split-K (decode shapes): grid.y slices of kt_per_split K-tiles, fp32 partial slab per slice (summed by a finish kernel)
-    int kt_begin = blockIdx.y * kt_per_split;
+    int kt_begin = kslice * kt_per_split;
     int nk = min(K / 64 - kt_begin, kt_per_split);
     int ni_lo = 0, ni_hi = TN;                               // column tiles this workgroup finishes (all of them unless mode 2)
     if constexpr (!SWIGLU) {
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tile_kernel(const uint16_t*
     }
     A += AS ? (int64_t)kt_begin * 64 * lda : (int64_t)kt_begin * 64;
     B += BS ? (int64_t)kt_begin * 64 * ldb : (int64_t)kt_begin * 64;
-    if (!OUT_BF16 && !SWIGLU && tail.mode != 2) Cf += blockIdx.y * slab_stride;
+    if (!OUT_BF16 && !SWIGLU && tail.mode != 2) Cf += kslice * slab_stride;
     if constexpr (!KMAJ) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s) if (s < nk) stage(s, smem + s * STAGE);

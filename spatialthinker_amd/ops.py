@@ -611,6 +611,12 @@ def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, sc
     return out, lse
 
 
+def decode_attn_select(persistent: bool):
+    """Kernel behind attn_fwd_ranges for decode-shaped launches: True = persistent one-workgroup-per-CU kernel (default), False = one
+    workgroup per item (st_decode_attn_select; A/B runs and the bit-identity test)."""
+    lib().st_decode_attn_select(1 if persistent else 0)
+
+
 def attn_merge(parts, lse, n_parts, heads, D, out=None, q_group=0):
     rows = parts.shape[0] // n_parts
     o = torch.empty(rows, heads * D, dtype=BF16, device=parts.device) if out is None else out

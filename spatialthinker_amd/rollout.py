@@ -51,12 +51,77 @@ class Generator:
             ops.autotune_decode_gemm(B, [w[f"l.{i}.{name}"] for i in range(L)])
         ops.autotune_decode_gemm(B, head)                      # single weight: only tuned when it alone exceeds the cache
 
+    # ------------------------------------------------------------------ memory plan of one call
+    def rollout_bytes(self, prompt_tokens: int, n_prompts: int, n: int, R: int) -> float:
+        """HBM one generate() call holds at its peak for `n_prompts` prompts of `prompt_tokens` valid tokens in total: prompt K/V of
+        every layer, the per-sample generated K/V [layer][sample][R], the pending logits of every sample, the decode wave's working set
+        (logits + attention partials of <= max_decode_batch rows) and the prefill activations of one chunk (~0.2 MB per packed token)."""
+        c = self.m.cfg
+        width, L, B = c.num_kv_heads * c.head_dim, c.num_layers, n_prompts * n
+        kv_prompt = 2.0 * L * (prompt_tokens + 128) * width * 2
+        kv_gen = 2.0 * L * B * R * width * 2
+        logits = 2.0 * B * c.vocab_size
+        wave = min(B, self.max_decode_batch)
+        work = wave * c.vocab_size * 2.0 * 3 + wave * c.num_heads * c.head_dim * 2.0 * 16
+        prefill = 0.2e6 * min(prompt_tokens, self.prefill_chunk_tokens) * (c.hidden_size / 3584.0)
+        return kv_prompt + kv_gen + logits + work + prefill
+
+    def plan_prompt_chunks(self, lens: np.ndarray, n: int, R: int, budget_bytes: Optional[float] = None) -> List[tuple]:
+        """Cut the prompts of one call into consecutive chunks whose rollouts fit the free HBM (the K/V caches of 128 prompts x 8 rollouts
+        at the shipped scripts' limits — 6144-token prompts, 2048-token responses, scripts/spatialthinker_7b_grpo.sh:23,33-34 — are
+        45 + 120 GB at 7B, next to 131 GB of weights, gradients, optimizer state and the frozen reference).  One chunk = the whole call
+        whenever it fits.  Raises a RuntimeError with the numbers when not even a single prompt's rollouts fit — never an OOM from the
+        middle of the decode loop."""
+        if budget_bytes is None:
+            if not torch.cuda.is_available():
+                return [(0, len(lens))]
+            free_b, _ = torch.cuda.mem_get_info()
+            cached = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()          # blocks the allocator can hand out again
+            budget_bytes = float(os.environ.get("ST_ROLLOUT_MEM_FRACTION", "0.85")) * (free_b + cached)
+        chunks, a = [], 0
+        while a < len(lens):
+            b = a + 1
+            if self.rollout_bytes(int(lens[a:b].sum()), 1, n, R) > budget_bytes:
+                raise RuntimeError(
+                    f"rollout does not fit: prompt {a} ({int(lens[a])} tokens) x {n} rollouts x {R} response tokens needs "
+                    f"{self.rollout_bytes(int(lens[a]), 1, n, R) / 2 ** 30:.1f} GB of K/V cache and logits, {budget_bytes / 2 ** 30:.1f} GB are free "
+                    f"(lower data.max_response_length / worker.rollout.n, or ST_MAX_DECODE)")
+            while b < len(lens) and self.rollout_bytes(int(lens[a:b + 1].sum()), b + 1 - a, n, R) <= budget_bytes:
+                b += 1
+            chunks.append((a, b))
+            a = b
+        return chunks
+
     @torch.no_grad()
-    def generate(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
-                 eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
-                 image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
-                 sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
-                 return_prompt_cache: bool = False):
+    def generate(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, return_prompt_cache: bool = False,
+                 pixel_values: Optional[Sequence] = None, image_grid_thw: Optional[Sequence] = None,
+                 forced_lengths: Optional[np.ndarray] = None, **kw):
+        """generate_chunk() over the whole call when its caches fit the free HBM, otherwise over consecutive chunks of prompts
+        (plan_prompt_chunks).  Samples keep their GLOBAL row ids for the counter RNG, so the tokens do not depend on the chunking.  A
+        chunked call returns no prompt cache (it would have to outlive the chunks): the old-policy pass then recomputes the prompts."""
+        mask_np = np.asarray(attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask)
+        lens = mask_np.sum(1).astype(np.int64)
+        chunks = self.plan_prompt_chunks(lens, n, max_new_tokens)
+        self.last_chunks = chunks
+        if len(chunks) == 1:
+            return self.generate_chunk(input_ids, attention_mask, position_ids, n=n, max_new_tokens=max_new_tokens,
+                                       return_prompt_cache=return_prompt_cache, pixel_values=pixel_values, image_grid_thw=image_grid_thw,
+                                       forced_lengths=forced_lengths, **kw)
+        outs = []
+        for (a, b) in chunks:
+            outs.append(self.generate_chunk(input_ids[a:b], attention_mask[a:b], position_ids[a:b], n=n, max_new_tokens=max_new_tokens,
+                                            return_prompt_cache=False, pixel_values=None if pixel_values is None else pixel_values[a:b],
+                                            image_grid_thw=None if image_grid_thw is None else image_grid_thw[a:b],
+                                            forced_lengths=None if forced_lengths is None else forced_lengths[a * n:b * n], rng_row_offset=a * n, **kw))
+        out = torch.cat(outs, 0)
+        return (out, None) if return_prompt_cache else out
+
+    @torch.no_grad()
+    def generate_chunk(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
+                       eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
+                       image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
+                       sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
+                       return_prompt_cache: bool = False, rng_row_offset: int = 0):
         """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
         pixel_values[i] (N_i, 1176) / image_grid_thw[i] (1, 3).  Returns responses (b*n, max_new_tokens) int64 on the
         device, prompt-major, padded with pad_token_id after the first EOS (vllm_rollout_spmd.py:144-147).
@@ -141,6 +206,7 @@ class Generator:
             fused = can_fuse and Bp <= ops.DECODE_MAX_ROWS
             S_t = ti(S_np)
             S_l = S_t.long()
+            S_rng = S_t + int(rng_row_offset) if rng_row_offset else S_t       # the counter RNG is keyed by the sample's row in the WHOLE call
             rows_all = Ba * g
             gen_len = gen_len_g[S_l].contiguous()
             pos = pos_g[:, S_l].contiguous()
@@ -200,7 +266,7 @@ class Generator:
                     # EOS, token record, live flags, response index, cache slot, key-range ends, M-RoPE table rows + position
                     # advance, embedding gather) — the unfused branch below is the same sequence as ~25 torch kernels
                     live = active.bool() if self.tap is not None else None
-                    ops.sample_partials(logits[:Ba], temperature, seed, samp_scratch, row_steps=gen_len, row_ids=S_t, top_k=top_k, top_p=top_p)
+                    ops.sample_partials(logits[:Ba], temperature, seed, samp_scratch, row_steps=gen_len, row_ids=S_rng, top_k=top_k, top_p=top_p)
                     ops.decode_step(samp_scratch, forced_len=forced_len, forced_token=int(eos[0]), eos_ids=eos_t, ignore_eos=ignore_eos,
                                     gen_len=gen_len, active=active, out_tokens=out_l, tok_out=tok32, slot_out=slot, k_base=kbase_row,
                                     kb_gen=kb2, ke_gen=ke_gen, n_chunks=Cg, chunk_keys=CKG, pos=pos, inv_freq=m.inv_freq, D=D,
@@ -210,7 +276,7 @@ class Generator:
                     forced = None
                     if forced_len is not None:
                         forced = torch.where(forced_len == gen_len + 1, int(eos[0]), -1).to(I32)
-                    ops.sample(logits[:Ba], temperature, seed, forced=forced, row_steps=gen_len, out=tok32, row_ids=S_t, top_k=top_k, top_p=top_p)
+                    ops.sample(logits[:Ba], temperature, seed, forced=forced, row_steps=gen_len, out=tok32, row_ids=S_rng, top_k=top_k, top_p=top_p)
                     tok = tok32.to(I64)
                     live = active.bool()
                     col = gen_len.clamp(max=R - 1).long()[:, None]

@@ -146,7 +146,8 @@ def test_main_with_a_real_tokenizer_and_processor(tmp_path):
            "worker.actor.micro_batch_size_per_device_for_experience=8", "worker.actor.optim.strategy=adamw_bf16", "worker.actor.fsdp.torch_dtype=bf16",
            "worker.actor.padding_free=true", "worker.rollout.n=4", "worker.reward.score_function=spatial_sgg", "algorithm.use_kl_loss=true",
            "algorithm.kl_penalty=low_var_kl", "algorithm.kl_coef=1.0e-2", "trainer.max_steps=2", "trainer.total_episodes=2", "trainer.n_gpus_per_node=1",
-           "trainer.val_before_train=true", "trainer.val_generations_to_log=1", "trainer.logger=['console']", f"trainer.save_checkpoint_path={tmp_path}/ckpt"]
+           "trainer.val_before_train=true", "trainer.val_generations_to_log=1", "trainer.logger=['console']", f"trainer.save_checkpoint_path={tmp_path}/ckpt",
+           "worker.rollout.val_override_config={'temperature': 0.5, 'n': 1}"]
     p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("step ") and "actor/pg_loss" in l]

@@ -731,3 +731,87 @@ def test_gemm_asm4_swiglu_epilogue_bit_identical(ops, M_, I, K):
         pass
     assert torch.equal(gu, gu_ref) and torch.equal(m, m_ref)
     assert gu2 is None and torch.equal(m2, m_ref)
+
+
+@pytest.mark.parametrize("case", ["mixed", "one_tile_items", "few_items"])
+def test_decode_attention_persistent_kernel_is_bit_identical_to_one_item_per_workgroup_and_matches_fp32(ops, measured, case):
+    """st_attn_fwd_ranges on decode-shaped item lists (the rollout's per-layer launch: shared-prompt partials with 56 query rows and a
+    prefix key range in the prompt cache + per-sample partials with 7 query rows over their own cache chunks, many of them empty): the
+    persistent kernel (attn_decode128_kernel — one workgroup per CU streaming the tiles of all its items through a 4-slot LDS ring with
+    counted waits) must give BIT-IDENTICAL partial outputs and lse to the one-item-per-workgroup kernel, -inf lse for empty items, and the
+    merged result must match dense fp32 attention over the union of every row's keys."""
+    import math
+    rs = np.random.RandomState({"mixed": 0, "one_tile_items": 1, "few_items": 2}[case])
+    nkv, g, D = 4, 7, 128
+    width = nkv * D
+    if case == "mixed":
+        n_prompts, n, CK, CKG, R = 9, 8, 576, 512, 1100
+        plens = rs.randint(500, 1250, n_prompts)
+        glens = rs.randint(0, R, n_prompts * n)
+        glens[:5] = [0, 1, 63, 64, 65]
+    elif case == "one_tile_items":
+        n_prompts, n, CK, CKG, R = 40, 8, 576, 512, 600
+        plens = rs.randint(20, 64, n_prompts)                    # every item a single (partial) tile: the producer runs one item ahead only
+        glens = rs.randint(0, 64, n_prompts * n)
+    else:
+        n_prompts, n, CK, CKG, R = 2, 3, 256, 128, 300          # fewer work items than CUs
+        plens = np.array([300, 77])
+        glens = np.array([5, 140, 0, 299, 128, 1])
+    B = n_prompts * n
+    p_off = np.concatenate([[0], np.cumsum(plens)]).astype(np.int64)
+    kp = bf(rs.standard_normal((int(p_off[-1]) + 64, width))).cuda(); vp = bf(rs.standard_normal((int(p_off[-1]) + 64, width))).cuda()
+    kg = bf(rs.standard_normal((B * R, width))).cuda(); vg = bf(rs.standard_normal((B * R, width))).cuda()
+    q = bf(rs.standard_normal((B, nkv * g * D)) * 0.5).cuda()
+    C, Cg = int(-(-plens.max() // CK)), -(-R // CKG)
+    NP, rows_all = C + Cg, B * g
+    i32 = lambda a_: torch.from_numpy(np.ascontiguousarray(a_).astype(np.int32)).cuda()
+    first = np.arange(n_prompts) * n
+    kb1 = np.concatenate([np.minimum(p_off[:-1] + c * CK, p_off[1:]) for c in range(C)]); ke1 = np.concatenate([np.minimum(p_off[:-1] + (c + 1) * CK, p_off[1:]) for c in range(C)])
+    qb1 = np.tile(first * g, C); qe1 = np.tile((first + n) * g, C)
+    ob1 = np.concatenate([c * rows_all + first * g for c in range(C)])
+    ar = np.arange(B)
+    qb2 = np.tile(ar * g, Cg); qe2 = qb2 + g
+    cidx = np.repeat(np.arange(Cg), B)
+    kb2 = np.tile(ar * R, Cg) + cidx * CKG
+    ke2 = np.maximum(np.minimum(kb2 + CKG, np.tile(ar * R + glens, Cg)), kb2)
+    ob2 = (C + cidx) * rows_all + np.tile(ar * g, Cg)
+    z1, z2 = np.zeros_like(kb1), np.zeros_like(kb2)
+    args = dict(q_beg=i32(np.concatenate([qb1, qb2])), q_end=i32(np.concatenate([qe1, qe2])), k_beg=i32(np.concatenate([z1, kb2])),
+                k_end=i32(np.concatenate([z1, ke2])), o_beg=i32(np.concatenate([ob1, ob2])), pre_beg=i32(np.concatenate([kb1, z2])),
+                pre_end=i32(np.concatenate([ke1, z2])))
+    scale = 1.0 / math.sqrt(D)
+    res = {}
+    try:
+        for mode in (False, True):
+            ops.decode_attn_select(mode)
+            parts = torch.full((NP * rows_all, width), float("nan"), dtype=torch.bfloat16, device="cuda")
+            lse = torch.full((nkv, NP * rows_all), float("nan"), dtype=torch.float32, device="cuda")
+            for _ in range(2):                                   # twice: the second launch starts with warm caches and stale LDS
+                ops.attn_fwd_ranges(q, kg, vg, args["q_beg"], args["q_end"], args["k_beg"], args["k_end"], n * g, nkv, nkv, D, scale, parts, lse,
+                                    o_beg=args["o_beg"], q_group=g, pre_beg=args["pre_beg"], pre_end=args["pre_end"], k_pre=kp, v_pre=vp)
+            merged = ops.attn_merge(parts, lse, NP, nkv, D, q_group=g)
+            torch.cuda.synchronize()
+            res[mode] = (parts.clone(), lse.clone(), merged.clone())
+    finally:
+        ops.decode_attn_select(True)
+    (p0, l0, m0), (p1, l1, m1) = res[False], res[True]
+    assert torch.equal(l0, l1) or torch.equal(torch.nan_to_num(l0, nan=7.0), torch.nan_to_num(l1, nan=7.0))
+    live = torch.isfinite(l0)                                     # (heads, slabs*rows): rows of items that had keys
+    assert int(live.sum()) > 0 and int((l0 == float("-inf")).sum()) > 0
+    rows_live = live.any(0)
+    assert torch.equal(p0[rows_live].view(torch.int16), p1[rows_live].view(torch.int16))
+    assert torch.equal(m0.view(torch.int16), m1.view(torch.int16))
+    # dense fp32 reference of the merged attention for a sample of rows
+    worst = 0.0
+    for b in rs.choice(B, size=min(B, 6), replace=False):
+        pr = b // n
+        K = torch.cat([kp[p_off[pr]:p_off[pr + 1]], kg[b * R:b * R + int(glens[b])]]).float()
+        V = torch.cat([vp[p_off[pr]:p_off[pr + 1]], vg[b * R:b * R + int(glens[b])]]).float()
+        for h in range(nkv):
+            qq = q[b].float().view(nkv * g, D)[h * g:(h + 1) * g]
+            Kh, Vh = K[:, h * D:(h + 1) * D], V[:, h * D:(h + 1) * D]
+            want = torch.softmax(qq @ Kh.t() * scale, -1) @ Vh
+            got = m1[b].float().view(nkv * g, D)[h * g:(h + 1) * g]
+            worst = max(worst, float((got - want).abs().max()))
+    measured(f"decode_attention_persistent_{case}_max_abs_vs_fp32", worst)
+    assert worst < 0.02                                           # bf16 partials + bf16 output, |v| ~ 1 (measured ~0.008)

@@ -286,3 +286,34 @@ def test_old_log_probs_from_prompt_cache_match_full_pass(env):
     # a cache built for other prompts (or other weights) is ignored, not misused
     bad = dict(cache); bad["prompt_ids"] = cache["prompt_ids"].copy(); bad["prompt_ids"][0, -1] += 1
     assert torch.equal(pe.compute_log_prob(data, 1.0, prompt_cache=bad), full)
+
+
+def test_prompt_chunked_rollout_matches_the_unchunked_call_and_overflow_fails_cleanly(env):
+    """Round 4 (the shipped scripts' worst case: 128 prompts x 8 rollouts, 6144-token prompts, 2048-token responses do not fit next to
+    the training state): generate() cuts the prompts into chunks by a memory plan.  The counter RNG is keyed by the sample's GLOBAL row,
+    so the chunked call draws the same samples (up to last-bit GEMM-plan differences of the different batch widths); a chunked call
+    hands back no prompt cache; a single prompt that cannot fit raises a RuntimeError with the numbers instead of an OOM."""
+    from spatialthinker_amd.rollout import Generator
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    n, R = 24, 16
+    rs = np.random.RandomState(2)
+    lens = np.where(rs.rand(2 * n) < 0.5, rs.randint(2, 7, 2 * n), rs.randint(9, R + 1, 2 * n)).astype(np.int64)
+    kw = dict(n=n, max_new_tokens=R, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID, seed=9, pixel_values=pix,
+              image_grid_thw=grids, forced_lengths=lens, sync_every=4)
+    whole, parts = Generator(eng), Generator(eng)
+    a, cache = whole.generate(ids, mask, pos, return_prompt_cache=True, **kw)
+    assert whole.last_chunks == [(0, 2)] and cache is not None
+    parts.plan_prompt_chunks = lambda lens_, n_, R_, budget_bytes=None: [(0, 1), (1, 2)]
+    b, cache_b = parts.generate(ids, mask, pos, return_prompt_cache=True, **kw)
+    assert parts.last_chunks == [(0, 1), (1, 2)] and cache_b is None
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert a.shape == b.shape == (2 * n, R)
+    assert np.mean([np.array_equal(a[r], b[r]) for r in range(2 * n)]) >= 0.9
+    # the plan itself: whole call when it fits, one chunk per prompt under a tight budget, a clean error when nothing fits
+    plens = mask.sum(1)
+    need_one = max(whole.rollout_bytes(int(plens[i]), 1, n, R) for i in range(2))
+    assert whole.plan_prompt_chunks(plens, n, R, budget_bytes=1e15) == [(0, 2)]
+    assert whole.plan_prompt_chunks(plens, n, R, budget_bytes=need_one * 1.01) == [(0, 1), (1, 2)]
+    with pytest.raises(RuntimeError, match="rollout does not fit"):
+        whole.plan_prompt_chunks(plens, n, R, budget_bytes=need_one * 0.5)

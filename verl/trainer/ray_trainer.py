@@ -268,7 +268,9 @@ class RayPPOTrainer:
             return {}
         chunk = int(os.environ.get("ST_VAL_CHUNK", "256"))
         over = dict(self.config.worker.rollout.val_override_config)
-        n = int(over.get("n", 1))
+        # rows per prompt the worker will return: the override's n, else the rollout's own n (the reference unions the un-repeated batch
+        # and would stop with a batch-size error for n > 1 without the shipped config's `val_override_config: {n: 1}`)
+        n = int(over.get("n", self.config.worker.rollout.n))
         scores_all: List[float] = []
         comp_all: Dict[str, list] = defaultdict(list)
         samples: List[tuple] = []

@@ -63,6 +63,9 @@ def parse():
                          "6144-token prompts, every response at the 2048 cap, ONE untimed-warm-up-free step, then an update_policy over a "
                          "micro-batch of 4 UNRELATED 8192-token rows; reports peak allocated / reserved memory, rollout chunks and passes per step, "
                          "and exits non-zero with a message (never an OOM traceback) if it does not fit")
+    ap.add_argument("--old-from-rollout", action="store_true",
+                    help="OPT-IN variant, not the headline configuration: the rollout records log pi_old of the tokens it samples (same logits the "
+                         "sampler reads) and the old-policy pass returns them instead of a second forward (worker.rollout.old_log_probs_from_rollout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--experience-micro-batch", type=int, default=16, help="rows per no-grad log-prob pass (reference: 16)")
     ap.add_argument("--master-fp32", action="store_true", help="the reference's default actor dtype pair: fp32 master weights + fp32 AdamW moments "
@@ -599,7 +602,7 @@ def main():
         t0 = tick()
         resp, prompt_cache = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=temperature, eos_token_id=eos_id,
                                           pad_token_id=pad_id, seed=a.seed * 1000 + step_idx, pixel_values=pix, image_grid_thw=grids,
-                                          forced_lengths=lens, return_prompt_cache=True)
+                                          forced_lengths=lens, return_prompt_cache=True, emit_log_probs=a.old_from_rollout)
         t1 = tick()
         # ---- the (B, P+R) batch of vllm_rollout_spmd.py:144-188, assembled by the worker's own post-processing
         out = assemble_rollout_batch(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), resp.cpu(), G, eos_id)
@@ -613,7 +616,8 @@ def main():
         rewards = torch.zeros(B, R)
         rewards[torch.arange(B), rmask.sum(1) - 1] = scores
         t2 = tick()
-        data["old_log_probs"] = actor.compute_log_prob(data, temperature, prompt_cache=prompt_cache)   # as FSDPWorker.compute_log_probs
+        data["old_log_probs"] = actor.compute_log_prob(data, temperature, prompt_cache=prompt_cache,
+                                                       use_rollout_log_probs=a.old_from_rollout)   # as FSDPWorker.compute_log_probs
         del prompt_cache
         t3 = tick()
         data["ref_log_probs"] = ref.compute_log_prob(data, temperature)
@@ -647,7 +651,7 @@ def main():
                                                  prefix_cached=cached)
             f_exp = executed(ref.last_plan["experience"])
             f_upd = executed(actor.last_plan["update"])
-            f_old = executed(actor.last_plan["experience"], cached=actor.last_prompt_cache_hit)   # prompt K/V re-used from the rollout
+            f_old = executed(actor.last_plan["experience"], cached=actor.last_prompt_cache_hit) if actor.last_plan["experience"] else 0.0   # prompt K/V re-used from the rollout; 0 when the rollout's own log-probs were used
             flops["old"] += f_old; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
             flops["reference_formulation"] = flops.get("reference_formulation", 0.0) + 5 * f_ref
             tokens_total[0] += int(mask_f.sum())
@@ -800,6 +804,7 @@ def main():
                                 "ref": len(ref.last_plan.get("experience", []))},
             "rollout_prompt_chunks": len(getattr(gen, "last_chunks", [(0, npr)])), "prompt_cache_hit": bool(actor.last_prompt_cache_hit),
             "prompt_tokens": tb + ta + 2 + n_img, "responses_at_cap": bool(a.responses_at_cap),
+            "old_log_probs": getattr(actor, "last_log_prob_source", "forward") + (" (OPT-IN --old-from-rollout: not the reference-faithful headline configuration)" if a.old_from_rollout else " (second forward over the responses on the rollout's prompt K/V, as the reference recomputes them)"),
             **({"worst_case": True, "unrelated_rows_probe": probe} if a.worst_case else {}),
             "actor_mfu": (flops["old"] + flops["ref"] + flops["update"]) / actor_t / PEAK_BF16 if actor_t > 0 else None,
             "actor_mfu_reference_flops": flops.get("reference_formulation", 0.0) / actor_t / PEAK_BF16 if actor_t > 0 else None,

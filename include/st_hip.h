@@ -240,8 +240,8 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
                        st_stream_t stream);
 /* Which kernel st_attn_fwd_ranges uses for decode-shaped launches (n_q == n_kv, items of <= 64 query rows, D = 128): 1 = the persistent
  * one-workgroup-per-CU kernel (attn_decode128_kernel: the tiles of all of a workgroup's items stream through one 4-slot LDS ring, 3 tiles
- * in flight per CU; default), 0 = one workgroup per item (attn_fwd128_kernel<false>; also the path of wider items).  Same arithmetic:
- * bit-identical partials (tests/test_gpu_kernels.py).  The environment variable ST_DECODE_ATTN=items sets the initial value to 0. */
+ * in flight per CU), 0 = one workgroup per item (attn_fwd128_kernel<false>; default — measured faster, see attention.hip — and the
+ * path of wider items).  Same arithmetic: bit-identical partials (tests/test_gpu_kernels.py).  ST_DECODE_ATTN=persistent sets the initial value to 1. */
 int st_decode_attn_select(int persistent);
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
@@ -348,15 +348,20 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
  *   if active[b]: out_tokens[b, min(gen_len[b], R-1)] = token;  active[b] &= !(gen_len[b] + 1 >= R || token in eos_ids (unless ignore_eos));
  *   tok_out[b] = token;  slot_out[b] = min(gen_len[b], R-1) (cache slot of this token's K/V);  gen_len[b] += 1;
  *   ke_gen[c*B + b] = clamp(k_base[b] + slot + 1, kb_gen[c*B + b], kb_gen[c*B + b] + chunk_keys) for the n_chunks generated-key chunks;
- *   cos_out/sin_out[b, :] = M-RoPE table row of pos[:, b] (as st_mrope_table), then pos[:, b] += 1;  x_out[b, :H] = embed[token, :H]. */
+ *   cos_out/sin_out[b, :] = M-RoPE table row of pos[:, b] (as st_mrope_table), then pos[:, b] += 1;  x_out[b, :H] = embed[token, :H].
+ * Round 4, optional (lse_partials / logp_out non-NULL): the rollout's OWN log-probabilities.  st_sample_partials additionally leaves, per row
+ *   and split, (max, sum exp(z - max)) of the unfiltered z = logit / T in lse_partials (B*32 floats); st_decode_step then writes
+ *   logp_out[b, slot] = logits[b, token] / T - logsumexp(z) for live rows — log pi_old(token) of the policy that sampled it, in the same pass
+ *   over the logits (what vLLM's `logprobs` would return; the reference recomputes it with a second forward, fsdp_workers.py compute_log_probs). */
 int st_sample_partials(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
                        uint64_t step, const int64_t* step_dev, const int32_t* row_ids, const int32_t* row_steps, float* scratch,
-                       st_stream_t stream);
+                       float* lse_partials, st_stream_t stream);
 int st_decode_step(const float* sample_scratch, const int32_t* forced_len, int32_t forced_token, const int64_t* eos_ids, int n_eos,
                    int ignore_eos, int32_t* gen_len, int32_t* active, int64_t* out_tokens, int R, int32_t* tok_out, int32_t* slot_out,
                    const int32_t* k_base, const int32_t* kb_gen, int32_t* ke_gen, int n_chunks, int chunk_keys, int32_t* pos,
                    const float* inv_freq, int D, int s0, int s1, int s2, float* cos_out, float* sin_out, const st_bf16* embed,
-                   int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, st_stream_t stream);
+                   int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, const float* lse_partials, const st_bf16* logits, int64_t ldl,
+                   float temperature, float* logp_out, st_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -378,17 +378,42 @@ class PolicyEngine:
             s0 = e
         return out
 
+    def rollout_log_probs(self, data: Dict[str, Any], temperature: float, cache: Optional[dict]) -> Optional[torch.Tensor]:
+        """The log-probs the rollout recorded while sampling (Generator.generate(emit_log_probs=True)), IF they are the old-policy
+        log-probs of exactly these rows: same weights (version counter), same temperature, the same response tokens row for row.
+        Masked to the response mask like every compute_log_prob result; None when anything differs (the caller recomputes)."""
+        if not cache or cache.get("log_probs") is None:
+            return None
+        if cache.get("weights_version", 0) != getattr(self.store, "version", 0) or abs(float(cache.get("temperature", -1.0)) - float(temperature)) > 0:
+            return None
+        resp = torch.as_tensor(data["responses"])
+        lp, gen = cache["log_probs"], cache["responses"]
+        if tuple(resp.shape) != tuple(gen.shape) or not torch.equal(resp.to(gen.device), gen):
+            return None
+        R = resp.shape[1]
+        return lp * torch.as_tensor(data["attention_mask"])[:, -R:].to(lp.device, lp.dtype)
+
     @torch.no_grad()
     def compute_log_prob(self, data: Dict[str, Any], temperature: float, micro_batch_size: Optional[int] = None,
-                         prompt_cache: Optional[dict] = None) -> torch.Tensor:
+                         prompt_cache: Optional[dict] = None, use_rollout_log_probs: bool = False) -> torch.Tensor:
         """dp_actor.py:169-210: (N, R) fp32 log-probs of the responses, micro-batched.
+        use_rollout_log_probs (opt-in, round 4): when the rollout recorded the log-probs of the tokens it sampled and `data` is exactly
+        that rollout under the current weights, they ARE the old-policy log-probs — returned without a second forward
+        (self.last_log_prob_source = "rollout"); any mismatch falls back to the pass below.
         prompt_cache (from Generator.generate(return_prompt_cache=True) with THESE weights, rows = its prompts x n, prompt-major):
         the pass then runs on the response tokens only, on top of the cached prompt K/V — the old-policy log-probs of a GRPO step
         need no second pass over the prompts and images."""
+        self.last_log_prob_source = "forward"
+        if use_rollout_log_probs:
+            got = self.rollout_log_probs(data, temperature, prompt_cache)
+            if got is not None:
+                self.last_log_prob_source, self.last_prompt_cache_hit = "rollout", False
+                self.last_plan["experience"] = []
+                return got
         N = data["input_ids"].shape[0]
         mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
         R = data["responses"].shape[1]
-        self.last_prompt_cache_hit = bool(prompt_cache is not None and self._cache_matches(data, prompt_cache, R))
+        self.last_prompt_cache_hit = bool(prompt_cache is not None and "kp" in prompt_cache and self._cache_matches(data, prompt_cache, R))
         p_len, r_len, keys = self._row_stats(data, R)
         passes = self._plan_passes(0, N, mb, max(1, int(self.fuse_experience)), self.tokens_per_pass_nograd, p_len, r_len, keys,
                                    prompts_cached=self.last_prompt_cache_hit)

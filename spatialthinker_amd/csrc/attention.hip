@@ -1603,7 +1603,12 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                            scale, causal, out, ldo, lse, max_seqlen, D == 128 ? ST_K_ATTN_FWD : ST_K_VIT_ATTN, stream);
 }
 
-static int g_decode_attn_persistent = [] { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'i') ? 0 : 1; }();
+// default 0: measured on MI355X the persistent kernel is SLOWER than one workgroup per item (per-layer launch at 512 rows / 448-token
+// generated contexts: 203 vs 144 us; 344 rows / 256: 109 vs 75 us; decode iteration 11.9 vs 10.8 ms at 512 rows — profiles/r04_notes.md):
+// with one workgroup per CU a single wave computes every tile of the CU (decode items have 7 or 56 query rows) and also issues its share
+// of the copies, ~2 us per tile, where two co-resident workgroups run two such waves side by side.  Kept selectable (ST_DECODE_ATTN=persistent,
+// st_decode_attn_select) and bit-identical (tests/test_gpu_kernels.py).
+static int g_decode_attn_persistent = [] { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'p') ? 1 : 0; }();
 int st_decode_attn_select(int persistent) {
     if (persistent != 0 && persistent != 1) return ST_EINVAL;
     g_decode_attn_persistent = persistent;
@@ -1615,8 +1620,7 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
                        const int32_t* o_beg, int q_group, int n_seq, int T_out, int n_q, int n_kv, int D, float scale, st_bf16* out,
                        int64_t ldo, float* lse, int max_q, const int32_t* pre_beg, const int32_t* pre_end, const st_bf16* k_pre,
                        int64_t ldk_pre, const st_bf16* v_pre, int64_t ldv_pre, st_stream_t stream) {
-    // decode launches (n_q == n_kv heads, items of <= 64 query rows): the persistent one-workgroup-per-CU kernel; ST_DECODE_ATTN=items
-    // keeps the one-item-per-workgroup kernel (A/B runs, and the only path for wider items: G = 16 rollouts x 7 heads)
+    // decode launches (n_q == n_kv heads, items of <= 64 query rows) may take the persistent one-workgroup-per-CU kernel (see the switch above)
     if (g_decode_attn_persistent && D == 128 && n_q == n_kv && max_q <= 64 && q && k && v && q_beg && q_end && k_beg && k_end && out && lse && n_seq > 0 && T_out > 0 &&
         n_q > 0 && !(ldq & 7) && !(ldk & 7) && !(ldv & 7) && !(ldo & 3) && max_q > 0 && (k_pre == nullptr) == (v_pre == nullptr) &&
         (!k_pre || (pre_beg && !(ldk_pre & 7) && !(ldv_pre & 7)))) {

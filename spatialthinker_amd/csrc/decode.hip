@@ -176,12 +176,16 @@ __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict_
                                                     int greedy, uint64_t seed, uint64_t step_host, const int64_t* __restrict__ step_dev,
                                                     const int32_t* __restrict__ forced, int32_t* __restrict__ out_ids,
                                                     float* __restrict__ scratch, const int32_t* __restrict__ row_ids,
-                                                    const uint32_t* __restrict__ thr, const int32_t* __restrict__ row_steps) {
+                                                    const uint32_t* __restrict__ thr, const int32_t* __restrict__ row_steps,
+                                                    float* __restrict__ lse_part) {
     const int row = blockIdx.x;
     const uint16_t* x = logits + (int64_t)row * ldl;
     const uint32_t min_key = thr ? thr[row] : 0u;                      // top-k / top-p cut (0 = keep everything)
     float best = -INFINITY;
     int besti = 0x7fffffff;
+    // lse_part (optional): this split's (max, sum exp(z - max)) of the UNFILTERED z = logit / T — st_decode_step turns the 16 partials
+    // into the log-probability of the token it records (the rollout's own old-policy log-probs, same pass over the logits)
+    float lm = -INFINITY, ls = 0.f;
     // response index of this row's token: per-row (rows of one launch may be at different positions once survivors of several
     // waves are decoded together), else a device counter, else the host value
     const uint64_t step = row_steps ? (uint64_t)row_steps[row] : (step_dev ? (uint64_t)step_dev[0] : step_host);
@@ -192,6 +196,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict_
     const int per = (V + gridDim.y - 1) / gridDim.y;
     const int v0 = blockIdx.y * per, v1 = min(V, v0 + per);
     for (int i = v0 + threadIdx.x; i < v1; i += 256) {
+        if (lse_part) {
+            const float zz = bf2f(x[i]) * inv_temp;
+            if (zz > lm) { ls = ls * __expf(lm - zz) + 1.f; lm = zz; } else ls += __expf(zz - lm);
+        }
         if (min_key && bf16_order_key(x[i]) < min_key) continue;
         float z = bf2f(x[i]) * inv_temp;
         if (!greedy) {
@@ -209,10 +217,31 @@ __global__ __launch_bounds__(256) void sample_kernel(const uint16_t* __restrict_
     }
     __shared__ float sb[4];
     __shared__ int si[4];
+    __shared__ float sm[4], ss[4];
+    if (lse_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(lm, o, 64), os = __shfl_xor(ls, o, 64);
+            const float nm = fmaxf(lm, om);
+            ls = (lm == -INFINITY ? 0.f : ls * __expf(lm - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+            lm = nm;
+        }
+        if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = lm; ss[threadIdx.x >> 6] = ls; }
+    }
     if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = besti; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; ++k) if (sb[k] > best || (sb[k] == best && si[k] < besti)) { best = sb[k]; besti = si[k]; }
+        if (lse_part) {
+            float m = sm[0], sacc = ss[0];
+            for (int k = 1; k < 4; ++k) {
+                const float nm = fmaxf(m, sm[k]);
+                sacc = (m == -INFINITY ? 0.f : sacc * __expf(m - nm)) + (sm[k] == -INFINITY ? 0.f : ss[k] * __expf(sm[k] - nm));
+                m = nm;
+            }
+            lse_part[((int64_t)row * gridDim.y + blockIdx.y) * 2] = m;
+            lse_part[((int64_t)row * gridDim.y + blockIdx.y) * 2 + 1] = sacc;
+        }
         if (scratch) {
             scratch[((int64_t)row * gridDim.y + blockIdx.y) * 2] = best;
             scratch[((int64_t)row * gridDim.y + blockIdx.y) * 2 + 1] = __int_as_float(besti);
@@ -407,7 +436,9 @@ __global__ __launch_bounds__(256) void decode_step_kernel(const float* __restric
                                                          int32_t* __restrict__ ke_gen, int n_chunks, int chunk_keys, int32_t* __restrict__ pos,
                                                          const float* __restrict__ inv_freq, int half, int s0, int s1, float* __restrict__ cosb,
                                                          float* __restrict__ sinb, const uint16_t* __restrict__ embed, int64_t ld_embed,
-                                                         uint16_t* __restrict__ x_out, int64_t ldx, int H, int B) {
+                                                         uint16_t* __restrict__ x_out, int64_t ldx, int H, int B,
+                                                         const float* __restrict__ lse_part, const uint16_t* __restrict__ logits, int64_t ldl,
+                                                         float inv_temp, float* __restrict__ logp_out) {
     __shared__ int s_tok, s_pos[3];
     const int row = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
@@ -423,6 +454,16 @@ __global__ __launch_bounds__(256) void decode_step_kernel(const float* __restric
         const bool live = active[row] != 0;
         const int col = j < R - 1 ? j : R - 1;               // finished rows at the cap rewrite their last slot
         if (live) out_tokens[(int64_t)row * R + col] = (int64_t)besti;
+        if (logp_out && live) {                              // log softmax(logits / T)[token]: 16 (max, sum) partials in fixed order
+            float m = -INFINITY, sacc = 0.f;
+            for (int k = 0; k < splits; ++k) {
+                const float pm = lse_part[((int64_t)row * splits + k) * 2], ps = lse_part[((int64_t)row * splits + k) * 2 + 1];
+                const float nm = fmaxf(m, pm);
+                sacc = (m == -INFINITY ? 0.f : sacc * __expf(m - nm)) + (pm == -INFINITY ? 0.f : ps * __expf(pm - nm));
+                m = nm;
+            }
+            logp_out[(int64_t)row * R + col] = bf2f(logits[(int64_t)row * ldl + besti]) * inv_temp - (m + __logf(sacc));
+        }
         bool stop = j + 1 >= R;                              // the length cap ends a sample like an EOS
         if (!ignore_eos)
             for (int e = 0; e < n_eos; ++e) stop = stop || ((int64_t)besti == eos_ids[e]);
@@ -517,7 +558,7 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
     if (filter)
         hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, 1.f / temperature, top_k, top_p, thr);
     hipLaunchKernelGGL(sample_kernel, dim3(B, splits), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature,
-                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids, thr, row_steps);
+                       greedy, seed, step, step_dev, forced, out_ids, scratch, row_ids, thr, row_steps, (float*)nullptr);
     if (scratch)
         hipLaunchKernelGGL(sample_finish_kernel, dim3(st_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, scratch, splits, forced, out_ids, B);
     ST_CHECK_LAUNCH();
@@ -527,7 +568,7 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
 /* The sampler without its last stage: partial (value, index) pairs [row][16][2] stay in `scratch`; st_decode_step finishes them. */
 int st_sample_partials(const st_bf16* logits, int64_t ldl, int B, int V, float temperature, int top_k, float top_p, uint64_t seed,
                        uint64_t step, const int64_t* step_dev, const int32_t* row_ids, const int32_t* row_steps, float* scratch,
-                       st_stream_t stream) {
+                       float* lse_partials, st_stream_t stream) {
     if (!logits || !scratch || B <= 0 || V <= 0 || temperature < 0.f) return ST_EINVAL;
     const int greedy = temperature == 0.f;
     const bool filter = !greedy && ((top_k > 0 && top_k < V) || top_p < 1.f);
@@ -536,7 +577,7 @@ int st_sample_partials(const st_bf16* logits, int64_t ldl, int B, int V, float t
     if (filter)
         hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, 1.f / temperature, top_k, top_p, thr);
     hipLaunchKernelGGL(sample_kernel, dim3(B, 16), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, greedy ? 1.f : 1.f / temperature, greedy,
-                       seed, step, step_dev, (const int32_t*)nullptr, (int32_t*)nullptr, scratch, row_ids, thr, row_steps);
+                       seed, step, step_dev, (const int32_t*)nullptr, (int32_t*)nullptr, scratch, row_ids, thr, row_steps, lse_partials);
     ST_CHECK_LAUNCH();
     return 0;
 }
@@ -545,14 +586,16 @@ int st_decode_step(const float* sample_scratch, const int32_t* forced_len, int32
                    int ignore_eos, int32_t* gen_len, int32_t* active, int64_t* out_tokens, int R, int32_t* tok_out, int32_t* slot_out,
                    const int32_t* k_base, const int32_t* kb_gen, int32_t* ke_gen, int n_chunks, int chunk_keys, int32_t* pos,
                    const float* inv_freq, int D, int s0, int s1, int s2, float* cos_out, float* sin_out, const st_bf16* embed,
-                   int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, st_stream_t stream) {
+                   int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, const float* lse_partials, const st_bf16* logits, int64_t ldl,
+                   float temperature, float* logp_out, st_stream_t stream) {
     if (!sample_scratch || !gen_len || !active || !out_tokens || !tok_out || !slot_out || !k_base || !kb_gen || !ke_gen || !pos || !inv_freq ||
         !cos_out || !sin_out || !embed || !x_out || B <= 0 || R <= 0 || n_chunks < 0 || D <= 0 || (D & 1) || D / 2 > 256 || s0 + s1 + s2 != D / 2 ||
-        H <= 0 || (H & 7) || (ld_embed & 7) || (ldx & 7) || (n_eos > 0 && !eos_ids))
+        H <= 0 || (H & 7) || (ld_embed & 7) || (ldx & 7) || (n_eos > 0 && !eos_ids) || (logp_out && (!lse_partials || !logits || temperature < 0.f)))
         return ST_EINVAL;
     hipLaunchKernelGGL(decode_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sample_scratch, 16, forced_len, (int)forced_token, eos_ids,
                        n_eos, ignore_eos, gen_len, active, out_tokens, R, tok_out, slot_out, k_base, kb_gen, ke_gen, n_chunks, chunk_keys, pos,
-                       inv_freq, D / 2, s0, s1, cos_out, sin_out, embed, ld_embed, x_out, ldx, H, B);
+                       inv_freq, D / 2, s0, s1, cos_out, sin_out, embed, ld_embed, x_out, ldx, H, B, lse_partials, logits, ldl,
+                       temperature > 0.f ? 1.f / temperature : 1.f, logp_out);
     ST_CHECK_LAUNCH();
     return 0;
 }

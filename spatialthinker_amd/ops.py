@@ -612,8 +612,8 @@ def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, sc
 
 
 def decode_attn_select(persistent: bool):
-    """Kernel behind attn_fwd_ranges for decode-shaped launches: True = persistent one-workgroup-per-CU kernel (default), False = one
-    workgroup per item (st_decode_attn_select; A/B runs and the bit-identity test)."""
+    """Kernel behind attn_fwd_ranges for decode-shaped launches: True = persistent one-workgroup-per-CU kernel, False = one workgroup
+    per item (default: measured faster; st_decode_attn_select; A/B runs and the bit-identity test)."""
     lib().st_decode_attn_select(1 if persistent else 0)
 
 
@@ -639,22 +639,25 @@ def sample(logits, temperature, seed, step=0, forced=None, top_k=-1, top_p=1.0, 
     return out
 
 
-def sample_partials(logits, temperature, seed, scratch, step=0, top_k=-1, top_p=1.0, row_ids=None, row_steps=None):
-    """The sampler up to its 16 partial (value, index) pairs per row (left in `scratch`, B*33 floats); decode_step finishes them."""
+def sample_partials(logits, temperature, seed, scratch, step=0, top_k=-1, top_p=1.0, row_ids=None, row_steps=None, lse_partials=None):
+    """The sampler up to its 16 partial (value, index) pairs per row (left in `scratch`, B*33 floats); decode_step finishes them.
+    lse_partials (B*32 floats, optional): per-split (max, sum exp) of logits / T for the rollout's own log-probs (decode_step logp_out)."""
     B, V = logits.shape
     lib().st_sample_partials(_p(logits), logits.stride(0), B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step), None,
-                             _p(row_ids), _p(row_steps), _p(scratch), _s())
+                             _p(row_ids), _p(row_steps), _p(scratch), _p(lse_partials), _s())
 
 
 def decode_step(scratch, *, forced_len, forced_token, eos_ids, ignore_eos, gen_len, active, out_tokens, tok_out, slot_out, k_base, kb_gen, ke_gen,
-                n_chunks, chunk_keys, pos, inv_freq, D, section, cos_out, sin_out, embed, x_out):
+                n_chunks, chunk_keys, pos, inv_freq, D, section, cos_out, sin_out, embed, x_out, lse_partials=None, logits=None, temperature=1.0,
+                logp_out=None):
     """One launch between two decode forwards (st_decode_step): sampler finish + forced EOS, token record, live flags, response index,
     cache slot, generated-key range ends, the rows' M-RoPE cos/sin + position advance, embedding gather."""
     B, R = out_tokens.shape
     lib().st_decode_step(_p(scratch), _p(forced_len), int(forced_token), _p(eos_ids), 0 if eos_ids is None else eos_ids.numel(), int(bool(ignore_eos)),
                          _p(gen_len), _p(active), _p(out_tokens), R, _p(tok_out), _p(slot_out), _p(k_base), _p(kb_gen), _p(ke_gen), int(n_chunks),
                          int(chunk_keys), _p(pos), _p(inv_freq), D, section[0], section[1], section[2], _p(cos_out), _p(sin_out), _p(embed),
-                         embed.stride(0), _p(x_out), x_out.stride(0), embed.shape[1], B, _s())
+                         embed.stride(0), _p(x_out), x_out.stride(0), embed.shape[1], B, _p(lse_partials), _p(logits),
+                         logits.stride(0) if logits is not None else 0, float(temperature), _p(logp_out), _s())
 
 
 def prof_disable(klass: int):

@@ -107,27 +107,40 @@ class Generator:
             return self.generate_chunk(input_ids, attention_mask, position_ids, n=n, max_new_tokens=max_new_tokens,
                                        return_prompt_cache=return_prompt_cache, pixel_values=pixel_values, image_grid_thw=image_grid_thw,
                                        forced_lengths=forced_lengths, **kw)
-        outs = []
+        outs, lps = [], []
+        emit = bool(kw.get("emit_log_probs"))
         for (a, b) in chunks:
             outs.append(self.generate_chunk(input_ids[a:b], attention_mask[a:b], position_ids[a:b], n=n, max_new_tokens=max_new_tokens,
                                             return_prompt_cache=False, pixel_values=None if pixel_values is None else pixel_values[a:b],
                                             image_grid_thw=None if image_grid_thw is None else image_grid_thw[a:b],
                                             forced_lengths=None if forced_lengths is None else forced_lengths[a * n:b * n], rng_row_offset=a * n, **kw))
+            if emit:                                               # (responses, {log_probs, ...}) per chunk
+                outs[-1], d = outs[-1]
+                lps.append(d["log_probs"])
         out = torch.cat(outs, 0)
-        return (out, None) if return_prompt_cache else out
+        if not return_prompt_cache:
+            return out
+        if emit:                            # no prompt K/V outlives the chunks, but the rollout's own log-probs do
+            return out, dict(log_probs=torch.cat(lps, 0), responses=out, temperature=float(kw.get("temperature", 1.0)),
+                             weights_version=getattr(self.m.p, "version", 0))
+        return out, None
 
     @torch.no_grad()
     def generate_chunk(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
                        eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
                        image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
                        sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
-                       return_prompt_cache: bool = False, rng_row_offset: int = 0):
+                       return_prompt_cache: bool = False, rng_row_offset: int = 0, emit_log_probs: bool = False):
         """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
         pixel_values[i] (N_i, 1176) / image_grid_thw[i] (1, 3).  Returns responses (b*n, max_new_tokens) int64 on the
         device, prompt-major, padded with pad_token_id after the first EOS (vllm_rollout_spmd.py:144-147).
         forced_lengths (b*n,): synthetic-benchmark mode — EOS is forced at exactly that response length.
         return_prompt_cache: also return {kp, vp, last_h, p_off, prompt_ids, prompt_mask, n} — the prompt K/V and last hidden
-        states of the prefill; PolicyEngine.compute_log_prob re-uses them for the old-policy log-probs (same weights)."""
+        states of the prefill; PolicyEngine.compute_log_prob re-uses them for the old-policy log-probs (same weights).
+        emit_log_probs (round 4, opt-in): the decode loop also records log softmax(logits / T)[token] of every token it samples —
+        log pi_old(a_t | s_t) of the policy that drew it, from the logits the sampler reads anyway (vLLM's `logprobs`).  Returned as
+        cache["log_probs"] (b*n, R) fp32 (0 behind the end of a response) with cache["responses"] / ["temperature"] for the identity
+        check of PolicyEngine.compute_log_prob(use_rollout_log_probs=True)."""
         m, c, w = self.m, self.m.cfg, self.m.p.w
         dev = self.m.p.device
         ids_np, mask_np, pos_np = (np.asarray(x.cpu() if torch.is_tensor(x) else x) for x in (input_ids, attention_mask, position_ids))
@@ -174,6 +187,7 @@ class Generator:
         rep = torch.arange(nb, device=dev, dtype=I32).repeat_interleave(n)
         hn, _ = ops.rmsnorm_fwd(ops.rows_gather(last_h, rep), w["final_norm"], c.rms_eps, want_rstd=False)
         out = torch.full((B, R), pad_token_id, dtype=I64, device=dev)
+        logp_g = torch.zeros(B, R, dtype=F32, device=dev) if emit_log_probs else None
         kg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
         vg = torch.empty(L, B, R, width, dtype=BF16, device=dev)
         gen_len_g = torch.zeros(B, dtype=I32, device=dev)      # tokens generated so far = response index of the next token
@@ -193,6 +207,7 @@ class Generator:
         ops.gemm_nt(hn, head, out=logits_g)
         w_bytes = 2.0 * (sum(w[f"l.{i}.{nm}"].numel() for i in range(L) for nm in ("qkv_w", "o_w", "gu_w", "down_w")) + head.numel())
         can_fuse = self.fused_decode and c.hidden_size <= 4096 and c.hidden_size % 8 == 0
+        assert can_fuse or not emit_log_probs, "emit_log_probs lives in the fused decode step (st_decode_step)"
         wave = max(1, self.max_decode_batch)
         if self.autotune and wave <= ops.DECODE_MAX_ROWS:
             self._tune_decode(ix.round_up(min(B, wave), 32))
@@ -213,6 +228,8 @@ class Generator:
             active = torch.ones(Ba, dtype=I32, device=dev)
             forced_len = None if forced_len_g is None else forced_len_g[S_l].contiguous()
             out_l = out[S_l].contiguous()
+            logp_l = logp_g[S_l].contiguous() if emit_log_probs else None
+            lse_scratch = torch.empty(Ba * 32, dtype=F32, device=dev) if emit_log_probs else None
             ar = torch.arange(Ba, device=dev, dtype=I32)
             # prompt partial: one "sequence" per (key chunk c, prompt p present in this phase) -> slab c (flash-decoding split-KV);
             # the samples of a prompt are consecutive local rows
@@ -266,11 +283,13 @@ class Generator:
                     # EOS, token record, live flags, response index, cache slot, key-range ends, M-RoPE table rows + position
                     # advance, embedding gather) — the unfused branch below is the same sequence as ~25 torch kernels
                     live = active.bool() if self.tap is not None else None
-                    ops.sample_partials(logits[:Ba], temperature, seed, samp_scratch, row_steps=gen_len, row_ids=S_rng, top_k=top_k, top_p=top_p)
+                    ops.sample_partials(logits[:Ba], temperature, seed, samp_scratch, row_steps=gen_len, row_ids=S_rng, top_k=top_k, top_p=top_p,
+                                        lse_partials=lse_scratch)
                     ops.decode_step(samp_scratch, forced_len=forced_len, forced_token=int(eos[0]), eos_ids=eos_t, ignore_eos=ignore_eos,
                                     gen_len=gen_len, active=active, out_tokens=out_l, tok_out=tok32, slot_out=slot, k_base=kbase_row,
                                     kb_gen=kb2, ke_gen=ke_gen, n_chunks=Cg, chunk_keys=CKG, pos=pos, inv_freq=m.inv_freq, D=D,
-                                    section=c.mrope_section, cos_out=cos_b, sin_out=sin_b, embed=w["embed"], x_out=xbuf)
+                                    section=c.mrope_section, cos_out=cos_b, sin_out=sin_b, embed=w["embed"], x_out=xbuf,
+                                    lse_partials=lse_scratch, logits=logits if emit_log_probs else None, temperature=temperature, logp_out=logp_l)
                     cos, sin, glen, x = cos_b, sin_b, slot, xbuf
                 else:
                     forced = None
@@ -373,6 +392,8 @@ class Generator:
                 flops = steps * (Ba * w_bytes + 4.0 * D * nq * L * row_ctx)
                 self._timers.append((ev0, ev1, steps, steps * (w_bytes + (prompt_ctx + gen_ctx) * kv_row), steps * Ba, flops))
             out[S_l] = out_l
+            if emit_log_probs:
+                logp_g[S_l] = logp_l
             gen_len_g[S_l] = gen_len
             pos_g[:, S_l] = pos
             if n_live == 0:
@@ -416,7 +437,12 @@ class Generator:
         del kg, vg, logits_g
         from .actor import release_cached_blocks
         release_cached_blocks()                       # the generated-token K/V and the logits of this rollout are gone: see actor.py
+        if emit_log_probs and not return_prompt_cache:
+            return out, dict(log_probs=logp_g, responses=out, temperature=float(temperature), weights_version=getattr(self.m.p, "version", 0))
         if return_prompt_cache:
-            return out, dict(kp=kp, vp=vp, last_h=last_h, p_off=p_off.astype(np.int64), prompt_ids=ids_np, prompt_mask=mask_np, n=n,
-                             weights_version=getattr(self.m.p, "version", 0))
+            cache = dict(kp=kp, vp=vp, last_h=last_h, p_off=p_off.astype(np.int64), prompt_ids=ids_np, prompt_mask=mask_np, n=n,
+                         weights_version=getattr(self.m.p, "version", 0))
+            if emit_log_probs:
+                cache.update(log_probs=logp_g, responses=out, temperature=float(temperature))
+            return out, cache
         return out

@@ -789,11 +789,11 @@ def test_decode_attention_persistent_kernel_is_bit_identical_to_one_item_per_wor
             for _ in range(2):                                   # twice: the second launch starts with warm caches and stale LDS
                 ops.attn_fwd_ranges(q, kg, vg, args["q_beg"], args["q_end"], args["k_beg"], args["k_end"], n * g, nkv, nkv, D, scale, parts, lse,
                                     o_beg=args["o_beg"], q_group=g, pre_beg=args["pre_beg"], pre_end=args["pre_end"], k_pre=kp, v_pre=vp)
-            merged = ops.attn_merge(parts, lse, NP, nkv, D, q_group=g)
+            merged = ops.attn_merge(parts, lse, NP, nkv, D, out=torch.zeros(B, nkv * g * D, dtype=torch.bfloat16, device="cuda"), q_group=g)
             torch.cuda.synchronize()
             res[mode] = (parts.clone(), lse.clone(), merged.clone())
     finally:
-        ops.decode_attn_select(True)
+        ops.decode_attn_select(False)                             # the default
     (p0, l0, m0), (p1, l1, m1) = res[False], res[True]
     assert torch.equal(l0, l1) or torch.equal(torch.nan_to_num(l0, nan=7.0), torch.nan_to_num(l1, nan=7.0))
     live = torch.isfinite(l0)                                     # (heads, slabs*rows): rows of items that had keys

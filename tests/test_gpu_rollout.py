@@ -317,3 +317,50 @@ def test_prompt_chunked_rollout_matches_the_unchunked_call_and_overflow_fails_cl
     assert whole.plan_prompt_chunks(plens, n, R, budget_bytes=need_one * 1.01) == [(0, 1), (1, 2)]
     with pytest.raises(RuntimeError, match="rollout does not fit"):
         whole.plan_prompt_chunks(plens, n, R, budget_bytes=need_one * 0.5)
+
+
+def test_rollout_recorded_log_probs_match_the_recomputed_old_policy_log_probs(env, measured):
+    """Opt-in `emit_log_probs` (worker.rollout.old_log_probs_from_rollout): the decode loop records log softmax(logits / T)[token] of every
+    token it samples.  Those ARE the old-policy log-probs of the rollout; the reference obtains the same quantity with a second forward
+    (fsdp_workers.py compute_log_probs).  Checked here against that second forward (PolicyEngine.compute_log_prob, full pass) at two
+    temperatures — the difference is the bf16 noise between the decode kernels and the packed-forward kernels, the same order as the
+    engine's own error against fp32 (tests/test_gpu_model.py: 0.0158) — and through the identity checks of use_rollout_log_probs."""
+    from spatialthinker_amd.actor import PolicyEngine
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    n, R = 4, 12
+    lens = np.array([12, 4, 7, 12, 2, 9, 5, 11])
+    pe = PolicyEngine(cfg, eng.p, None)
+    worst = 0.0
+    for temp in (1.0, 0.7):
+        resp, cache = gen.generate(ids, mask, pos, n=n, max_new_tokens=R, temperature=temp, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                                   seed=3, pixel_values=pix, image_grid_thw=grids, forced_lengths=lens, return_prompt_cache=True, emit_log_probs=True)
+        assert cache["log_probs"].shape == (2 * n, R) and cache["temperature"] == temp
+        resp_c = resp.cpu()
+        rmask = (torch.cumsum((resp_c == tiny.EOS_ID).long(), 1) - (resp_c == tiny.EOS_ID).long() == 0).long()
+        ids_f = torch.cat([torch.from_numpy(ids).repeat_interleave(n, 0), resp_c], 1)
+        mask_f = torch.cat([torch.from_numpy(mask).repeat_interleave(n, 0), rmask], 1)
+        pos_p = torch.from_numpy(pos).repeat_interleave(n, 0)
+        pos_f = torch.cat([pos_p, pos_p[..., -1:] + torch.arange(1, R + 1)], -1)
+        mm = np.repeat(np.array([{"pixel_values": p_, "image_grid_thw": g_} for p_, g_ in zip(pix, grids)], dtype=object), n)
+        data = dict(input_ids=ids_f, attention_mask=mask_f, position_ids=pos_f, responses=resp_c, multi_modal_inputs=mm)
+        full = pe.compute_log_prob(data, temp).cpu()
+        m = rmask.bool()
+        rec = cache["log_probs"].cpu()
+        assert torch.all(rec[~m] == 0) and torch.all(rec[m] < 0)                    # nothing behind the end of a response
+        d = float((rec - full)[m].abs().max())
+        print(f"T = {temp}: rollout-recorded vs recomputed old log-probs, max |d| = {d:.4f} over {int(m.sum())} tokens (mean logp {float(full[m].mean()):.2f})")
+        worst = max(worst, d)
+        got = pe.compute_log_prob(data, temp, prompt_cache=cache, use_rollout_log_probs=True)
+        assert pe.last_log_prob_source == "rollout" and torch.equal(got.cpu(), rec * rmask)
+        # identity checks: other responses, another temperature, stale weights -> the forward pass runs (prompt K/V cache still usable)
+        other = dict(data, responses=resp_c.clone()); other["responses"][0, 0] += 1
+        pe.compute_log_prob(other, temp, prompt_cache=cache, use_rollout_log_probs=True)
+        assert pe.last_log_prob_source == "forward"
+        pe.compute_log_prob(data, temp * 0.5, prompt_cache=cache, use_rollout_log_probs=True)
+        assert pe.last_log_prob_source == "forward"
+        stale = dict(cache, weights_version=cache["weights_version"] + 1)
+        pe.compute_log_prob(data, temp, prompt_cache=stale, use_rollout_log_probs=True)
+        assert pe.last_log_prob_source == "forward"
+    measured("rollout_recorded_vs_recomputed_old_logp_max_abs", worst)
+    assert worst < 0.03

@@ -87,6 +87,9 @@ CriticConfig = _build("CriticConfig", {
 RolloutConfig = _build("RolloutConfig", {
     "name": (str, "vllm"), "n": (int, 1), "temperature": (float, 1.0), "top_p": (float, 1.0), "top_k": (int, -1), "limit_images": (int, 0),
     "dtype": (str, "bf16"), "gpu_memory_utilization": (float, 0.6), "ignore_eos": (bool, False), "enforce_eager": (bool, False),
+    # extension (not a reference key; default off = the reference's behaviour): the rollout records log pi_old of every token it samples and
+    # compute_log_probs returns those instead of running the old-policy forward again (spatialthinker_amd.rollout emit_log_probs)
+    "old_log_probs_from_rollout": (bool, False),
     "enable_chunked_prefill": (bool, False), "tensor_parallel_size": (int, 2), "max_num_batched_tokens": (int, 8192),
     "max_num_seqs": (int, 1024), "disable_log_stats": (bool, True), "val_override_config": (Dict[str, Any], {}),
     "prompt_length": (int, -1), "response_length": (int, -1),

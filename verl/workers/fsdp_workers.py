@@ -160,7 +160,7 @@ class FSDPWorker:
             ids, mask, pos, n=n, max_new_tokens=r.response_length, temperature=temperature, eos_token_id=eos,
             pad_token_id=self.special["pad"], seed=(self.rank + 1000) * 100003 + self._gen_calls, pixel_values=px, image_grid_thw=gr,
             ignore_eos=bool(over.get("ignore_eos", r.ignore_eos)), forced_lengths=forced,
-            top_k=top_k, top_p=top_p, return_prompt_cache=True)
+            top_k=top_k, top_p=top_p, return_prompt_cache=True, emit_log_probs=self._old_from_rollout())
         batch = assemble_rollout_batch(ids, mask, pos, resp.cpu(), n, eos)          # vllm_rollout_spmd.py:144-188
         non_tensor = {}
         if mm is not None:
@@ -173,9 +173,14 @@ class FSDPWorker:
         t = self.config.rollout.temperature
         data.meta_info["temperature"] = t
         cache, self._prompt_cache = getattr(self, "_prompt_cache", None), None            # one use, then the K/V memory is released
-        lp = self.actor.compute_log_prob(self._as_dict(data), t, prompt_cache=cache).cpu()
+        lp = self.actor.compute_log_prob(self._as_dict(data), t, prompt_cache=cache, use_rollout_log_probs=self._old_from_rollout()).cpu()
         return DataProto.from_dict(tensors={"old_log_probs": lp},
-                                   meta_info={"temperature": t, "prompt_cache_hit": bool(self.actor.last_prompt_cache_hit)})
+                                   meta_info={"temperature": t, "prompt_cache_hit": bool(self.actor.last_prompt_cache_hit),
+                                              "old_log_probs_source": getattr(self.actor, "last_log_prob_source", "forward")})
+
+    def _old_from_rollout(self) -> bool:
+        """worker.rollout.old_log_probs_from_rollout (or ST_OLD_FROM_ROLLOUT=1): opt-in, see PolicyEngine.compute_log_prob."""
+        return bool(getattr(self.config.rollout, "old_log_probs_from_rollout", False)) or os.environ.get("ST_OLD_FROM_ROLLOUT", "0") == "1"
 
     @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
     def compute_ref_log_probs(self, data: DataProto) -> DataProto:

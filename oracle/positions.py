@@ -49,6 +49,44 @@ def mrope_position_ids(input_ids, image_grid_thw, attention_mask, *, image_token
     return out
 
 
+def mrope_position_ids_with_video(input_ids, image_grid_thw, video_grid_thw, second_per_grid_ts, attention_mask, *, image_token_id: int,
+                                  video_token_id: int, vision_start_token_id: int, merge_size: int = 2, tokens_per_second: int = 2) -> np.ndarray:
+    """verl/models/transformers/qwen2_vl.py:36-136 with video blocks (:88-101, :117-118), restated as a token walk: every vision-start
+    token opens a block of t * (h/m) * (w/m) tokens; an image keeps its temporal row at the block's base, a video's frame f sits at
+    trunc(f * seconds_per_grid * tokens_per_second); text continues at max(previous block) + 1 on all three rows."""
+    ids = np.asarray(input_ids, dtype=np.int64)
+    mask = np.ones_like(ids) if attention_mask is None else np.asarray(attention_mask, dtype=np.int64)
+    toks = ids[mask == 1].tolist()
+    cols, nxt, i, ni, nv = [], 0, 0, 0, 0
+    while i < len(toks):
+        opens = toks[i] == vision_start_token_id and i + 1 < len(toks) and toks[i + 1] in (image_token_id, video_token_id)
+        cols.append((nxt, nxt, nxt))
+        nxt += 1
+        i += 1
+        if not opens:
+            continue
+        if toks[i] == image_token_id:
+            t, h, w = (int(x) for x in image_grid_thw[ni]); ni += 1
+            sec = 0.0
+        else:
+            t, h, w = (int(x) for x in video_grid_thw[nv])
+            sec = float(second_per_grid_ts[nv]) if second_per_grid_ts is not None and len(second_per_grid_ts) else 1.0
+            nv += 1
+        gh, gw = h // merge_size, w // merge_size
+        top = nxt
+        for f in range(t):
+            tt = int(np.float32(f) * np.float32(sec) * np.float32(tokens_per_second))
+            for y in range(gh):
+                for x in range(gw):
+                    cols.append((nxt + tt, nxt + y, nxt + x))
+                    top = max(top, nxt + tt, nxt + y, nxt + x)
+        i += t * gh * gw
+        nxt = top + 1
+    out = np.ones((3, ids.shape[0]), dtype=np.int64)
+    out[:, mask == 1] = np.asarray(cols, dtype=np.int64).T
+    return out
+
+
 def continue_position_ids(prompt_position_ids: np.ndarray, response_length: int) -> np.ndarray:
     """verl/workers/rollout/vllm_rollout_spmd.py:159-170: pos[..., P+j] = pos[..., P-1]+1+j
     on every row (all three M-RoPE rows alike), continued past EOS."""

@@ -84,7 +84,9 @@ template <int N> __device__ __forceinline__ void a4_wait_vm() {
 // silu(gate) * up for 128 output columns per workgroup (+ optionally the bf16 gate|up values the backward needs).
 // DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment reads, 4 = MFMAs only, 5 = no epilogue, 6 = epilogue without the global stores, 7 = the real kernel + a per-workgroup time trace in the workspace,
 
-template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0, bool AS = false, bool BS = false>
+// DEC: no effect on the code — the decode entry's instantiation gets its own symbol so that kernel traces / PMC summaries can tell the
+// 257..512-row decode launches from the prefill's launches of the same tile
+template <bool HAS_BIAS, bool HAS_RES, bool OUT_BF16, bool ACCUM, bool SWIGLU, int DBG = 0, bool AS = false, bool BS = false, bool DEC = false>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
                                                       uint16_t* __restrict__ Cb, float* __restrict__ Cf, int64_t ldc, uint16_t* __restrict__ gu,
@@ -402,7 +404,19 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
             }
         __syncthreads();
         const int t = threadIdx.x;
-        if constexpr (SWIGLU) {
+        if (piece >= 0) {                                            // K-slice of a tail tile: the raw fp32 tile, row-major [256][256]
+            // (SwiGLU tiles too — round 4: the silu(gate) * up of a split tile is formed by gemm_a4_swiglu_finish_kernel from the summed slices;
+            // raw column wn*128 + p*64 + x holds image column 64*wn + x of pass p, see the column map there)
+            const int c8 = (t & 15) * 8;
+            const int col = (c8 >> 6) * 128 + p * 64 + (c8 & 63);
+            float* wp = tail_ws + (int64_t)piece * (A4_BM * A4_BN);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 16 + (t >> 4);
+                *reinterpret_cast<float4*>(wp + row * A4_BN + col) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
+                *reinterpret_cast<float4*>(wp + row * A4_BN + col + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
+            }
+        } else if constexpr (SWIGLU) {
             // image columns: wave wn at 64*wn; inside, [gate16 | up16 | gate16 | up16]; thread handles 8 output columns of one row
             const int c8 = (t & 7) * 8;                              // 64 output columns per pass: (wn, pair q, half h)
             const int wn_ = c8 >> 5, q = (c8 >> 4) & 1, h = c8 & 8;
@@ -465,16 +479,6 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
                         *reinterpret_cast<uint4*>(gp + N) = pack8(u);
                     } else for (int r = 0; r < 8; ++r) if (n + r < N) { gp[r] = f2bf(g[r]); gp[N + r] = f2bf(u[r]); }
                 }
-            }
-        } else if (piece >= 0) {                                     // K-slice of a tail tile: the raw fp32 tile, row-major [256][256]
-            const int c8 = (t & 15) * 8;
-            const int col = (c8 >> 6) * 128 + p * 64 + (c8 & 63);
-            float* wp = tail_ws + (int64_t)piece * (A4_BM * A4_BN);
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 16 + (t >> 4);
-                *reinterpret_cast<float4*>(wp + row * A4_BN + col) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
-                *reinterpret_cast<float4*>(wp + row * A4_BN + col + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
             }
         } else if (interior) {
             // whole tile inside the matrix, every pointer 16-byte aligned (the production case): straight-line code, two batches of 8
@@ -627,14 +631,55 @@ __global__ __launch_bounds__(256) void gemm_a4_finish_kernel(const float* __rest
     }
 }
 
+// SwiGLU tiles cut into K-slices (round 4: the 257..512-row decode gate/up GEMM is 296 tiles = 1.16 rounds of CUs): sum the raw slices in
+// a fixed order, round gate and up to bf16 and write bf16(silu(gate)) * up — the roundings of the unsplit epilogue.  Raw tile column
+// wn*128 + p*64 + q*32 + j (j < 16) holds the GATE of output column wn*64 + p*32 + q*16 + j, the UP value sits 16 columns further.
+// grid (tail tiles, 32): a block owns 8 rows of a tile, a thread 4 consecutive output columns of one row.
+__global__ __launch_bounds__(256) void gemm_a4_swiglu_finish_kernel(const float* __restrict__ ws, int split, int full_blocks, uint16_t* __restrict__ Cb,
+                                                                   int64_t ldc, int M, int N, int tiles_m, int tiles_n) {
+    const int nb = tiles_m * tiles_n;
+    int bid = full_blocks + blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = 8 * tiles_n;
+    const int group = bid / per_group, in_g = bid % per_group;
+    const int first_m = group * 8;
+    const int gsz = min(tiles_m - first_m, 8);
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int row = blockIdx.y * 8 + (threadIdx.x >> 5), nl = (threadIdx.x & 31) * 4;
+    const int m = tm * A4_BM + row, n = tn * (A4_BN / 2) + nl;
+    if (m >= M || n >= N) return;
+    const int gcol = (nl >> 6) * 128 + ((nl >> 5) & 1) * 64 + ((nl >> 4) & 1) * 32 + (nl & 15);
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < split; ++sp) {
+        const float* wp = ws + ((int64_t)blockIdx.x * split + sp) * (A4_BM * A4_BN) + row * A4_BN + gcol;
+        const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 16);
+        g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; u[0] += b.x; u[1] += b.y; u[2] += b.z; u[3] += b.w;
+    }
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        g[r] = bfround(g[r]); u[r] = bfround(u[r]);
+        o[r] = bfround(g[r] * sigmoidf_(g[r])) * u[r];
+    }
+    uint16_t* cp = Cb + (int64_t)m * ldc + n;
+    if (n + 3 < N && (reinterpret_cast<uintptr_t>(cp) & 7) == 0) {
+        uint2 w;
+        w.x = f2bf2(o[0], o[1]); w.y = f2bf2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(cp) = w;
+    } else for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+}
+
 extern float* g_tail_ws;          // st_gemm_set_workspace (gemm_tiles.hip)
 extern int64_t g_tail_ws_bytes;
 
-template <bool HB, bool HR, bool OB, bool AC, bool SW, bool AS = false, bool BS = false>
+template <bool HB, bool HR, bool OB, bool AC, bool SW, bool AS = false, bool BS = false, bool DEC = false>
 static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
-                       uint16_t* Cb, float* Cf, int64_t ldc, uint16_t* gu, int64_t ldgu, int M, int N, int K, hipStream_t s) {
+                       uint16_t* Cb, float* Cf, int64_t ldc, uint16_t* gu, int64_t ldgu, int M, int N, int K, hipStream_t s, bool sw_tail = false) {
     constexpr int smem = 256 * 528;                              // >= the two 64-KiB operand slots
-    auto kern = gemm_nt4_kernel<HB, HR, OB, AC, SW, 0, AS, BS>;
+    auto kern = gemm_nt4_kernel<HB, HR, OB, AC, SW, 0, AS, BS, DEC>;
     static bool configured = false;
     if (!configured) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -643,7 +688,9 @@ static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     const int tiles_m = st_cdiv(M, A4_BM), tiles_n = st_cdiv(N, SW ? A4_BN / 2 : A4_BN);
     const int nb = tiles_m * tiles_n;
     int full = nb, split = 1, tail_tiles = 0;
-    if (!SW && g_tail_ws) {                                      // cost model of launch_tile (K-tile steps, fitted to kernel traces)
+    // SwiGLU tiles are split only on request (the decode entry, where gate|up is not kept): the training / log-prob passes keep the
+    // unsplit epilogue, bit-identical to st_gemm_nt + st_swiglu_fwd
+    if ((!SW || (sw_tail && gu == nullptr)) && g_tail_ws) {     // cost model of launch_tile (K-tile steps, fitted to kernel traces)
         const int ncu = st_num_cus(), nkt = K / 64, r = nb % ncu;
         const int64_t cap = g_tail_ws_bytes / ((int64_t)A4_BM * A4_BN * 4);
         int best = 1, best_cost = nkt + 4;
@@ -656,9 +703,13 @@ static int launch_asm4(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     }
     hipLaunchKernelGGL(kern, dim3(full + tail_tiles * split), dim3(256), smem, s, A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, gu, ldgu, M, N, K, tiles_m,
                        tiles_n, g_tail_ws, full, split);
-    if (tail_tiles)
-        hipLaunchKernelGGL((gemm_a4_finish_kernel<HB, HR, OB, AC>), dim3(tail_tiles, 32), dim3(256), 0, s, g_tail_ws, split, full, bias, res, ldr, Cb, Cf,
-                           ldc, M, N, tiles_m, tiles_n);
+    if (tail_tiles) {
+        if constexpr (SW)
+            hipLaunchKernelGGL(gemm_a4_swiglu_finish_kernel, dim3(tail_tiles, 32), dim3(256), 0, s, g_tail_ws, split, full, Cb, ldc, M, N, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL((gemm_a4_finish_kernel<HB, HR, OB, AC>), dim3(tail_tiles, 32), dim3(256), 0, s, g_tail_ws, split, full, bias, res, ldr, Cb, Cf,
+                               ldc, M, N, tiles_m, tiles_n);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -704,7 +755,10 @@ int st_gemm_asm4_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
 
 // gate/up projection with the SwiGLU epilogue: m_out[M, I] = silu(A gate^T) * (A up^T), gu_out (optional) = bf16 gate | up
 int st_gemm_asm4_swiglu(const uint16_t* A, int64_t lda, const uint16_t* gate_up_w, int64_t ldb, uint16_t* gu_out, int64_t ldgu, uint16_t* m_out,
-                        int64_t ldm, int M, int I, int K, hipStream_t s) {
+                        int64_t ldm, int M, int I, int K, hipStream_t s, int split_tail) {
     if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
-    return launch_asm4<false, false, true, false, true>(A, lda, gate_up_w, ldb, nullptr, nullptr, 0, m_out, nullptr, ldm, gu_out, ldgu, M, I, K, s);
+    if (split_tail)                                              // the decode entry (257..512 rows): own symbol, K-split tail
+        return launch_asm4<false, false, true, false, true, false, false, true>(A, lda, gate_up_w, ldb, nullptr, nullptr, 0, m_out, nullptr, ldm, gu_out, ldgu,
+                                                                                M, I, K, s, true);
+    return launch_asm4<false, false, true, false, true>(A, lda, gate_up_w, ldb, nullptr, nullptr, 0, m_out, nullptr, ldm, gu_out, ldgu, M, I, K, s, false);
 }

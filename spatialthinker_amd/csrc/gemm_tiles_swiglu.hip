@@ -1,9 +1,10 @@
 // gemm_tiles_swiglu.hip — gate/up projection with the SwiGLU epilogue (training and decode).
 #include "gemm_tile_kernel.h"
+#include <stdlib.h>
 
 extern int g_train_variant;
 int st_gemm_asm4_swiglu(const uint16_t* A, int64_t lda, const uint16_t* gate_up_w, int64_t ldb, uint16_t* gu_out, int64_t ldgu, uint16_t* m_out,
-                        int64_t ldm, int M, int I, int K, hipStream_t s);
+                        int64_t ldm, int M, int I, int K, hipStream_t s, int split_tail = 0);
 
 /* gate/up projection with the SwiGLU in the epilogue for any M (training / prefill): m_out[M, I] = silu(A gate_w^T) * (A up_w^T);
  * gu_out (optional, [M, 2I]) additionally receives the bf16 gate|up values the backward needs. */
@@ -54,9 +55,16 @@ static int swiglu_decode_plan(int M, int I) {
     if (cost(96) <= cost(128)) return 2;
     return 3;
 }
+// 257..512 rows (two row tiles): the 4-wave training tile with the SwiGLU epilogue and a K-split tail (round 4) once it fills at least
+// one round of CUs — 7B: 2 x 148 = 296 tiles, 256 whole + 40 cut into K-slices; both row tiles of a weight tile meet in one XCD's L2
+// (ST_DECODE_GU_ASM4=0 keeps the 256x160 decode tile for A/B runs).  Plan id 40.
+static bool swiglu_decode_on_asm4(int M, int I) {
+    static const bool gu_asm4 = [] { const char* e = getenv("ST_DECODE_GU_ASM4"); return !(e && e[0] == '0'); }();
+    return gu_asm4 && M > 256 && g_train_variant == 40 && (int64_t)st_cdiv(M, 256) * st_cdiv(I, 128) >= st_num_cus();
+}
 extern "C" int st_gemm_swiglu_decode_plan(int M, int I, int* variant_out) {
     if (M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || !variant_out) return ST_EINVAL;
-    *variant_out = swiglu_decode_plan(M, I);
+    *variant_out = swiglu_decode_on_asm4(M, I) ? 40 : swiglu_decode_plan(M, I);
     return 0;
 }
 
@@ -66,6 +74,8 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
         ldc < I || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (swiglu_decode_on_asm4(M, I) && lda < (1 << 22) && ldb < (1 << 22))
+        return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
     const int plan = swiglu_decode_plan(M, I);
     if (g_decode_nt && M <= 256) {                           // one row tile: the weights are read once — non-temporal stream
         if (plan == 7) return launch_tile_swiglu<64, 128, 1, 4, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);

@@ -18,37 +18,55 @@ def round_up(x: int, m: int) -> int:
 
 # ------------------------------------------------------------------ M-RoPE position ids
 def get_rope_index(input_ids: np.ndarray, image_grid_thw: Optional[np.ndarray], attention_mask: Optional[np.ndarray], *,
-                   image_token_id: int, vision_start_token_id: int, spatial_merge_size: int = 2) -> np.ndarray:
+                   image_token_id: int, vision_start_token_id: int, spatial_merge_size: int = 2,
+                   video_grid_thw: Optional[np.ndarray] = None, second_per_grid_ts: Optional[np.ndarray] = None,
+                   video_token_id: Optional[int] = None, tokens_per_second: int = 2) -> np.ndarray:
     """(3, S) M-RoPE ids of ONE sequence; same contract as the reference function
-    (verl/models/transformers/qwen2_vl.py:36-136, images only): text tokens advance all three
-    rows together, an image contributes a (t=0, h, w) grid shifted by the running offset, the
-    text after it resumes at max+1, masked positions hold 1."""
+    (verl/models/transformers/qwen2_vl.py:36-136): text tokens advance all three rows together, a vision block contributes a
+    (t, h, w) grid shifted by the running offset, the text after it resumes at max+1, masked positions hold 1.  Images keep the temporal
+    row at 0 (second_per_grid_t = 0, :83-87); a VIDEO block's temporal index is trunc(frame * second_per_grid_t * tokens_per_second)
+    with second_per_grid_t = second_per_grid_ts[video] or 1.0 (:96-101, :117-118).  Blocks are taken in the order they appear in the
+    sequence; the k-th image block uses image_grid_thw[k], the k-th video block video_grid_thw[k]."""
     ids = np.asarray(input_ids).astype(np.int64)
     S = ids.shape[0]
     mask = np.ones(S, dtype=np.int64) if attention_mask is None else np.asarray(attention_mask).astype(np.int64)
-    if image_grid_thw is None or len(image_grid_thw) == 0:
+    no_img = image_grid_thw is None or len(image_grid_thw) == 0
+    no_vid = video_grid_thw is None or len(video_grid_thw) == 0
+    if no_img and no_vid:
         pos = np.cumsum(mask) - 1
         pos[mask == 0] = 1
         return np.tile(pos, (3, 1))
+    if not no_vid and video_token_id is None:
+        raise ValueError("video_grid_thw given without video_token_id")
     keep = np.nonzero(mask == 1)[0]
     toks = ids[keep]
-    is_img = toks == image_token_id
-    # an image block = maximal run of image tokens that follows a vision-start token
-    starts = np.nonzero(is_img & np.concatenate([[False], toks[:-1] == vision_start_token_id]))[0]
+    after_start = np.concatenate([[False], toks[:-1] == vision_start_token_id])
+    is_vis = (toks == image_token_id) | ((toks == video_token_id) if video_token_id is not None else False)
+    # a vision block = the run of image / video tokens that follows a vision-start token
+    starts = np.nonzero(is_vis & after_start)[0]
     packed = np.empty((3, toks.shape[0]), dtype=np.int64)
     cursor, nxt = 0, 0                     # cursor: token index, nxt: next position value
-    for img, st in enumerate(starts):
-        t, h, w = (int(v) for v in image_grid_thw[img])
+    n_image = n_video = 0
+    for st in starts:
+        if toks[st] == image_token_id:
+            t, h, w = (int(v) for v in image_grid_thw[n_image])
+            n_image += 1
+            sec = 0.0
+        else:
+            t, h, w = (int(v) for v in video_grid_thw[n_video])
+            sec = float(second_per_grid_ts[n_video]) if second_per_grid_ts is not None else 1.0
+            n_video += 1
         gh, gw = h // spatial_merge_size, w // spatial_merge_size
         n_txt = int(st) - cursor
         packed[:, cursor:st] = nxt + np.arange(n_txt)
         base = nxt + n_txt
-        n_img = t * gh * gw
+        n_vis = t * gh * gw
         grid = np.indices((t, gh, gw)).reshape(3, -1)
-        grid[0] = 0                         # images: temporal index scaled by second_per_grid_t = 0
-        packed[:, st:st + n_img] = grid + base
-        nxt = int(packed[:, st:st + n_img].max()) + 1
-        cursor = int(st) + n_img
+        # float32 product truncated toward zero, as torch's `(t_index * second_per_grid_t * tokens_per_second).long()`
+        grid[0] = (grid[0].astype(np.float32) * np.float32(sec) * np.float32(tokens_per_second)).astype(np.int64)
+        packed[:, st:st + n_vis] = grid + base
+        nxt = int(packed[:, st:st + n_vis].max()) + 1
+        cursor = int(st) + n_vis
     packed[:, cursor:] = nxt + np.arange(toks.shape[0] - cursor)
     out = np.ones((3, S), dtype=np.int64)
     out[:, keep] = packed

@@ -350,6 +350,8 @@ def gemm_swiglu_decode(a, gate_up_w, out=None):
     M, K = a.shape
     I = gate_up_w.shape[0] // 2
     out = torch.empty(M, I, dtype=BF16, device=a.device) if out is None else out
+    if M > 256:
+        _gemm_workspace(a.device)                           # 257..512 rows run the training tile with its K-split tail (st_gemm_set_workspace)
     lib().st_gemm_swiglu_decode(_p(a), a.stride(0), _p(gate_up_w), gate_up_w.stride(0), _p(out), out.stride(0), M, I, K, _s())
     return out
 

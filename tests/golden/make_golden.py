@@ -178,6 +178,31 @@ def gen_positions():
         out[f"rope{i}_ids"], out[f"rope{i}_mask"] = ids, mask
         out[f"rope{i}_thw"] = thw.numpy() if thw is not None else np.zeros((0, 3), dtype=np.int64)
         out[f"rope{i}_pos"] = pos.numpy()
+    # video blocks (and image + video mixed), with and without second_per_grid_ts (:88-101, :117-118)
+    def vseq(parts, pad):
+        toks = []
+        for kind, val in parts:
+            if kind == "text":
+                toks += rs.randint(0, 900, size=val).tolist()
+            else:
+                t, h, w = val
+                toks += [991] + [990 if kind == "image" else 989] * (t * h * w // 4) + [992]
+        return np.asarray([993] * pad + toks), np.asarray([0] * pad + [1] * len(toks))
+
+    vspecs = [([("text", 3), ("video", (4, 4, 4)), ("text", 5)], 2, None),
+              ([("text", 2), ("video", (3, 4, 8)), ("text", 1), ("image", (1, 4, 4)), ("text", 4)], 0, [0.5]),
+              ([("image", (1, 8, 4)), ("text", 2), ("video", (2, 4, 4)), ("video", (5, 2, 4)), ("text", 3)], 5, [1.5, 0.4])]
+    for i, (parts, pad, secs) in enumerate(vspecs):
+        ids, mask = vseq(parts, pad)
+        img = [v for k_, v in parts if k_ == "image"]
+        vid = [v for k_, v in parts if k_ == "video"]
+        pos = get_rope_index(proc, torch.from_numpy(ids), image_grid_thw=torch.tensor(img, dtype=torch.long) if img else None,
+                             video_grid_thw=torch.tensor(vid, dtype=torch.long), second_per_grid_ts=torch.tensor(secs) if secs else None,
+                             attention_mask=torch.from_numpy(mask))
+        out[f"ropev{i}_ids"], out[f"ropev{i}_mask"], out[f"ropev{i}_pos"] = ids, mask, pos.numpy()
+        out[f"ropev{i}_img"] = np.asarray(img, dtype=np.int64).reshape(-1, 3)
+        out[f"ropev{i}_vid"] = np.asarray(vid, dtype=np.int64).reshape(-1, 3)
+        out[f"ropev{i}_secs"] = np.asarray(secs if secs else [], dtype=np.float32)
     # HF vision index helpers
     from transformers.vision_utils import get_vision_position_ids, get_vision_window_index
 

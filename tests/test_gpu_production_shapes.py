@@ -183,7 +183,7 @@ def test_decode_path_at_7b_widths_vs_fp32_oracle(ops, lm7b, measured, rows, wave
 
 def test_decode_plans_hit_the_production_tiles(ops):
     """The (M, N, K) of the cases above select the tile variants the bench runs: 128x128 (14) / 256x128 (16) / 256x256 (18) decode
-    tiles, the 256x160 8-column-interleave SwiGLU tile (1) and split-K >= 4 slabs — asserted through the library's own plan query."""
+    tiles, the 256x160 8-column-interleave SwiGLU tile (1; 40 = the 4-wave training tile with a K-split tail above 256 rows) and split-K >= 4 slabs — asserted through the library's own plan query."""
     seen, max_split, swiglu = set(), 0, set()
     for M in (64, 200, 344, 512):
         Bp = -(-M // 32) * 32 if M <= 256 else -(-M // 128) * 128
@@ -194,7 +194,7 @@ def test_decode_plans_hit_the_production_tiles(ops):
             v, sp = ops.decode_plan(Bp, N, K)
             seen.add(v); max_split = max(max_split, sp)
     assert {14, 16, 18} <= seen, seen
-    assert 1 in swiglu, swiglu
+    assert 1 in swiglu and 40 in swiglu, swiglu          # <= 256 rows: the 256x160 decode tile; 257..512 rows: the 4-wave tile with the K-split tail
     assert max_split >= 4, max_split
 
 

@@ -16,6 +16,31 @@ def test_rope_index_golden(golden_dir):
         np.testing.assert_array_equal(pos, z[f"rope{i}_pos"])
 
 
+def test_rope_index_with_video_blocks_golden(golden_dir):
+    """Video grids (reference :88-101, :117-118; outside the SpatialThinker data, closed in round 4 for completeness): temporal index
+    = trunc(frame * second_per_grid_t * 2), mixed image + video blocks in sequence order, with and without second_per_grid_ts — the
+    product function, its by-name wrapper and the oracle restatement against the reference function's own output."""
+    import types
+    import torch
+    from oracle import positions as OP
+    from verl.models.transformers.qwen2_vl import get_rope_index as by_name
+    z = np.load(os.path.join(golden_dir, "positions.npz"))
+    proc = types.SimpleNamespace(tokenizer=types.SimpleNamespace(convert_tokens_to_ids={"<|image_pad|>": 990, "<|video_pad|>": 989, "<|vision_start|>": 991}.get),
+                                 image_processor=types.SimpleNamespace(merge_size=2))
+    for i in range(3):
+        img, vid, secs = z[f"ropev{i}_img"], z[f"ropev{i}_vid"], z[f"ropev{i}_secs"]
+        kw = dict(image_token_id=990, vision_start_token_id=991, video_grid_thw=vid, second_per_grid_ts=secs if len(secs) else None, video_token_id=989)
+        pos = I.get_rope_index(z[f"ropev{i}_ids"], img if len(img) else None, z[f"ropev{i}_mask"], **kw)
+        np.testing.assert_array_equal(pos, z[f"ropev{i}_pos"])
+        orc = OP.mrope_position_ids_with_video(z[f"ropev{i}_ids"], img, vid, secs if len(secs) else None, z[f"ropev{i}_mask"], image_token_id=990,
+                                               video_token_id=989, vision_start_token_id=991)
+        np.testing.assert_array_equal(orc, z[f"ropev{i}_pos"])
+        got = by_name(proc, torch.from_numpy(z[f"ropev{i}_ids"]), image_grid_thw=torch.from_numpy(img) if len(img) else None,
+                      video_grid_thw=torch.from_numpy(vid), second_per_grid_ts=torch.from_numpy(secs) if len(secs) else None,
+                      attention_mask=torch.from_numpy(z[f"ropev{i}_mask"]))
+        np.testing.assert_array_equal(got.numpy(), z[f"ropev{i}_pos"])
+
+
 def test_vision_indices_golden(golden_dir):
     z = np.load(os.path.join(golden_dir, "positions.npz"))
     for i in range(4):

@@ -22,4 +22,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_dec_$c.json
   rm -rf $d
 done
-python3 tools/make_traffic_json.py gpurun_out/pmc_bench_FETCH_SIZE.json gpurun_out/pmc_bench_WRITE_SIZE.json gpurun_out/bench_traffic_FETCH_SIZE.json gpurun_out/r03_gemm_traffic.json gpurun_out/pmc_dec_FETCH_SIZE.json gpurun_out/pmc_dec_WRITE_SIZE.json 10
+python3 tools/make_traffic_json.py gpurun_out/pmc_bench_FETCH_SIZE.json gpurun_out/pmc_bench_WRITE_SIZE.json gpurun_out/bench_traffic_FETCH_SIZE.json gpurun_out/r04_gemm_traffic.json gpurun_out/pmc_dec_FETCH_SIZE.json gpurun_out/pmc_dec_WRITE_SIZE.json 10

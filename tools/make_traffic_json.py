@@ -1,4 +1,4 @@
-"""profiles/r03_gemm_traffic.json from the PMC passes of tools/bench_traffic.sh.
+"""profiles/r04_gemm_traffic.json (r03_… in round 3) from the PMC passes of tools/bench_traffic.sh.
     python tools/make_traffic_json.py <pmc FETCH json> <pmc WRITE json> <bench line of the FETCH pass> <out.json>
 FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it counts 128-byte
 requests as 64 bytes for wide coalesced reads).  Training GEMM class = the 256x256 tiles (4-wave asm tile, 8-wave tile in its TN /
@@ -14,12 +14,23 @@ DF, DW = (json.load(open(sys.argv[5])), json.load(open(sys.argv[6]))) if len(sys
 line = json.loads(open(bench_line).read().strip().splitlines()[-1])
 
 
+def is_decode_a4(k):
+    """the decode entry's instantiation of the 4-wave tile: last template argument (DEC) true"""
+    if not k.startswith("gemm_nt4_kernel<") or ">" not in k:
+        return False
+    args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+    return len(args) == 9 and args[-1] == "true"
+
+
 def is_train_gemm(k):
+    if is_decode_a4(k) or k.startswith("gemm_a4_swiglu_finish_kernel"):
+        return False
     return k.startswith(("gemm_nt4_kernel", "gemm_a4_finish_kernel", "gemm_nt_kernel")) or (k.startswith("gemm_tile_kernel<256, 256") and "true, false, true" not in k[:80] and True)
 
 
 DECODE = ("gemm_tile_kernel<256, 160", "gemm_tile_kernel<256, 128", "gemm_tile_kernel<128,", "gemm_tile_kernel<64,", "attn_fwd128_kernel<false>",
-          "attn_merge_kernel", "decode_finish", "decode_step_kernel", "sample_kernel", "sample_filter_kernel", "gemm_skinny_finish")
+          "attn_merge_kernel", "decode_finish", "decode_step_kernel", "sample_kernel", "sample_filter_kernel", "gemm_skinny_finish",
+          "gemm_a4_swiglu_finish_kernel", "attn_decode128_kernel")
 tr_bytes = tr_launch = 0.0
 per_kernel = {}
 dec_bytes = 0.0
@@ -34,7 +45,7 @@ for k in set(F) | set(W):
 dec_its = int(sys.argv[7]) if len(sys.argv) > 7 else 10        # decode iterations of the probe (tools/gen_flat.py 6 64 8: two calls x 5 iterations)
 dec_kernels = {}
 for k in set(DF) | set(DW):
-    if not k.startswith(DECODE):
+    if not (k.startswith(DECODE) or is_decode_a4(k)):
         continue                                              # prefill / ViT kernels of the probe
     b = DF.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 + DW.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
     dec_bytes += b

@@ -10,11 +10,10 @@ from spatialthinker_amd.indexing import get_rope_index as _rope_index
 
 def get_rope_index(processor, input_ids: torch.Tensor, image_grid_thw: Optional[torch.Tensor] = None, video_grid_thw=None,
                    second_per_grid_ts=None, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    if video_grid_thw is not None:
-        raise NotImplementedError("video inputs are outside the SpatialThinker path")
     tok = processor.tokenizer
-    out = _rope_index(input_ids.cpu().numpy(), None if image_grid_thw is None else image_grid_thw.cpu().numpy(),
-                      None if attention_mask is None else attention_mask.cpu().numpy(),
+    np_ = lambda t: None if t is None else (t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
+    out = _rope_index(input_ids.cpu().numpy(), np_(image_grid_thw), np_(attention_mask),
                       image_token_id=tok.convert_tokens_to_ids("<|image_pad|>"), vision_start_token_id=tok.convert_tokens_to_ids("<|vision_start|>"),
-                      spatial_merge_size=processor.image_processor.merge_size)
+                      spatial_merge_size=processor.image_processor.merge_size, video_grid_thw=np_(video_grid_thw),
+                      second_per_grid_ts=np_(second_per_grid_ts), video_token_id=tok.convert_tokens_to_ids("<|video_pad|>"))
     return torch.from_numpy(out).to(input_ids.device)

@@ -36,22 +36,38 @@ def _exact_similarity(a: str, b: str) -> float:
     return 1.0 if a == b else 0.0
 
 
+SIMILARITY_KIND = "unset"        # which label similarity the scores of this process use: "spacy:en_core_web_md" | "exact-match" | "custom"
+
+
 def _load_default_similarity() -> Callable[[str, str], float]:
-    try:                                                    # the reference's choice, when available
+    """The reference's choice (spaCy `en_core_web_md` vectors) when the package and the model are installed, else exact label match.
+    The two give DIFFERENT object-matching scores, so the choice is announced once per process (stderr) and kept in SIMILARITY_KIND —
+    a run must not change its reward scale silently with what happens to be installed."""
+    global SIMILARITY_KIND
+    import sys
+    try:
         import spacy
         nlp = spacy.load("en_core_web_md", disable=["parser", "ner", "tagger"])
         doc = lru_cache(maxsize=4096)(nlp)
-        return lambda a, b: float(doc(a).similarity(doc(b)))
-    except Exception:
-        return _exact_similarity
+        SIMILARITY_KIND = "spacy:en_core_web_md"
+        fn = lambda a, b: float(doc(a).similarity(doc(b)))
+    except Exception as e:
+        SIMILARITY_KIND = "exact-match"
+        fn = _exact_similarity
+        print(f"[spatial_sgg] spaCy en_core_web_md is not available ({type(e).__name__}): object labels are matched EXACTLY (similarity 1 / 0); "
+              f"the reference's scores use spaCy vector similarity — install it or call set_similarity(fn) for comparable rewards", file=sys.stderr)
+    else:
+        print("[spatial_sgg] label similarity: spaCy en_core_web_md vectors (the reference's)", file=sys.stderr)
+    return fn
 
 
 _similarity: Optional[Callable[[str, str], float]] = None
 
 
 def set_similarity(fn: Optional[Callable[[str, str], float]]) -> None:
-    global _similarity
+    global _similarity, SIMILARITY_KIND
     _similarity = fn
+    SIMILARITY_KIND = "custom" if fn is not None else "unset"
     _match_cached.cache_clear()
 
 

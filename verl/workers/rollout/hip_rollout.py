@@ -1,7 +1,7 @@
 """Rollout post-processing: the (b*n, P+R) batch the trainer expects from `generate_sequences`
 (reference: verl/workers/rollout/vllm_rollout_spmd.py:144-188).  The token generation itself is
 spatialthinker_amd.rollout.Generator (prefill + hipGraph decode on the actor's weights); this is the integer bookkeeping
-around it, kept separate so it is testable without a GPU (tests/test_rollout_postprocess.py, golden rl_extra.npz ro_*)."""
+around it, kept separate so it is testable without a GPU (tests/test_trainer_math.py against the golden rl_extra.npz ro_*)."""
 from __future__ import annotations
 
 from typing import Dict, List, Union

@@ -81,6 +81,10 @@ def parse():
                     help="the same synthetic step through the kept API: `python -m verl.trainer.main` (config merge, RLHF dataloader, FSDPWorker "
                          "methods, DataProto .cpu() round trips, tokenizer decode + CustomRewardManager, RayPPOTrainer.fit) instead of calling the "
                          "engine directly; the JSON line reports the step rate the trainer itself logged")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="TEST MODE for a 1-GPU box: the N ranks of --gpus N all use cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on "
+                         "one device).  Runs the real multi-rank step — rank-sharded batches, overlapped gradient exchange on device tensors, "
+                         "barrier / max-over-ranks timing, the exchange statistics of the JSON line — with a small model; not a scaling measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/contract check without a GPU: ranks rendezvous over gloo, time K trivial steps, rank 0 prints the JSON line")
     return ap.parse_args()
@@ -522,11 +526,16 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if a.ranks_share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import datetime
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=600))
-        preflight(rank, world, local, need_gb={"7b": 215.0, "3b": 120.0}.get(a.model, 1.0))
+        if a.ranks_share_gpu:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))          # device tensors through gloo: correctness, not speed
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=600))
+            preflight(rank, world, local, need_gb={"7b": 215.0, "3b": 120.0}.get(a.model, 1.0))
     from spatialthinker_amd import ops
     from spatialthinker_amd.actor import ActorHyper, PolicyEngine
     from spatialthinker_amd.model import ParamStore, VLConfig
@@ -786,7 +795,7 @@ def main():
                                      f"{grid[1] * grid[2]} random patches; response lengths ~ clip(N(512,128),64,cap) enforced by forcing EOS; templated reward strings)",
             "config": {"workload": f"{name} dense spatial-reward GRPO step (gen + reward + old/ref log-probs + advantage + update), G={G}, "
                                    f"{npr} prompts/GPU, micro-batch {micro}, {n_opt} optimizer steps/step, max_response_length {R}",
-                       "global_batch": B * world, "seq_len": P + R, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "seq_len": P + R, "parallelism": f"dp{world}" + (" (ranks share ONE GPU, gloo exchange: test mode)" if a.ranks_share_gpu else "")},
             "timing_s": {k: v / a.steps for k, v in phase.items()},
             "timing_s_max_over_ranks": {k: v / a.steps for k, v in phase_max.items()},
             # gradient exchange per step (max over ranks; device events on the compute stream, actor.GradReducer): the whole exchange from the

@@ -22,7 +22,7 @@ extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate
 
 /* tuning entry: the decode gate/up + SwiGLU GEMM on an explicit tile (tools/decode_swiglu_tune.py):
  * 1 = 256x160 3 slots (8-column interleave)   2 = 256x192 2 slots   3 = 256x256 2 slots   4 = 256x256 mid-tile barrier (training tile)
- * 5 = 256x192 mid-tile barrier   6 = 128x128 3 slots   7 = 64x128 3 slots */
+ * 5 = 256x192 mid-tile barrier   6 = 128x128 3 slots   7 = 64x128 3 slots   40 = 4-wave training tile + K-split SwiGLU tail */
 extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int64_t lda, const st_bf16* gate_up_w, int64_t ldb, st_bf16* out,
                                              int64_t ldc, int M, int I, int K, st_stream_t stream) {
     if (!A || !gate_up_w || !out || M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || K <= 0 || (K % 64) || (lda & 7) || (ldb & 7) || lda < K || ldb < K ||
@@ -30,6 +30,9 @@ extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int6
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
+        case 40:                                             // the 4-wave training tile with the K-split SwiGLU tail (needs st_gemm_set_workspace for the split)
+            if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
+            return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
         case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 3: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
@@ -55,11 +58,12 @@ static int swiglu_decode_plan(int M, int I) {
     if (cost(96) <= cost(128)) return 2;
     return 3;
 }
-// 257..512 rows (two row tiles): the 4-wave training tile with the SwiGLU epilogue and a K-split tail (round 4) once it fills at least
-// one round of CUs — 7B: 2 x 148 = 296 tiles, 256 whole + 40 cut into K-slices; both row tiles of a weight tile meet in one XCD's L2
-// (ST_DECODE_GU_ASM4=0 keeps the 256x160 decode tile for A/B runs).  Plan id 40.
+// 257..512 rows (two row tiles) on the 4-wave training tile with the SwiGLU epilogue and a K-split tail (round 4; plan id 40) once it
+// fills at least one round of CUs — 7B: 2 x 148 = 296 tiles, 256 whole + 40 cut into K-slices.  OPT-IN (ST_DECODE_GU_ASM4=1, or variant 40
+// of st_gemm_swiglu_decode_variant): measured 1 % faster per decode iteration (10.42 vs 10.53 ms at 512 rows, same box) but 4 GB MORE HBM
+// traffic per iteration (the fp32 K-slices of the tail: 16.1 vs 12.0 GB for gate/up, PMC) — the 256x160 decode tile stays the default.
 static bool swiglu_decode_on_asm4(int M, int I) {
-    static const bool gu_asm4 = [] { const char* e = getenv("ST_DECODE_GU_ASM4"); return !(e && e[0] == '0'); }();
+    static const bool gu_asm4 = [] { const char* e = getenv("ST_DECODE_GU_ASM4"); return e && e[0] == '1'; }();
     return gu_asm4 && M > 256 && g_train_variant == 40 && (int64_t)st_cdiv(M, 256) * st_cdiv(I, 128) >= st_num_cus();
 }
 extern "C" int st_gemm_swiglu_decode_plan(int M, int I, int* variant_out) {

@@ -183,7 +183,7 @@ def test_decode_path_at_7b_widths_vs_fp32_oracle(ops, lm7b, measured, rows, wave
 
 def test_decode_plans_hit_the_production_tiles(ops):
     """The (M, N, K) of the cases above select the tile variants the bench runs: 128x128 (14) / 256x128 (16) / 256x256 (18) decode
-    tiles, the 256x160 8-column-interleave SwiGLU tile (1; 40 = the 4-wave training tile with a K-split tail above 256 rows) and split-K >= 4 slabs — asserted through the library's own plan query."""
+    tiles, the 256x160 8-column-interleave SwiGLU tile (1) and split-K >= 4 slabs — asserted through the library's own plan query."""
     seen, max_split, swiglu = set(), 0, set()
     for M in (64, 200, 344, 512):
         Bp = -(-M // 32) * 32 if M <= 256 else -(-M // 128) * 128
@@ -194,7 +194,7 @@ def test_decode_plans_hit_the_production_tiles(ops):
             v, sp = ops.decode_plan(Bp, N, K)
             seen.add(v); max_split = max(max_split, sp)
     assert {14, 16, 18} <= seen, seen
-    assert 1 in swiglu and 40 in swiglu, swiglu          # <= 256 rows: the 256x160 decode tile; 257..512 rows: the 4-wave tile with the K-split tail
+    assert 1 in swiglu, swiglu
     assert max_split >= 4, max_split
 
 
@@ -216,6 +216,18 @@ def test_decode_shaped_gemms_at_7b_shapes_vs_fp32(ops, measured, M_):
             err = float((got.float() - ref).abs().max() / ref.abs().max())
             measured(f"decode_gemm_swiglu_M{M_}_rel", err)
             assert err < 9.1e-3, (name, err)                     # measured <= 0.0070 (1.3x)
+            if M_ > 256:
+                # the opt-in plan 40 (4-wave training tile, the 40 tail tiles cut into K-slices and finished by gemm_a4_swiglu_finish_kernel):
+                # same bound against fp32; against the default tile only single-bf16-step differences of gate / up (other fp32 summation order)
+                from spatialthinker_amd.lib import lib
+                ops.gemm_tail_split(True)
+                out40 = torch.empty_like(got)
+                lib().st_gemm_swiglu_decode_variant(40, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out40.data_ptr(), out40.stride(0), M_, I, K,
+                                                    torch.cuda.current_stream().cuda_stream)
+                err40 = float((out40.float() - ref).abs().max() / ref.abs().max())
+                measured(f"decode_gemm_swiglu_plan40_M{M_}_rel", err40)
+                assert err40 < 9.1e-3, err40
+                assert float((out40 != got).float().mean()) < 0.02
         else:
             res = _randn_bf16((M_, N), 1.0, 5) if N <= 4608 else None
             got = ops.gemm_nt(a, w, bias=bias, residual=res, decode=True)

@@ -273,10 +273,13 @@ int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width
  * st_mxfp8_quantize: x (R, K) bf16 -> q (R, K) bytes and scales[K/128][scale_rows] dwords (byte j of scales[kt][r] = scale of
  *   k-block 4*kt + j of row r; scale = 2^(byte - 127), shared exponent = floor(log2(max|x|)) - 8, elements RNE, saturating at 448).
  *   K % 128 == 0, scale_rows >= R and a multiple of 4.
- * st_gemm_mxfp8_nt: out[M,N] (bf16) = dequant(A)[M,K] dequant(B)[N,K]^T (+bias)(+residual), fp32 accumulation on
- *   v_mfma_scale_f32_16x16x128_f8f6f4 (the only fp8 MFMA that runs at twice the bf16 rate on gfx950). */
+ * st_gemm_mxfp8_nt: out[M,N] (bf16) = dequant(A)[M,K] dequant(B)[N,K]^T (+bias)(+residual), fp32 accumulation on the block-scaled
+ *   MFMAs (the only fp8 MFMAs that run at twice the bf16 rate on gfx950): the 4-wave hand-scheduled 256x256 tile on
+ *   v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_mx4.hip; default) or the 8-wave tile on v_mfma_scale_f32_16x16x128_f8f6f4 (gemm_fp8.hip).
+ * st_gemm_mxfp8_select: waves = 4 | 8 picks the tile (A/B runs, tests; ST_FP8_TILE=8 sets the initial value). */
 int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int K,
                       st_stream_t stream);
+int st_gemm_mxfp8_select(int waves);
 int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
                      const uint32_t* SB, int64_t sb_rows, const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out,
                      int64_t ldc, int M, int N, int K, st_stream_t stream);

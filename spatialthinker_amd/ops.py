@@ -6,6 +6,7 @@ kernels of libst_hip.so on torch's current stream and raises if a tensor is not 
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -379,6 +380,18 @@ def mxfp8_quantize(x):
     sc = torch.zeros(K // 128, rows, dtype=torch.int32, device=x.device)
     lib().st_mxfp8_quantize(_p(x), x.stride(0), _p(q), q.stride(0), _p(sc), rows, R, K, _s())
     return q, sc
+
+
+_fp8_tile = 8 if os.environ.get("ST_FP8_TILE", "") == "8" else 4
+
+
+def gemm_mxfp8_select(waves: int) -> int:
+    """Tile behind gemm_mxfp8_nt: 4 = the hand-scheduled 4-wave tile (gemm_mx4.hip, default), 8 = the 8-wave tile; returns the previous."""
+    global _fp8_tile
+    prev = _fp8_tile
+    lib().st_gemm_mxfp8_select(int(waves))
+    _fp8_tile = int(waves)
+    return prev
 
 
 def gemm_mxfp8_nt(aq, sa, bq, sb, *, bias=None, residual=None, out=None):

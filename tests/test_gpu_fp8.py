@@ -43,12 +43,26 @@ def test_quantiser_bit_exact_vs_oracle(ops, shape):
     assert float((err / np.maximum(blk, 1e-30)).max()) <= 2.0 ** -3 + 1e-6
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 520, 384), (1000, 3584, 1024), (4096, 4608, 3584)])
-def test_gemm_vs_fp32_product_of_dequantised_operands(ops, shape):
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 256, 256), (300, 520, 384), (1000, 3584, 1024), (4096, 4608, 3584), (515, 3584, 18944),
+                                   (257, 37888, 3584)])
+def test_gemm_vs_fp32_product_of_dequantised_operands(ops, shape, waves):
+    """Both tiles: the 4-wave hand-scheduled one (gemm_mx4.hip; K-tile counts 1, 2, 3 exercise its prologue / re-fetch paths, the ragged
+    shapes its clamped rows and the generic epilogue) and the 8-wave one."""
     M, N, K = shape
+    prev = ops.gemm_mxfp8_select(waves)
+    try:
+        _gemm_case(ops, M, N, K)
+    finally:
+        ops.gemm_mxfp8_select(prev)
+
+
+def _gemm_case(ops, M, N, K):
     rs = np.random.RandomState(M + N + K)
-    a = _bf(rs.standard_normal((M, K))).cuda()
-    b = _bf(rs.standard_normal((N, K)) * (1 + np.arange(N)[:, None] / N)).cuda()       # asymmetric: catches a transposed C
+    # every (row, 32-k block) gets its own power-of-two magnitude: a scale taken from the wrong row or block shows up at once
+    blk = lambda R: np.repeat(2.0 ** rs.randint(-3, 4, (R, K // 32)), 32, axis=1)
+    a = _bf(rs.standard_normal((M, K)) * blk(M)).cuda()
+    b = _bf(rs.standard_normal((N, K)) * blk(N) * (1 + np.arange(N)[:, None] / N)).cuda()       # asymmetric: catches a transposed C
     aq, sa = ops.mxfp8_quantize(a)
     bq, sb = ops.mxfp8_quantize(b)
     qa, sba = MX.quantize(a.float().cpu().numpy())

@@ -283,6 +283,10 @@ int st_gemm_mxfp8_select(int waves);
 int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
                      const uint32_t* SB, int64_t sb_rows, const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out,
                      int64_t ldc, int M, int N, int K, st_stream_t stream);
+/* out[M,N] = bf16(silu(gate)) * up with [gate | up] = dequant(A)[M,K] dequant(B)[2N,K]^T (B: the N gate rows, then the N up rows):
+ * the MLP's first product with the SwiGLU in the epilogue of the 4-wave fp8 tile (no-grad passes; roundings of st_gemm_swiglu). */
+int st_gemm_mxfp8_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                         const uint32_t* SB, int64_t sb_rows, st_bf16* out, int64_t ldc, int M, int N, int K, st_stream_t stream);
 
 /* ---- optimizer: AnyPrecisionAdamW with bf16 states + Kahan compensation, one fused pass
  *      (verl/utils/torch_functional.py:253-329; ~10 eager passes in the reference) ---------------

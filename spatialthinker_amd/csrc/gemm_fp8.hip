@@ -185,6 +185,8 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_kernel(const uint8_t* __restri
 int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
                        int64_t sb_rows, const uint16_t* bias, const uint16_t* residual, int64_t ldr, uint16_t* out, int64_t ldc, int M, int N,
                        int K, hipStream_t s);
+int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
+                              int64_t sb_rows, uint16_t* out, int64_t ldc, int M, int N, int K, hipStream_t s);
 static int g_fp8_tile = -1;
 static int fp8_tile_waves() {
     if (g_fp8_tile < 0) { const char* e = getenv("ST_FP8_TILE"); g_fp8_tile = (e && atoi(e) == 8) ? 8 : 4; }
@@ -236,6 +238,17 @@ int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t 
 #undef QGO
     ST_CHECK_LAUNCH();
     return 0;
+}
+
+int st_gemm_mxfp8_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                         const uint32_t* SB, int64_t sb_rows, st_bf16* out, int64_t ldc, int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || !SA || !SB || !out || M <= 0 || N <= 0 || K <= 0 || (K % 128) || (lda & 15) || (ldb & 15) || lda < K || ldb < K ||
+        ldc < N || sa_rows < M || sb_rows < 2 * (int64_t)N || (sa_rows & 3) || (sb_rows & 3) || sa_rows < 4 || (((uintptr_t)A) & 15) ||
+        (((uintptr_t)B) & 15) || (((uintptr_t)SA) & 15) || (((uintptr_t)SB) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM_FP8, s, 4.0 * (double)M * (double)N * (double)K);
+    return st_launch_gemm_mx4_swiglu(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, out, ldc, M, N, K, s);
 }
 
 }  // extern "C"

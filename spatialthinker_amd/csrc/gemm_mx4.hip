@@ -85,7 +85,10 @@ __device__ __forceinline__ i32x8 q4_frag(const i32x4& lo, const i32x4& hi) { ret
 __host__ __device__ constexpr int q4_dma_slot(int j) { return 8 + (j >> 1) * 3 + (j & 1); }
 static_assert(q4_dma_slot(11) == 24 && q4_dma_slot(12) == 26 && q4_dma_slot(15) == 30, "12 operand copies before the vmcnt(14) of slot 25, 4 behind it");
 
-template <bool HAS_BIAS, bool HAS_RES>
+// SWIGLU: B = [gate rows | up rows] (2N x K, N = output width); the B tile interleaves 32 gate rows with the 32 matching up rows, so a
+// lane holds gate and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
+// bf16(silu(gate)) * up for 128 output columns per workgroup — the roundings of gemm_asm4.hip's SwiGLU epilogue (bf16 gate / up / act).
+template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false>
 __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint32_t* __restrict__ SA, int64_t sa_rows,
                                                       const uint8_t* __restrict__ B, int64_t ldb, const uint32_t* __restrict__ SB, int64_t sb_rows,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
@@ -106,7 +109,9 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
     const int group = bid / per_group, in_g = bid % per_group;
     const int first_m = group * 8;
     const int gsz = min(tiles_m - first_m, 8);
-    const int m0 = (first_m + in_g % gsz) * Q4_BM, n0 = (in_g / gsz) * Q4_BN;
+    const int m0 = (first_m + in_g % gsz) * Q4_BM;
+    const int n0 = (in_g / gsz) * (SWIGLU ? Q4_BN / 2 : Q4_BN);      // SWIGLU: first OUTPUT column
+    static_assert(!SWIGLU || (!HAS_BIAS && !HAS_RES), "SwiGLU tiles carry no bias / residual");
 
     // ---- buffer resources: base = first row of the tile (operands) / first row-dword of the tile in K-tile 0 (scales)
     auto make_srd = [&](uint64_t base) {
@@ -118,8 +123,9 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
         return s;
     };
     const i32x4 srdA = make_srd((uint64_t)(A + (int64_t)m0 * lda)), srdB = make_srd((uint64_t)(B + (int64_t)n0 * ldb));
+    const i32x4 srdB2 = make_srd((uint64_t)(B + (int64_t)(n0 + (SWIGLU ? N : 0)) * ldb));       // SWIGLU: the up rows follow the N gate rows
     const i32x4 srdSA = make_srd((uint64_t)(SA + m0)), srdSB = make_srd((uint64_t)(SB + n0));
-    const int rows_a = min(Q4_BM, M - m0), cols_b = min(Q4_BN, N - n0);
+    const int rows_a = min(Q4_BM, M - m0), cols_b = min(SWIGLU ? Q4_BN / 2 : Q4_BN, N - n0);    // B rows (= output columns) this tile owns
     // source offset of operand copy j of this wave, per lane: row (lane >> 3) of the copy's 8 rows, clamped to the last valid row of the
     // tile (such rows compute values that are never stored), 16-byte chunk (lane & 7) ^ row — the swizzle, on the source
     uint32_t voffA[8], voffB[8];
@@ -127,11 +133,14 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
         constexpr int j = decltype(jc)::value;
         const int rl = lane >> 3, ch = ((lane & 7) ^ rl) << 4;
         voffA[j] = (uint32_t)min(wave * 64 + j * 8 + rl, rows_a - 1) * (uint32_t)lda + ch;
-        voffB[j] = (uint32_t)min(wave * 64 + j * 8 + rl, cols_b - 1) * (uint32_t)ldb + ch;
+        // SWIGLU: tile rows 64w .. 64w+31 are the gate rows of output columns 32w .., rows 64w+32 .. the up rows (copies 4..7, through srdB2)
+        const int src = SWIGLU ? wave * 32 + (j & 3) * 8 + rl : wave * 64 + j * 8 + rl;
+        voffB[j] = (uint32_t)min(src, cols_b - 1) * (uint32_t)ldb + ch;
     });
     // scale copies: this wave's 64 row-dwords of each operand (rows past the scale arrays clamped: never stored either)
     const uint32_t voffSA = (uint32_t)(min((int64_t)m0 + wave * 64 + lane, sa_rows - 1) - m0) * 4u;
-    const uint32_t voffSB = (uint32_t)(min((int64_t)n0 + wave * 64 + lane, sb_rows - 1) - n0) * 4u;
+    const uint32_t voffSB = SWIGLU ? (uint32_t)(min((int64_t)n0 + wave * 32 + (lane & 31), (int64_t)N - 1) - n0 + (lane >= 32 ? N : 0)) * 4u
+                                   : (uint32_t)(min((int64_t)n0 + wave * 64 + lane, sb_rows - 1) - n0) * 4u;
     const uint32_t stepSA = (uint32_t)sa_rows * 4u, stepSB = (uint32_t)sb_rows * 4u;
     uint32_t koff = 0, soffA = 0, soffB = 0;                         // byte offsets of the K-tile the next copies fetch (SGPRs)
     const uint32_t smem32 = (uint32_t)(uintptr_t)smem;
@@ -177,7 +186,9 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
 
     auto dma_tile = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (j < 8) q4_dma(voffA[j], srdA, koff); else q4_dma(voffB[j - 8], srdB, koff);
+        if constexpr (j < 8) q4_dma(voffA[j], srdA, koff);
+        else if constexpr (SWIGLU && j >= 12) q4_dma(voffB[j - 8], srdB2, koff);
+        else q4_dma(voffB[j - 8], srdB, koff);
     };
     // read r of a k-step: 0..7 A fragment halves (tile r >> 1, half r & 1), 8..15 B; scale read r: 0..3 A tiles, 4..7 B tiles
     auto rd_frag = [&](auto rc, auto sc_) {
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
     // ---- epilogue through LDS: 2 passes of 256 rows x 128 columns of fp32 (rows padded to 528 bytes), as gemm_asm4.hip.
     // Swapped operands (B first): lane holds m = mi*32 + (lane & 31) and, per register group q, n = ni*32 + 8q + 4g + 0..3
     constexpr int ROWB = 128 * 4 + 16;
-    const bool interior = m0 + Q4_BM <= M && n0 + Q4_BN <= N && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+    const bool interior = m0 + Q4_BM <= M && n0 + (SWIGLU ? Q4_BN / 2 : Q4_BN) <= N && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
                           (!HAS_BIAS || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                           (!HAS_RES || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
     __syncthreads();                                                 // every wave is done with the operand slots; no DMA in flight
@@ -300,6 +311,31 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
                 }
         __syncthreads();
         const int t = threadIdx.x;
+        if constexpr (SWIGLU) {
+            // image columns: wave wn at 64*wn = [gate 32 | up 32] of output columns (2*wn + p)*32 ..; a thread handles 8 output columns of a row
+            const int c8 = (t & 7) * 8, wn_ = c8 >> 5, lcol = wn_ * 64 + (c8 & 31);
+            const int n = n0 + (wn_ * 2 + p) * 32 + (c8 & 31);
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 32 + (t >> 3), m = m0 + row;
+                if (m >= M || n >= N) continue;
+                float g[8], u[8], o[8];
+                *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4);
+                *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4 + 16);
+                *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 32) * 4);
+                *reinterpret_cast<float4*>(u + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 32) * 4 + 16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {                        // same roundings as the bf16 path: bf16 gate / up, bf16 act
+                    g[r] = bfround(g[r]); u[r] = bfround(u[r]);
+                    o[r] = bfround(g[r] * sigmoidf_(g[r])) * u[r];
+                }
+                uint16_t* cp = C + (int64_t)m * ldc + n;
+                if (interior || (n + 7 < N && (reinterpret_cast<uintptr_t>(cp) & 15) == 0)) *reinterpret_cast<uint4*>(cp) = pack8(o);
+                else for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = f2bf(o[r]);
+            }
+            if (p == 0) __syncthreads();
+            continue;
+        }
         const int c8 = (t & 15) * 8;
         const int n = n0 + (c8 >> 6) * 128 + p * 64 + (c8 & 63);
         if (interior) {
@@ -378,6 +414,19 @@ int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_
     } while (0)
     if (bias && residual) Q4GO(true, true); else if (bias) Q4GO(true, false); else if (residual) Q4GO(false, true); else Q4GO(false, false);
 #undef Q4GO
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[M, N] = bf16(silu(gate)) * up with [gate | up] = dequant(A) dequant(B)^T, B = (2N, K): the SwiGLU tile (no-grad passes)
+int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
+                              int64_t sb_rows, uint16_t* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    const int tiles_m = st_cdiv(M, Q4_BM), tiles_n = st_cdiv(N, Q4_BN / 2);
+    auto kern = gemm_mx4_kernel<false, false, true>;
+    static bool configured = false;
+    if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_SMEM); configured = true; }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Q4_SMEM, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows, (const uint16_t*)nullptr,
+                       (const uint16_t*)nullptr, (int64_t)0, out, ldc, M, N, K, tiles_m, tiles_n);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -596,10 +596,13 @@ class Qwen25VL:
         x1 = self._linear(a, p + "o_w", residual=x0)
         h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
         if self.fp8 and h2.shape[0] > 256:
-            gu = self._linear(h2, p + "gu_w")
-            m = ops.swiglu_fwd(gu)
-            if save is None:
-                gu = None
+            if save is None:                                   # no-grad passes: SwiGLU in the fp8 tile's epilogue, gate|up never stored
+                xq, xs = ops.mxfp8_quantize(h2)
+                wq, ws = self.p.wq[p + "gu_w"]
+                gu, m = None, ops.gemm_mxfp8_swiglu(xq, xs, wq, ws)
+            else:
+                gu = self._linear(h2, p + "gu_w")
+                m = ops.swiglu_fwd(gu)
         else:
             if save is not None and self.unfused_swiglu_with_grad and h2.shape[0] > 256:
                 # with gradients the backward needs gate|up, and a GEMM epilogue that stores m AND gate|up (192 KiB per tile instead of

@@ -405,6 +405,17 @@ def gemm_mxfp8_nt(aq, sa, bq, sb, *, bias=None, residual=None, out=None):
     return out
 
 
+def gemm_mxfp8_swiglu(aq, sa, bq, sb, *, out=None):
+    """out[M, I] bf16 = silu(gate) * up with [gate | up] = dequant(aq, sa) @ dequant(bq, sb)^T, bq = (2I, K): SwiGLU in the fp8 tile's epilogue."""
+    M, K = aq.shape
+    I = bq.shape[0] // 2
+    assert bq.shape[1] == K and bq.shape[0] == 2 * I and sa.shape[0] == K // 128 and sb.shape[0] == K // 128
+    out = torch.empty(M, I, dtype=BF16, device=aq.device) if out is None else out
+    lib().st_gemm_mxfp8_swiglu(_p(aq), aq.stride(0), _p(sa), sa.shape[1], _p(bq), bq.stride(0), _p(sb), sb.shape[1], _p(out), out.stride(0),
+                               M, I, K, _s())
+    return out
+
+
 def gemm_select(variant: int):
     """Production tile of the training-shape GEMMs (st_gemm_select): 23 = 8-wave tile, 40 = 4-wave tile with the hand-scheduled loop."""
     lib().st_gemm_select(int(variant))

@@ -81,6 +81,27 @@ def _gemm_case(ops, M, N, K):
     assert rel < 0.05
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 128), (300, 200, 384), (1000, 18944, 3584)])
+def test_swiglu_epilogue_of_the_fp8_tile_matches_the_unfused_pair(ops, shape):
+    """st_gemm_mxfp8_swiglu = st_gemm_mxfp8_nt on [gate | up] followed by st_swiglu_fwd, bit for bit (same accumulation order per output
+    element, same roundings), incl. ragged rows / columns."""
+    M, I, K = shape
+    rs = np.random.RandomState(M + I + K)
+    blk = lambda R: np.repeat(2.0 ** rs.randint(-2, 3, (R, K // 32)), 32, axis=1)
+    a = _bf(rs.standard_normal((M, K)) * blk(M)).cuda()
+    b = _bf(rs.standard_normal((2 * I, K)) * blk(2 * I) * K ** -0.5).cuda()
+    aq, sa = ops.mxfp8_quantize(a)
+    bq, sb = ops.mxfp8_quantize(b)
+    prev = ops.gemm_mxfp8_select(4)
+    try:
+        want = ops.swiglu_fwd(ops.gemm_mxfp8_nt(aq, sa, bq, sb))
+        got = ops.gemm_mxfp8_swiglu(aq, sa, bq, sb)
+    finally:
+        ops.gemm_mxfp8_select(prev)
+    assert float(want.float().abs().max()) > 0.1
+    assert torch.equal(got, want)
+
+
 def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
     """Qwen25VL.enable_fp8 at the real 7B layer widths (1 LM layer + 2 ViT blocks, shared-prompt group of 6 rollouts): response
     log-probs with the four LM projections on the MX-fp8 path vs the bf16 engine and vs the fp32 oracle, and the straight-through

@@ -287,6 +287,19 @@ int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t 
  * the MLP's first product with the SwiGLU in the epilogue of the 4-wave fp8 tile (no-grad passes; roundings of st_gemm_swiglu). */
 int st_gemm_mxfp8_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
                          const uint32_t* SB, int64_t sb_rows, st_bf16* out, int64_t ldc, int M, int N, int K, st_stream_t stream);
+/* The same product with the result leaving as MX-fp8 (the operand of the down projection): q (M, N) e4m3 bytes + sq[N/128][sq_rows] scale
+ * dwords = st_mxfp8_quantize of st_gemm_mxfp8_swiglu's bf16 result, bit for bit; the bf16 activation is never stored.  N % 128 == 0. */
+int st_gemm_mxfp8_swiglu_q(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                           const uint32_t* SB, int64_t sb_rows, uint8_t* q, int64_t ldq, uint32_t* sq, int64_t sq_rows, int M, int N, int K,
+                           st_stream_t stream);
+/* Producers that emit the MX-fp8 operand of the next GEMM in the same pass (bit-identical to the bf16 op followed by st_mxfp8_quantize):
+ * st_rmsnorm_mxfp8: RMSNorm forward (HF rounding points, modeling_qwen2_5_vl.py:74-79); y optional (NULL: the bf16 result is not kept),
+ *   rstd optional.  H % 128 == 0.
+ * st_swiglu_mxfp8: SwiGLU forward on gu = [gate | up] (T, 2I); out optional.  I % 128 == 0. */
+int st_rmsnorm_mxfp8(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, st_bf16* y, int64_t ldy, uint8_t* q, int64_t ldq,
+                     uint32_t* scales, int64_t scale_rows, float* rstd, int T, int H, st_stream_t stream);
+int st_swiglu_mxfp8(const st_bf16* gu, int64_t ldgu, st_bf16* out, int64_t ldo, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows,
+                    int T, int I, st_stream_t stream);
 
 /* ---- optimizer: AnyPrecisionAdamW with bf16 states + Kahan compensation, one fused pass
  *      (verl/utils/torch_functional.py:253-329; ~10 eager passes in the reference) ---------------

@@ -55,6 +55,37 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// ---- MX-fp8 (OCP e4m3 elements, one e8m0 scale per 32 consecutive k): the quantiser's step for 8 consecutive k held by one lane; the 4
+// lanes of a block must be 4 consecutive lanes starting at a multiple of 4.  Shared exponent = floor(log2(amax)) - 8 (e4m3's largest
+// binade), elements = RNE(x * 2^-shared), saturated to +-448.  Returns the biased e8m0 scale byte; w = the 8 e4m3 bytes.
+__device__ __forceinline__ int mx_quant8(const float (&f)[8], uint32_t (&w)[2]) {
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;  // biased exponent of the scale 2^(floor(log2 amax) - 8)
+    e = e < 0 ? 0 : (e > 254 ? 254 : e);                      // amax == 0 (or subnormal) -> smallest scale, all elements quantise to 0
+    const float inv = __uint_as_float((uint32_t)(254 - e) << 23);   // 2^-(e - 127), exact
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(f[4 * h + j] * inv, -448.f), 448.f);
+        int packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], packed, true);
+        w[h] = (uint32_t)packed;
+    }
+    return e;
+}
+// the 4 block scales of a 128-k tile sit in lanes 0, 4, 8, 12 of its 16-lane group: the tile's scale dword (valid in every lane of the group)
+__device__ __forceinline__ uint32_t mx_scale_dword(int e, int lane) {
+    const int base = lane & 48;
+    const uint32_t s0 = (uint32_t)__shfl(e, base, 64), s1 = (uint32_t)__shfl(e, base + 4, 64);
+    const uint32_t s2 = (uint32_t)__shfl(e, base + 8, 64), s3 = (uint32_t)__shfl(e, base + 12, 64);
+    return s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+}
+
 // ---- gfx950 data-movement helpers ------------------------------------------------------------
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));

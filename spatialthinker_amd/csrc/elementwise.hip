@@ -66,6 +66,33 @@ __global__ void swiglu_fwd_kernel(const uint16_t* __restrict__ gu, int64_t ldgu,
     *reinterpret_cast<uint4*>(out + (int64_t)t * ldo + c) = pack8(o);
 }
 
+// SwiGLU forward feeding an MX-fp8 GEMM (config #5): out (optional) as swiglu_fwd_kernel, plus its MX-fp8 quantisation in the same pass
+// (bit-identical to st_swiglu_fwd followed by st_mxfp8_quantize).  One wave per (row, 512 columns), a lane = 8 consecutive columns.
+__global__ __launch_bounds__(256) void swiglu_mxfp8_kernel(const uint16_t* __restrict__ gu, int64_t ldgu, uint16_t* __restrict__ out, int64_t ldo,
+                                                          uint8_t* __restrict__ q, int64_t ldq, uint32_t* __restrict__ scales, int64_t scale_rows,
+                                                          int T, int I) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = (I + 511) / 512;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)T * chunks) return;
+    const int t = (int)(item / chunks), c = (int)(item % chunks) * 512 + lane * 8;
+    const bool live = c < I;                                  // I is a multiple of 128: a lane is all-in or all-out
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        float g[8], u[8];
+        unpack8(*reinterpret_cast<const uint4*>(gu + (int64_t)t * ldgu + c), g);
+        unpack8(*reinterpret_cast<const uint4*>(gu + (int64_t)t * ldgu + I + c), u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bfround(bfround(g[j] * sigmoidf_(g[j])) * u[j]);
+        if (out) *reinterpret_cast<uint4*>(out + (int64_t)t * ldo + c) = pack8(o);
+    }
+    uint32_t w[2];
+    const int e = mx_quant8(o, w);
+    if (live) *reinterpret_cast<uint2*>(q + (int64_t)t * ldq + c) = make_uint2(w[0], w[1]);
+    const uint32_t sd = mx_scale_dword(e, lane);
+    if (live && (lane & 15) == 0) scales[(int64_t)(c >> 7) * scale_rows + t] = sd;
+}
+
 __global__ void swiglu_bwd_kernel(const uint16_t* __restrict__ gu, int64_t ldgu, const uint16_t* __restrict__ dout,
                                   int64_t lddo, uint16_t* __restrict__ dgu, int64_t lddgu, int T, int I) {
     const int chunks = I >> 3;
@@ -550,6 +577,19 @@ int st_swiglu_fwd(const st_bf16* gu, int64_t ldgu, st_bf16* out, int64_t ldo, in
     if (T == 0) return 0;
     const int64_t n = (int64_t)T * (I / 8);
     hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(st_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gu, ldgu, out, ldo, T, I);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_swiglu_mxfp8(const st_bf16* gu, int64_t ldgu, st_bf16* out, int64_t ldo, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows,
+                    int T, int I, st_stream_t stream) {
+    if (!gu || !q || !scales || T < 0 || I <= 0 || (I % 128) || (ldgu & 7) || (out && (ldo & 7)) || (ldq & 7) || ldq < I || scale_rows < T ||
+        (((uintptr_t)q) & 7))
+        return ST_EINVAL;
+    if (T == 0) return 0;
+    const int64_t items = (int64_t)T * ((I + 511) / 512);
+    hipLaunchKernelGGL(swiglu_mxfp8_kernel, dim3(st_cdiv(items, 4)), dim3(256), 0, (hipStream_t)stream, gu, ldgu, out, ldo, q, ldq, scales,
+                       scale_rows, T, I);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -37,30 +37,11 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_kernel(const uint16_t* __r
     const bool live = k0 < K;                                 // K is a multiple of 128: a lane is all-in or all-out
     float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)r * ldx + k0), f);
-    float amax = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;  // biased exponent of the scale 2^(floor(log2 amax) - 8)
-    e = e < 0 ? 0 : (e > 254 ? 254 : e);                      // amax == 0 (or subnormal) -> smallest scale, all elements quantise to 0
-    const float inv = __uint_as_float((uint32_t)(254 - e) << 23);   // 2^-(e - 127), exact
     uint32_t w[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(f[4 * h + j] * inv, -448.f), 448.f);
-        int packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-        packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], packed, true);
-        w[h] = (uint32_t)packed;
-    }
+    const int e = mx_quant8(f, w);
     if (live) *reinterpret_cast<uint2*>(q + (int64_t)r * ldq + k0) = make_uint2(w[0], w[1]);
-    // the 4 block scales of a K-tile sit in lanes 0, 4, 8, 12 of its 16-lane group
-    const int base = lane & 48;
-    const uint32_t s0 = (uint32_t)__shfl(e, base, 64), s1 = (uint32_t)__shfl(e, base + 4, 64);
-    const uint32_t s2 = (uint32_t)__shfl(e, base + 8, 64), s3 = (uint32_t)__shfl(e, base + 12, 64);
-    if (live && (lane & 15) == 0) scales[(int64_t)(k0 >> 7) * scale_rows + r] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+    const uint32_t sd = mx_scale_dword(e, lane);
+    if (live && (lane & 15) == 0) scales[(int64_t)(k0 >> 7) * scale_rows + r] = sd;
 }
 
 // ------------------------------------------------------------------------------ GEMM
@@ -186,7 +167,7 @@ int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_
                        int64_t sb_rows, const uint16_t* bias, const uint16_t* residual, int64_t ldr, uint16_t* out, int64_t ldc, int M, int N,
                        int K, hipStream_t s);
 int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
-                              int64_t sb_rows, uint16_t* out, int64_t ldc, int M, int N, int K, hipStream_t s);
+                              int64_t sb_rows, void* out, int64_t ldc, uint32_t* sq, int64_t sq_rows, int M, int N, int K, hipStream_t s);
 static int g_fp8_tile = -1;
 static int fp8_tile_waves() {
     if (g_fp8_tile < 0) { const char* e = getenv("ST_FP8_TILE"); g_fp8_tile = (e && atoi(e) == 8) ? 8 : 4; }
@@ -248,7 +229,20 @@ int st_gemm_mxfp8_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int6
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     StProfScope ps(ST_K_GEMM_FP8, s, 4.0 * (double)M * (double)N * (double)K);
-    return st_launch_gemm_mx4_swiglu(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, out, ldc, M, N, K, s);
+    return st_launch_gemm_mx4_swiglu(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, out, ldc, nullptr, 0, M, N, K, s);
+}
+
+int st_gemm_mxfp8_swiglu_q(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                           const uint32_t* SB, int64_t sb_rows, uint8_t* q, int64_t ldq, uint32_t* sq, int64_t sq_rows, int M, int N, int K,
+                           st_stream_t stream) {
+    if (!A || !B || !SA || !SB || !q || !sq || M <= 0 || N <= 0 || K <= 0 || (K % 128) || (N % 128) || (lda & 15) || (ldb & 15) || lda < K ||
+        ldb < K || ldq < N || (ldq & 7) || sa_rows < M || sb_rows < 2 * (int64_t)N || sq_rows < M || (sa_rows & 3) || (sb_rows & 3) ||
+        (sq_rows & 3) || sa_rows < 4 || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15) || (((uintptr_t)SA) & 15) || (((uintptr_t)SB) & 15) ||
+        (((uintptr_t)q) & 7))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM_FP8, s, 4.0 * (double)M * (double)N * (double)K);
+    return st_launch_gemm_mx4_swiglu(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, q, ldq, sq, sq_rows, M, N, K, s);
 }
 
 }  // extern "C"

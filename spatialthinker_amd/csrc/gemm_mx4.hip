@@ -88,11 +88,16 @@ static_assert(q4_dma_slot(11) == 24 && q4_dma_slot(12) == 26 && q4_dma_slot(15) 
 // SWIGLU: B = [gate rows | up rows] (2N x K, N = output width); the B tile interleaves 32 gate rows with the 32 matching up rows, so a
 // lane holds gate and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
 // bf16(silu(gate)) * up for 128 output columns per workgroup — the roundings of gemm_asm4.hip's SwiGLU epilogue (bf16 gate / up / act).
-template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false>
+// QOUT (SwiGLU tiles): the result leaves as MX-fp8 — the operand of the down projection — instead of bf16: C = e4m3 bytes (ldc in bytes),
+// SQ[tile column][row] = the scale dword of the tile's 128 output columns (= one K-tile of the next GEMM), exactly what st_mxfp8_quantize
+// makes of the bf16 result (same rounding to bf16 first).
+template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false, bool QOUT = false>
 __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint32_t* __restrict__ SA, int64_t sa_rows,
                                                       const uint8_t* __restrict__ B, int64_t ldb, const uint32_t* __restrict__ SB, int64_t sb_rows,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
-                                                      uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+                                                      uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n,
+                                                      uint32_t* __restrict__ SQ, int64_t sq_rows) {
+    static_assert(!QOUT || SWIGLU, "fp8 output: SwiGLU tiles only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,6 +323,27 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
 #pragma unroll 2
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 32 + (t >> 3), m = m0 + row;
+                if constexpr (QOUT) {
+                    // N % 128 == 0 (the next GEMM's K): no column edge; rows past M compute on clamped operands and store nothing.
+                    // The 4 threads of an MX block (32 output columns) are 4 consecutive lanes: t & 3.
+                    float g[8], u[8], o[8];
+                    *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4);
+                    *reinterpret_cast<float4*>(g + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4 + 16);
+                    *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 32) * 4);
+                    *reinterpret_cast<float4*>(u + 4) = *reinterpret_cast<const float4*>(smem + row * ROWB + (lcol + 32) * 4 + 16);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        g[r] = bfround(g[r]); u[r] = bfround(u[r]);
+                        o[r] = bfround(bfround(g[r] * sigmoidf_(g[r])) * u[r]);
+                    }
+                    uint32_t wq[2];
+                    const int e = mx_quant8(o, wq);
+                    if (m < M) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(C) + (int64_t)m * ldc + n) = make_uint2(wq[0], wq[1]);
+                        if ((t & 3) == 0) reinterpret_cast<uint8_t*>(SQ + (int64_t)(n0 >> 7) * sq_rows + m)[wn_ * 2 + p] = (uint8_t)e;
+                    }
+                    continue;
+                }
                 if (m >= M || n >= N) continue;
                 float g[8], u[8], o[8];
                 *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(smem + row * ROWB + lcol * 4);
@@ -410,7 +436,7 @@ int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_
         static bool configured = false;                                                                                           \
         if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_SMEM); configured = true; } \
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Q4_SMEM, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows, bias, residual, \
-                           ldr, out, ldc, M, N, K, tiles_m, tiles_n);                                                             \
+                           ldr, out, ldc, M, N, K, tiles_m, tiles_n, (uint32_t*)nullptr, (int64_t)0);                             \
     } while (0)
     if (bias && residual) Q4GO(true, true); else if (bias) Q4GO(true, false); else if (residual) Q4GO(false, true); else Q4GO(false, false);
 #undef Q4GO
@@ -418,15 +444,21 @@ int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_
     return 0;
 }
 
-// out[M, N] = bf16(silu(gate)) * up with [gate | up] = dequant(A) dequant(B)^T, B = (2N, K): the SwiGLU tile (no-grad passes)
+// out[M, N] = bf16(silu(gate)) * up with [gate | up] = dequant(A) dequant(B)^T, B = (2N, K): the SwiGLU tile (no-grad passes);
+// sq != nullptr: out is the MX-fp8 quantisation of that result (bytes, ldc in bytes) with its scale dwords in sq
 int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
-                              int64_t sb_rows, uint16_t* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+                              int64_t sb_rows, void* out, int64_t ldc, uint32_t* sq, int64_t sq_rows, int M, int N, int K, hipStream_t s) {
     const int tiles_m = st_cdiv(M, Q4_BM), tiles_n = st_cdiv(N, Q4_BN / 2);
-    auto kern = gemm_mx4_kernel<false, false, true>;
-    static bool configured = false;
-    if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_SMEM); configured = true; }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Q4_SMEM, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows, (const uint16_t*)nullptr,
-                       (const uint16_t*)nullptr, (int64_t)0, out, ldc, M, N, K, tiles_m, tiles_n);
+#define Q4SW(QO)                                                                                                                  \
+    do {                                                                                                                          \
+        auto kern = gemm_mx4_kernel<false, false, true, QO>;                                                                      \
+        static bool configured = false;                                                                                           \
+        if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_SMEM); configured = true; } \
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Q4_SMEM, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows,        \
+                           (const uint16_t*)nullptr, (const uint16_t*)nullptr, (int64_t)0, (uint16_t*)out, ldc, M, N, K, tiles_m, tiles_n, sq, sq_rows); \
+    } while (0)
+    if (sq) Q4SW(true); else Q4SW(false);
+#undef Q4SW
     ST_CHECK_LAUNCH();
     return 0;
 }

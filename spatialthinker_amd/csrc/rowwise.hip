@@ -139,6 +139,48 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const uint16_t* __rest
     }
 }
 
+// RMSNorm forward feeding an MX-fp8 GEMM (config #5): the same row arithmetic, and the bf16 result is quantised in the same pass (e4m3 +
+// e8m0 block scales in the layout of st_mxfp8_quantize: bit-identical to st_rmsnorm_fwd followed by st_mxfp8_quantize); the bf16 result
+// itself is written only when the caller keeps it (y != nullptr: the weight-gradient GEMM of a pass with gradients).  H % 128 == 0:
+// a lane's 8 consecutive columns never straddle an MX block, 4 lanes = one block, 16 lanes = one 128-column scale dword.
+__global__ __launch_bounds__(256) void rmsnorm_mxfp8_kernel(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ w, float eps,
+                                                           uint16_t* __restrict__ y, int64_t ldy, uint8_t* __restrict__ q, int64_t ldq,
+                                                           uint32_t* __restrict__ scales, int64_t scale_rows, float* __restrict__ rstd_out,
+                                                           int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    float ss = 0.f;
+    for (int i = lane * 8; i < H; i += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(xr + i), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+    for (int i0 = 0; i0 < H; i0 += 512) {                         // uniform trip count: the block reductions below need every lane
+        const int i = i0 + lane * 8;
+        const bool live = i < H;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            float wf[8];
+            unpack8(*reinterpret_cast<const uint4*>(xr + i), f);
+            unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = bfround(wf[j] * bfround(f[j] * rstd));
+            if (y) *reinterpret_cast<uint4*>(y + (int64_t)row * ldy + i) = pack8(f);
+        }
+        uint32_t wq[2];
+        const int e = mx_quant8(f, wq);
+        if (live) *reinterpret_cast<uint2*>(q + (int64_t)row * ldq + i) = make_uint2(wq[0], wq[1]);
+        const uint32_t sd = mx_scale_dword(e, lane);
+        if (live && (lane & 15) == 0) scales[(int64_t)(i >> 7) * scale_rows + row] = sd;
+    }
+}
+
 // Small-T variant (decode: one token per live sequence): one 256-thread workgroup per row so a 64-row call still puts 64
 // workgroups in flight and the row is touched once per thread (row kept in registers between the two passes).
 __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(const uint16_t* __restrict__ x, int64_t ldx,
@@ -262,6 +304,18 @@ int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, s
         hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, H);
     else
         hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_rmsnorm_mxfp8(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, st_bf16* y, int64_t ldy, uint8_t* q, int64_t ldq,
+                     uint32_t* scales, int64_t scale_rows, float* rstd, int T, int H, st_stream_t stream) {
+    if (!x || !w || !q || !scales || T < 0 || H <= 0 || (H % 128) || (ldx & 7) || (y && (ldy & 7)) || (ldq & 7) || ldq < H || scale_rows < T ||
+        (((uintptr_t)q) & 7))
+        return ST_EINVAL;
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(rmsnorm_mxfp8_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, eps, y, ldy, q, ldq, scales,
+                       scale_rows, rstd, T, H);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -185,6 +185,7 @@ class ParamStore:
         self.grad = self.g = None
         self.m = self.v = self.c = None
         self.wq = None                   # MX-fp8 copies of the LM projection weights (refresh_fp8), only in fp8 mode
+        self.wqt = None                  # ... transposed copies for the fp8 input-gradient GEMMs (enable_fp8(dgrad=True))
         self.master = None               # fp32 master weights (enable_fp32_master), None = the bf16 weights ARE the parameters
         if trainable:
             self.grad = torch.zeros(off, dtype=F32, device=device)
@@ -219,11 +220,17 @@ class ParamStore:
 
     def refresh_fp8(self):
         """MX-fp8 copies (e4m3 bytes + e8m0 block scales) of the LM projection weights for the fp8 forward GEMMs (Qwen25VL.fp8);
-        re-quantised from the bf16 master weights after every optimizer step.  ~0.53 bytes per parameter on top of the bf16 store."""
+        re-quantised from the bf16 master weights after every optimizer step.  ~0.53 bytes per parameter on top of the bf16 store.
+        fp8_dgrad: a second copy of each weight TRANSPOSED and quantised along the output dimension — dX = dY W contracts over it, and
+        MX blocks must run along the contraction — for the fp8 input-gradient GEMMs (same size again)."""
         self.wq = {}
+        self.wqt = {} if getattr(self, "fp8_dgrad", False) else None
         for i in range(self.cfg.num_layers):
             for nm in ("qkv_w", "o_w", "gu_w", "down_w"):
-                self.wq[f"l.{i}.{nm}"] = ops.mxfp8_quantize(self.w[f"l.{i}.{nm}"])
+                w = self.w[f"l.{i}.{nm}"]
+                self.wq[f"l.{i}.{nm}"] = ops.mxfp8_quantize(w)
+                if self.wqt is not None:
+                    self.wqt[f"l.{i}.{nm}"] = ops.mxfp8_quantize(ops.transpose(w))
 
     # ---- HF state_dict interop (names of transformers Qwen2_5_VLForConditionalGeneration) -------------
     def load_hf_state_dict(self, sd: Dict[str, torch.Tensor], target: Optional[torch.Tensor] = None):
@@ -365,20 +372,40 @@ class Qwen25VL:
         self.recompute_light = False     # see _lm_layer_fwd
         self.unfused_swiglu_with_grad = os.environ.get("ST_SWIGLU_UNFUSED_GRAD", "1") != "0"      # see _lm_layer_fwd
         self.fp8 = False                 # config #5: the LM's four projection GEMMs run forward in MX-fp8 (enable_fp8)
+        self.fp8_dgrad = False           # ... and their input-gradient GEMMs too
 
-    def enable_fp8(self, on: bool = True):
+    def enable_fp8(self, on: bool = True, dgrad: bool = False):
         """Forward GEMMs of the LM layers (qkv, o, gate/up, down — 93 % of the forward FLOPs) on the block-scaled fp8 MFMA path:
         activations are quantised on the fly (one HBM pass each), weights once per optimizer step.  Attention, norms, the lm_head,
-        the ViT and the whole backward stay bf16 (straight-through: gradients are those of the bf16 layer evaluated at the fp8
-        forward's activations).  Tolerance: DESIGN.md §4 (fp8)."""
+        the ViT and the weight gradients stay bf16 (straight-through: gradients are those of the bf16 layer evaluated at the fp8
+        forward's activations).  dgrad=True also runs the four input-gradient GEMMs dX = dY W of every LM layer in MX-fp8 (dY quantised
+        on the fly along its feature dimension, a transposed fp8 copy of W); dW = dY^T X contracts over tokens and stays bf16.
+        Tolerance: DESIGN.md §4 (fp8)."""
+        if on and (self.cfg.hidden_size % 128 or self.cfg.intermediate_size % 128):
+            raise ValueError("fp8 mode needs hidden and intermediate sizes that are multiples of 128 (MX K-tiles)")
         self.fp8 = bool(on)
-        if on and not getattr(self.p, "wq", None):
+        self.fp8_dgrad = bool(on and dgrad)
+        self.p.fp8_dgrad = self.fp8_dgrad
+        if on and (not getattr(self.p, "wq", None) or (self.fp8_dgrad and not getattr(self.p, "wqt", None))):
             self.p.refresh_fp8()
         if not on:
             self.p.wq = None
+            self.p.wqt = None
 
-    def _linear(self, x, name, bias=None, residual=None):
-        """y = x W^T (+bias)(+residual) for an LM projection: bf16 MFMA GEMM, or MX-fp8 when enabled and the shape fits its tile."""
+    def _dgrad(self, dy, name):
+        """dX = dY W for an LM projection: bf16 (W read as stored, contraction-major) or MX-fp8 against the transposed fp8 copy."""
+        if self.fp8_dgrad and dy.shape[0] > 256 and dy.shape[1] % 128 == 0:
+            dq, ds = ops.mxfp8_quantize(dy)
+            wq, ws = self.p.wqt[name]
+            return ops.gemm_mxfp8_nt(dq, ds, wq, ws)
+        return ops.gemm_nn(dy, self.p.w[name])
+
+    def _linear(self, x, name, bias=None, residual=None, xq=None):
+        """y = x W^T (+bias)(+residual) for an LM projection: bf16 MFMA GEMM, or MX-fp8 when enabled and the shape fits its tile
+        (xq: the input's MX-fp8 operand (q, scales) when its producer already emitted it)."""
+        if xq is not None:
+            wq, ws = self.p.wq[name]
+            return ops.gemm_mxfp8_nt(xq[0], xq[1], wq, ws, bias=bias, residual=residual)
         w = self.p.w[name]
         if self.fp8 and x.shape[0] > 256 and x.shape[1] % 128 == 0:
             xq, xs = ops.mxfp8_quantize(x)
@@ -583,8 +610,16 @@ class Qwen25VL:
         c, w = self.cfg, self.p.w
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
-        h1, r1 = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps)
-        qkv = self._linear(h1, p + "qkv_w", bias=w[p + "qkv_b"])
+        # fp8 mode: the producers of a projection's input emit its MX-fp8 operand in the same pass (RMSNorm, SwiGLU — bit-identical to the
+        # bf16 op + st_mxfp8_quantize); the bf16 tensor itself is written only when the backward keeps it for the weight gradient
+        fp8 = self.fp8 and x0.shape[0] > 256
+        keep = save is not None and not self.recompute_light
+        if fp8:
+            h1, r1, h1q = ops.rmsnorm_mxfp8(x0, w[p + "in_norm"], c.rms_eps, want_y=keep, want_rstd=save is not None)
+            qkv = self._linear(None, p + "qkv_w", bias=w[p + "qkv_b"], xq=h1q)
+        else:
+            h1, r1 = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps)
+            qkv = self._linear(h1, p + "qkv_w", bias=w[p + "qkv_b"])
         ops.rope_apply_(qkv, b.cos, b.sin, nq + nkv, D)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         if kv_out is not None:
@@ -594,16 +629,18 @@ class Qwen25VL:
         _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a,
                                   k_pre=kpre, v_pre=vpre, pairs=b.pairs)
         x1 = self._linear(a, p + "o_w", residual=x0)
-        h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
-        if self.fp8 and h2.shape[0] > 256:
-            if save is None:                                   # no-grad passes: SwiGLU in the fp8 tile's epilogue, gate|up never stored
-                xq, xs = ops.mxfp8_quantize(h2)
-                wq, ws = self.p.wq[p + "gu_w"]
-                gu, m = None, ops.gemm_mxfp8_swiglu(xq, xs, wq, ws)
+        if fp8:
+            h2, r2, h2q = ops.rmsnorm_mxfp8(x1, w[p + "post_norm"], c.rms_eps, want_y=keep, want_rstd=save is not None)
+            wq, ws = self.p.wq[p + "gu_w"]
+            if save is None:                                   # no-grad passes: SwiGLU + quantiser in the fp8 tile's epilogue — neither
+                gu, m = None, None                             # gate|up nor the bf16 activation is ever stored
+                mq = ops.gemm_mxfp8_swiglu_q(h2q[0], h2q[1], wq, ws)
             else:
-                gu = self._linear(h2, p + "gu_w")
-                m = ops.swiglu_fwd(gu)
+                gu = ops.gemm_mxfp8_nt(h2q[0], h2q[1], wq, ws)
+                m, mq = ops.swiglu_mxfp8(gu, want_out=keep)
+            x2 = self._linear(None, p + "down_w", residual=x1, xq=mq)
         else:
+            h2, r2 = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps)
             if save is not None and self.unfused_swiglu_with_grad and h2.shape[0] > 256:
                 # with gradients the backward needs gate|up, and a GEMM epilogue that stores m AND gate|up (192 KiB per tile instead of
                 # 128) costs more than the stand-alone SwiGLU pass over the kept gate|up (tools/swiglu_ab.py, T = 21504: 4.45-4.54 ms
@@ -612,7 +649,8 @@ class Qwen25VL:
                 m = ops.swiglu_fwd(gu)
             else:
                 gu, m = ops.gemm_swiglu(h2, w[p + "gu_w"], want_gu=save is not None)  # SwiGLU in the epilogue (no-grad passes: m only)
-        x2 = self._linear(m, p + "down_w", residual=x1)
+        if not fp8:
+            x2 = self._linear(m, p + "down_w", residual=x1)
         if save is not None:
             # h1, h2 (RMSNorm outputs) and m (SwiGLU output) are cheap row-wise functions of tensors that are kept anyway: with
             # recompute_light the backward recomputes them (bit-identical kernels) instead of holding 1/3 of the activation
@@ -633,20 +671,20 @@ class Qwen25VL:
             h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
             h1, _ = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps, want_rstd=False)
         self._dw(g[p + "down_w"], dx2, m, None)
-        dm = ops.gemm_nn(dx2, w[p + "down_w"])
+        dm = self._dgrad(dx2, p + "down_w")
         dgu = ops.swiglu_bwd(gu, dm)
         self._dw(g[p + "gu_w"], dgu, h2, None)
-        dh2 = ops.gemm_nn(dgu, w[p + "gu_w"])
+        dh2 = self._dgrad(dgu, p + "gu_w")
         dx1 = ops.rmsnorm_bwd(x1, w[p + "post_norm"], r2, dh2, dres=dx2, dw_accum=g[p + "post_norm"])
         self._dw(g[p + "o_w"], dx1, a, None)
-        da = ops.gemm_nn(dx1, w[p + "o_w"])
+        da = self._dgrad(dx1, p + "o_w")
         dqkv = torch.zeros_like(qkv)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
                          self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
         ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
         self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
-        dh1 = ops.gemm_nn(dqkv, w[p + "qkv_w"])
+        dh1 = self._dgrad(dqkv, p + "qkv_w")
         return ops.rmsnorm_bwd(x0, w[p + "in_norm"], r1, dh1, dres=dx1, dw_accum=g[p + "in_norm"])
 
     def _head_fwd(self, x: torch.Tensor, b: DeviceBatch, temperature: float):

@@ -416,6 +416,43 @@ def gemm_mxfp8_swiglu(aq, sa, bq, sb, *, out=None):
     return out
 
 
+def _mx_buffers(R, K, device):
+    rows = (R + 3) // 4 * 4
+    return torch.empty(R, K, dtype=torch.uint8, device=device), torch.zeros(K // 128, rows, dtype=torch.int32, device=device)
+
+
+def gemm_mxfp8_swiglu_q(aq, sa, bq, sb):
+    """MX-fp8 (q, scales) of silu(gate) * up — gemm_mxfp8_swiglu + mxfp8_quantize in the tile's epilogue; the bf16 activation is never stored."""
+    M, K = aq.shape
+    I = bq.shape[0] // 2
+    assert bq.shape[1] == K and bq.shape[0] == 2 * I and I % 128 == 0
+    q, sc = _mx_buffers(M, I, aq.device)
+    lib().st_gemm_mxfp8_swiglu_q(_p(aq), aq.stride(0), _p(sa), sa.shape[1], _p(bq), bq.stride(0), _p(sb), sb.shape[1], _p(q), q.stride(0),
+                                 _p(sc), sc.shape[1], M, I, K, _s())
+    return q, sc
+
+
+def rmsnorm_mxfp8(x, w, eps, want_y=True, want_rstd=True):
+    """RMSNorm forward + MX-fp8 quantisation of its bf16 result in one pass: (y | None, rstd | None, (q, scales))."""
+    T, H = x.shape
+    y = torch.empty(T, H, dtype=BF16, device=x.device) if want_y else None
+    rstd = torch.empty(T, dtype=F32, device=x.device) if want_rstd else None
+    q, sc = _mx_buffers(T, H, x.device)
+    lib().st_rmsnorm_mxfp8(_p(x), x.stride(0), _p(w), float(eps), _p(y), y.stride(0) if want_y else 0, _p(q), q.stride(0), _p(sc), sc.shape[1],
+                           _p(rstd), T, H, _s())
+    return y, rstd, (q, sc)
+
+
+def swiglu_mxfp8(gu, want_out=True):
+    """SwiGLU forward + MX-fp8 quantisation of its bf16 result in one pass: (out | None, (q, scales))."""
+    T, I2 = gu.shape
+    I = I2 // 2
+    out = torch.empty(T, I, dtype=BF16, device=gu.device) if want_out else None
+    q, sc = _mx_buffers(T, I, gu.device)
+    lib().st_swiglu_mxfp8(_p(gu), gu.stride(0), _p(out), out.stride(0) if want_out else 0, _p(q), q.stride(0), _p(sc), sc.shape[1], T, I, _s())
+    return out, (q, sc)
+
+
 def gemm_select(variant: int):
     """Production tile of the training-shape GEMMs (st_gemm_select): 23 = 8-wave tile, 40 = 4-wave tile with the hand-scheduled loop."""
     lib().st_gemm_select(int(variant))

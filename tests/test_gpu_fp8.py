@@ -102,6 +102,62 @@ def test_swiglu_epilogue_of_the_fp8_tile_matches_the_unfused_pair(ops, shape):
     assert torch.equal(got, want)
 
 
+def _same_mx(got, want, R):
+    assert torch.equal(got[0], want[0])
+    assert torch.equal(got[1][:, :R], want[1][:, :R])
+
+
+@pytest.mark.parametrize("shape", [(5, 128), (301, 3584), (1100, 2048), (2000, 3584)])
+def test_rmsnorm_with_fp8_output_matches_rmsnorm_then_quantiser(ops, shape):
+    """Bit-identical to st_rmsnorm_fwd + st_mxfp8_quantize where st_rmsnorm_fwd runs its wave-per-row kernel (T > 1024 or H > 4096: the
+    same summation order); below that st_rmsnorm_fwd sums a row with a whole workgroup, rstd may differ in the last bit and y by one bf16
+    step — there the quantised output must still be exactly the quantisation of the kernel's own y."""
+    T, H = shape
+    rs = np.random.RandomState(T + H)
+    x = _bf(rs.standard_normal((T, H)) * np.exp(rs.uniform(-3, 3, (T, 1)))).cuda()
+    w = _bf(1.0 + 0.3 * rs.standard_normal(H)).cuda()
+    y0, r0 = ops.rmsnorm_fwd(x, w, 1e-6)
+    y1, r1, got = ops.rmsnorm_mxfp8(x, w, 1e-6)
+    if T > 1024 or H > 4096:
+        assert torch.equal(y1, y0) and torch.equal(r1, r0)
+    else:
+        assert float(((r1 - r0).abs() / r0).max()) < 1e-6
+        assert float(((y1.float() - y0.float()).abs() / y0.float().abs().clamp_min(1e-30)).max()) <= 2.0 ** -7
+    want = ops.mxfp8_quantize(y1)
+    _same_mx(got, want, T)
+    y2, r2, got2 = ops.rmsnorm_mxfp8(x, w, 1e-6, want_y=False, want_rstd=False)
+    assert y2 is None and r2 is None
+    _same_mx(got2, want, T)
+
+
+@pytest.mark.parametrize("shape", [(3, 128), (301, 18944), (700, 1408)])
+def test_swiglu_with_fp8_output_matches_swiglu_then_quantiser(ops, shape):
+    T, I = shape
+    rs = np.random.RandomState(T + I)
+    gu = _bf(rs.standard_normal((T, 2 * I)) * 2.0).cuda()
+    m0 = ops.swiglu_fwd(gu)
+    want = ops.mxfp8_quantize(m0)
+    m1, got = ops.swiglu_mxfp8(gu)
+    assert torch.equal(m1, m0)
+    _same_mx(got, want, T)
+    m2, got2 = ops.swiglu_mxfp8(gu, want_out=False)
+    assert m2 is None
+    _same_mx(got2, want, T)
+
+
+@pytest.mark.parametrize("shape", [(256, 128, 128), (300, 256, 384), (1000, 18944, 3584)])
+def test_swiglu_epilogue_with_fp8_output_matches_epilogue_then_quantiser(ops, shape):
+    M, I, K = shape
+    rs = np.random.RandomState(M + I + K + 1)
+    blk = lambda R: np.repeat(2.0 ** rs.randint(-2, 3, (R, K // 32)), 32, axis=1)
+    aq, sa = ops.mxfp8_quantize(_bf(rs.standard_normal((M, K)) * blk(M)).cuda())
+    bq, sb = ops.mxfp8_quantize(_bf(rs.standard_normal((2 * I, K)) * blk(2 * I) * K ** -0.5).cuda())
+    want = ops.mxfp8_quantize(ops.gemm_mxfp8_swiglu(aq, sa, bq, sb))
+    got = ops.gemm_mxfp8_swiglu_q(aq, sa, bq, sb)
+    assert int((want[0] != 0).sum()) > M * I // 2
+    _same_mx(got, want, M)
+
+
 def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
     """Qwen25VL.enable_fp8 at the real 7B layer widths (1 LM layer + 2 ViT blocks, shared-prompt group of 6 rollouts): response
     log-probs with the four LM projections on the MX-fp8 path vs the bf16 engine and vs the fp32 oracle, and the straight-through
@@ -134,8 +190,8 @@ def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
     li = dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64))
     kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
     res = {}
-    for mode in ("bf16", "fp8"):
-        eng.enable_fp8(mode == "fp8")
+    for mode in ("bf16", "fp8", "fp8+dgrad"):
+        eng.enable_fp8(mode != "bf16", dgrad=mode == "fp8+dgrad")
         store.grad.zero_()
         lp_e, _ = eng.forward_backward(b, li, 1.0, **kw)
         grads = store.export_hf(store.g)
@@ -148,7 +204,14 @@ def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
     assert store.wq is None
     assert not torch.equal(res["fp8"][2], res["bf16"][2])      # the fp8 path really ran
     # measured (round 2): bf16 0.0140 / 2.3-5.1 %, fp8 0.209 / 24-37 % — each projection carries ~4.2 % relative L2 quantisation error
-    # (3 mantissa bits on both operands), which a random-init layer passes on undamped; bounds at 1.3x the measurement
+    # (3 mantissa bits on both operands), which a random-init layer passes on undamped; bounds at 1.3x the measurement.  Round 4 (4-wave
+    # tile: another fp32 summation order, so other elements sit on e4m3 rounding boundaries): fp8 0.263 / 26-41 %, fp8 + dgrad 27-44 %.
     assert res["fp8"][0] <= 0.28
     for n_ in res["bf16"][1]:
         assert res["fp8"][1][n_] <= 0.49, n_
+    # fp8 input gradients on top (round 4): the forward is the same (same log-probs), the gradients pass through four more quantised
+    # products per layer
+    assert torch.equal(res["fp8+dgrad"][2], res["fp8"][2])
+    assert any(res["fp8+dgrad"][1][n_] != res["fp8"][1][n_] for n_ in res["fp8"][1])       # the fp8 dgrad path really ran
+    for n_ in res["bf16"][1]:
+        assert res["fp8+dgrad"][1][n_] <= 0.60, n_

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm_mxfp8_kernel(const uint8_t* __restri
 // gemm_mx4.hip: the 4-wave hand-scheduled tile (default); ST_FP8_TILE=8 keeps the 8-wave tile above for A/B runs
 int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
                        int64_t sb_rows, const uint16_t* bias, const uint16_t* residual, int64_t ldr, uint16_t* out, int64_t ldc, int M, int N,
-                       int K, hipStream_t s);
+                       int K, int dbg, hipStream_t s);
 int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
                               int64_t sb_rows, void* out, int64_t ldc, uint32_t* sq, int64_t sq_rows, int M, int N, int K, hipStream_t s);
 static int g_fp8_tile = -1;
@@ -177,7 +177,7 @@ static int fp8_tile_waves() {
 extern "C" {
 
 int st_gemm_mxfp8_select(int waves) {
-    if (waves != 4 && waves != 8) return ST_EINVAL;
+    if (waves != 4 && waves != 8 && !(waves >= 41 && waves <= 44) && waves != 50 && waves != 52 && waves != 56) return ST_EINVAL;
     g_fp8_tile = waves;
     return 0;
 }
@@ -205,8 +205,9 @@ int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t 
     const int tiles_m = st_cdiv(M, Q_BM), tiles_n = st_cdiv(N, Q_BN);
     constexpr int smem = 2 * Q_STAGE;
     StProfScope ps(ST_K_GEMM_FP8, s, 2.0 * (double)M * (double)N * (double)K);
-    if (fp8_tile_waves() == 4)
-        return st_launch_gemm_mx4(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, bias, residual, ldr, out, ldc, M, N, K, s);
+    if (fp8_tile_waves() != 8)        // 4, or 41..44 = the 4-wave tile's timing experiments (tools/mx4_ksweep.py; wrong results), 50 / 52 / 56 = its K-tile schedules 0 / 2 / 6 (correct)
+        return st_launch_gemm_mx4(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, bias, residual, ldr, out, ldc, M, N, K,
+                                  fp8_tile_waves() > 40 ? fp8_tile_waves() - 40 : 0, s);
 #define QGO(HB, HR)                                                                                                              \
     do {                                                                                                                         \
         auto kern = gemm_mxfp8_kernel<HB, HR>;                                                                                   \

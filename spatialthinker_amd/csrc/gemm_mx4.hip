@@ -67,23 +67,47 @@ __device__ __forceinline__ void q4_dma1(uint32_t voff, i32x4 srd, uint32_t soff)
 __device__ __forceinline__ void q4_m0_set(uint32_t v) { asm volatile("s_mov_b32 m0, %0" : : "s"(v) : "memory"); }
 __device__ __forceinline__ void q4_m0_next() { asm volatile("s_add_u32 m0, m0, 0x400" : : : "memory", "scc"); }
 __device__ __forceinline__ void q4_barrier() { asm volatile("s_barrier" : : : "memory"); }
-template <int N> __device__ __forceinline__ void q4_wait_lgkm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    else if constexpr (N == 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
-    else static_assert(N < 0, "add the lgkmcnt literal");
-}
-template <int N> __device__ __forceinline__ void q4_wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else static_assert(N < 0, "add the vmcnt literal");
-}
+template <int N> __device__ __forceinline__ void q4_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void q4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 __device__ __forceinline__ i32x8 q4_frag(const i32x4& lo, const i32x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-// MFMA slot of operand copy j (0..15: A copies 0..7, then B copies 0..7) of tile t+2: two of every three slots from 8 on
-__host__ __device__ constexpr int q4_dma_slot(int j) { return 8 + (j >> 1) * 3 + (j & 1); }
-static_assert(q4_dma_slot(11) == 24 && q4_dma_slot(12) == 26 && q4_dma_slot(15) == 30, "12 operand copies before the vmcnt(14) of slot 25, 4 behind it");
+// The K-tile schedule (MFMA slots 0..31) as compile-time data, so that variants can be timed against each other (tools/mx4_ksweep.py):
+//   RD1      k-step-1 reads per slot from slot 0 on (24 reads: per 6, four fragment halves + two scale dwords)
+//   BAR1     slot of lgkmcnt(0) + barrier #1 (every wave is done reading this tile's slot)
+//   SDMA     slot of the two scale copies of tile t+2;  dma_slot(j): slot of operand copy j (0..15: A copies 0..7, then B copies 0..7)
+//   BAR2     slot of the vmcnt wait + barrier #2 (tile t+1 has landed for every wave)
+//   RD0, RD0N  first slot and reads per slot of the 24 reads of (t+1, k-step 0); the tile ends with lgkmcnt(6): B1..B3 land in the next tile
+template <int V> struct Q4Sched;
+template <> struct Q4Sched<0> {              // first version: reads bunched at both ends of the tile (6 and 5 per slot), copies on two of every three slots
+    static constexpr int RD1 = 6, BAR1 = 6, SDMA = 7, BAR2 = 25, RD0 = 26, RD0N = 5;
+    static constexpr int dma_slot(int j) { return 8 + (j >> 1) * 3 + (j & 1); }
+};
+template <> struct Q4Sched<2> {              // both read groups spread 3 per slot, barrier #1 at 13, copies dense from 14, barrier #2 at 23
+    static constexpr int RD1 = 3, BAR1 = 13, SDMA = 13, BAR2 = 23, RD0 = 24, RD0N = 3;
+    static constexpr int dma_slot(int j) { return 14 + j; }
+};
+// default.  By elimination (tools/mx4_ksweep.py, profiles/r04_notes.md §7) the first version lost 14 % to its reads and nothing to its copies
+// or barriers: 4 waves x 24 reads in 4 slots are 576 cycles of LDS pipe against 256 cycles of MFMA, and lgkmcnt(0) at slot 6 waited for them.
+// Here the reads go out 3 per slot (the LDS pipe keeps up), barrier #1 waits until they have returned anyway (slot 11), the copies follow
+// one per slot (a 64-cycle MFMA hides the ~50-cycle issue), barrier #2 sits at 21 and the k-step-0 reads of the next tile run 22..29.
+// Measured against schedule 0 in steady state: +14 % (L2-hot 4096 x 4096 x 8192), +3..5 % on the layer's shapes; bit-identical results.
+// Nine more placements were timed (barrier #1 at 9..13, copies from 10..14, barrier #2 at 19..23, reads 2..6 per slot): within 2 % of this one.
+template <> struct Q4Sched<6> {
+    static constexpr int RD1 = 3, BAR1 = 11, SDMA = 11, BAR2 = 21, RD0 = 22, RD0N = 3;
+    static constexpr int dma_slot(int j) { return 12 + j; }
+};
+#ifndef Q4_SCHED
+#define Q4_SCHED 6
+#endif
+template <int V> __host__ __device__ constexpr int q4_copies_before_bar2() {      // copies of tile t+2 already issued at barrier #2: they stay in flight
+    int n = Q4Sched<V>::SDMA < Q4Sched<V>::BAR2 ? 2 : 0;
+    for (int j = 0; j < 16; ++j) n += Q4Sched<V>::dma_slot(j) < Q4Sched<V>::BAR2 ? 1 : 0;
+    return n;
+}
+template <int V> __host__ __device__ constexpr int q4_copy_at(int sl) {          // operand copy issued at slot sl, or -1
+    for (int j = 0; j < 16; ++j) if (Q4Sched<V>::dma_slot(j) == sl) return j;
+    return -1;
+}
 
 // SWIGLU: B = [gate rows | up rows] (2N x K, N = output width); the B tile interleaves 32 gate rows with the 32 matching up rows, so a
 // lane holds gate and up of the same output column in adjacent MFMA column tiles (ni even: gate, ni odd: up) and the epilogue writes
@@ -91,13 +115,17 @@ static_assert(q4_dma_slot(11) == 24 && q4_dma_slot(12) == 26 && q4_dma_slot(15) 
 // QOUT (SwiGLU tiles): the result leaves as MX-fp8 — the operand of the down projection — instead of bf16: C = e4m3 bytes (ldc in bytes),
 // SQ[tile column][row] = the scale dword of the tile's 128 output columns (= one K-tile of the next GEMM), exactly what st_mxfp8_quantize
 // makes of the bf16 result (same rounding to bf16 first).
-template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false, bool QOUT = false>
+// DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment / scale reads, 4 = MFMAs only
+template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false, bool QOUT = false, int DBG = 0, int SV = Q4_SCHED>
 __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint32_t* __restrict__ SA, int64_t sa_rows,
                                                       const uint8_t* __restrict__ B, int64_t ldb, const uint32_t* __restrict__ SB, int64_t sb_rows,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
                                                       uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n,
                                                       uint32_t* __restrict__ SQ, int64_t sq_rows) {
     static_assert(!QOUT || SWIGLU, "fp8 output: SwiGLU tiles only");
+    static_assert(Q4Sched<SV>::BAR1 >= (24 + Q4Sched<SV>::RD1 - 1) / Q4Sched<SV>::RD1 - 1 && Q4Sched<SV>::SDMA >= Q4Sched<SV>::BAR1 &&
+                  Q4Sched<SV>::dma_slot(0) >= Q4Sched<SV>::SDMA && Q4Sched<SV>::dma_slot(15) <= 31 && Q4Sched<SV>::RD0 > Q4Sched<SV>::BAR2 &&
+                  Q4Sched<SV>::BAR2 >= 16 && (31 - Q4Sched<SV>::RD0 + 1) * Q4Sched<SV>::RD0N >= 24, "K-tile schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -249,34 +277,42 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
             constexpr int sl = decltype(ic)::value;
             constexpr int ks = sl >> 4, idx = sl & 15, ni = idx >> 2, mi = idx & 3;
             q4_mfma<ks>(acc[ni][mi], q4_frag(bl[ks][ni], bh[ks][ni]), q4_frag(al[ks][mi], ah[ks][mi]), sc[ks][4 + ni], sc[ks][mi]);
-            if constexpr (sl < 4) {                                  // k-step 1 of this tile: 4 fragment reads + 2 scale reads per slot
-                q4_for<0, 4>([&](auto rc) { rd_frag(std::integral_constant<int, (sl * 4 + decltype(rc)::value)>{}, K1{}); });
-                q4_for<0, 2>([&](auto rc) { rd_scale(std::integral_constant<int, (sl * 2 + decltype(rc)::value)>{}, K1{}); });
+            constexpr bool RD = DBG != 3 && DBG != 4, BAR = DBG != 2 && DBG != 4, DMA = DBG != 1 && DBG != 4;
+            using S = Q4Sched<SV>;
+            if constexpr (RD && sl * S::RD1 < 24) {                  // k-step 1 of this tile: per 6 reads, 4 fragment halves + 2 scale dwords
+                q4_for<sl * S::RD1, (sl * S::RD1 + S::RD1 < 24 ? sl * S::RD1 + S::RD1 : 24)>([&](auto xc) {
+                    constexpr int x = decltype(xc)::value, g = x / 6, w6 = x % 6;
+                    if constexpr (w6 < 4) rd_frag(std::integral_constant<int, (g * 4 + w6)>{}, K1{});
+                    else rd_scale(std::integral_constant<int, (g * 2 + w6 - 4)>{}, K1{});
+                });
             }
-            if constexpr (sl == 3) q4_wait_lgkm<15>();               // B1..B3 of k-step 0 (the six oldest of the <= 30 reads outstanding)
-            if constexpr (sl == 6) { q4_wait_lgkm<0>(); q4_barrier(); }
-            if constexpr (sl == 7) {
-                q4_for<0, 8>([&](auto ic2) { q4_shift(sc[1][decltype(ic2)::value], shv); });
+            // B1..B3 of k-step 0 were read LAST in the previous tile (the six oldest of the <= 30 reads outstanding): needed from slots 4, 8, 12
+            if constexpr ((sl == 3 || sl == 7 || sl == 11) && sl < S::BAR1) q4_wait_lgkm<15>();
+            if constexpr (sl == S::BAR1) {
+                q4_wait_lgkm<0>();
+                if constexpr (BAR) q4_barrier();
+                if constexpr (RD) q4_for<0, 8>([&](auto ic2) { q4_shift(sc[1][decltype(ic2)::value], shv); });
+            }
+            if constexpr (DMA && sl == S::SDMA) {
                 q4_m0_set(m0S_cur);
                 q4_dma1(voffSA, srdSA, soffA);
                 q4_m0_set(m0S_cur + 1024);
                 q4_dma1(voffSB, srdSB, soffB);
                 q4_m0_set(m0A_cur);
             }
-            if constexpr (sl >= 8 && sl <= 30 && (sl - 8) % 3 != 2) {
-                constexpr int j = ((sl - 8) / 3) * 2 + (sl - 8) % 3;
-                static_assert(q4_dma_slot(j) == sl, "copy schedule");
+            if constexpr (DMA && q4_copy_at<SV>(sl) >= 0) {
+                constexpr int j = q4_copy_at<SV>(sl);
                 dma_tile(std::integral_constant<int, j>{});
                 if constexpr (j == 7) q4_m0_set(m0B_cur); else if constexpr (j < 15) q4_m0_next();
             }
-            if constexpr (sl == 25) { q4_wait_vm<14>(); q4_barrier(); }
-            if constexpr (sl >= 26 && sl <= 30) {                    // 24 reads over five slots: 5 5 5 5 4
-                constexpr int x0 = (sl - 26) * 5;
-                q4_for<x0, (x0 + 5 < 24 ? x0 + 5 : 24)>([&](auto xc) { rd_next(xc); });
+            if constexpr (sl == S::BAR2) { if constexpr (DMA) q4_wait_vm<q4_copies_before_bar2<SV>()>(); if constexpr (BAR) q4_barrier(); }
+            if constexpr (RD && sl >= S::RD0 && (sl - S::RD0) * S::RD0N < 24) {
+                constexpr int x0 = (sl - S::RD0) * S::RD0N;
+                q4_for<x0, (x0 + S::RD0N < 24 ? x0 + S::RD0N : 24)>([&](auto xc) { rd_next(xc); });
             }
             if constexpr (sl == 31) {
                 q4_wait_lgkm<6>();
-                q4_for<0, 8>([&](auto ic2) { q4_shift(sc[0][decltype(ic2)::value], shv); });
+                if constexpr (RD) q4_for<0, 8>([&](auto ic2) { q4_shift(sc[0][decltype(ic2)::value], shv); });
             }
         });
         // flip the slots; advance the source of the next copies (the last two tiles re-fetch tile nk-1: lands in a slot nobody reads)
@@ -425,21 +461,26 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
     }
 }
 
-// called by st_gemm_mxfp8_nt (gemm_fp8.hip) after its argument checks
+// called by st_gemm_mxfp8_nt (gemm_fp8.hip) after its argument checks; dbg = 1..4: the timing-experiment instantiations (wrong results)
 int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
                        int64_t sb_rows, const uint16_t* bias, const uint16_t* residual, int64_t ldr, uint16_t* out, int64_t ldc, int M, int N,
-                       int K, hipStream_t s) {
+                       int K, int dbg, hipStream_t s) {
     const int tiles_m = st_cdiv(M, Q4_BM), tiles_n = st_cdiv(N, Q4_BN);
-#define Q4GO(HB, HR)                                                                                                              \
+#define Q4GO(HB, HR, D) Q4GOS(HB, HR, D, Q4_SCHED)
+#define Q4GOS(HB, HR, D, SVV)                                                                                                     \
     do {                                                                                                                          \
-        auto kern = gemm_mx4_kernel<HB, HR>;                                                                                      \
+        auto kern = gemm_mx4_kernel<HB, HR, false, false, D, SVV>;                                                                \
         static bool configured = false;                                                                                           \
         if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_SMEM); configured = true; } \
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Q4_SMEM, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows, bias, residual, \
                            ldr, out, ldc, M, N, K, tiles_m, tiles_n, (uint32_t*)nullptr, (int64_t)0);                             \
     } while (0)
-    if (bias && residual) Q4GO(true, true); else if (bias) Q4GO(true, false); else if (residual) Q4GO(false, true); else Q4GO(false, false);
+    if (dbg == 1) Q4GO(false, false, 1); else if (dbg == 2) Q4GO(false, false, 2); else if (dbg == 3) Q4GO(false, false, 3);
+    else if (dbg == 4) Q4GO(false, false, 4);
+    else if (dbg == 10) Q4GOS(false, false, 0, 0); else if (dbg == 12) Q4GOS(false, false, 0, 2); else if (dbg == 16) Q4GOS(false, false, 0, 6);
+    else if (bias && residual) Q4GO(true, true, 0); else if (bias) Q4GO(true, false, 0); else if (residual) Q4GO(false, true, 0); else Q4GO(false, false, 0);
 #undef Q4GO
+#undef Q4GOS
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -5,9 +5,6 @@ int st_gemm_asm4_debug(int dbg, const uint16_t* A, int64_t lda, const uint16_t* 
 int st_gemm_asm4_dispatch(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res, int64_t ldr,
                           uint16_t* Cb, float* Cf, int64_t ldc, int accumulate, int M, int N, int K, hipStream_t s);
 
-int st_gemm_asm4w_dispatch(int sched, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias, const uint16_t* res,
-                           int64_t ldr, uint16_t* Cb, int64_t ldc, int M, int N, int K, hipStream_t s);
-
 // variant ids: 0 = 128x128 2x2 waves 2 stages, 1 = 128x128 3 stages, 2 = 256x128 4x2 2 stages, 3 = 256x128 4x2 3 stages,
 //              4 = 256x256 4x2 2 stages, 5 = 128x256 2x4 3 stages, 6 / 7 = 256x256 / 128x128 with the mid-tile barrier schedule
 int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* bias,
@@ -28,9 +25,6 @@ int st_gemm_tile_dispatch(int variant, const uint16_t* A, int64_t lda, const uin
     } while (0)
     switch (variant) {
         case 41: case 42: case 43: case 44: case 45: case 46: case 47: return st_gemm_asm4_debug(variant - 40, A, lda, B, ldb, Cb, ldc, M, N, K, s);   // timing experiments (wrong results)
-        case 48: case 49: case 50: case 51: case 52: case 53: case 54:   // 52..54: timing experiments on schedule 1 (no LDS-DMA / no reads / MFMAs only; wrong results)
-                      // the 4-wave tile on the 32-cycle MFMA (gemm_asm4w.hip): K-tile schedules 0..3; bf16 results only
-            return Cb ? st_gemm_asm4w_dispatch(variant - 48, A, lda, B, ldb, bias, res, ldr, Cb, ldc, M, N, K, s) : ST_EINVAL;
         case 40: return st_gemm_asm4_dispatch(A, lda, B, ldb, bias, res, ldr, Cb, Cf, ldc, accumulate, M, N, K, s);   // 4 waves x 128x128, hand-scheduled K loop (gemm_asm4.hip)
         case 0: TILE_GO(128, 128, 2, 2, 2, false);
         case 1: TILE_GO(128, 128, 2, 2, 3, false);

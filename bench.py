@@ -683,7 +683,7 @@ def main():
         ops.K_LOGPROB: ("logprob_fwd/bwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_RMSNORM: ("rmsnorm_fwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_ADAMW: ("adamw_kahan_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
-        ops.K_GEMM_FP8: ("gemm_mxfp8_kernel (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 + e8m0 block scales)", "mfma", PEAK_FP8, 1e12, "TFLOP/s"),
+        ops.K_GEMM_FP8: ("gemm_mx4_kernel (4-wave tile, v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 + e8m0 block scales; gemm_mxfp8_kernel with ST_FP8_TILE=8)", "mfma", PEAK_FP8, 1e12, "TFLOP/s"),
     }
     for k in classes:
         ops.prof_enable(k, max(4096, 6000 * a.steps if k == ops.K_GEMM else 1500 * a.steps), PROF_STRIDE if k != ops.K_ADAMW else 1)

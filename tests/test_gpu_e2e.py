@@ -191,10 +191,7 @@ def test_bench_two_ranks_on_one_gpu_runs_the_real_multi_rank_step():
     assert set(d["timing_s_max_over_ranks"]) == set(d["timing_s"]) and d["timing_s_max_over_ranks"]["update_actor"] >= d["timing_s"]["update_actor"] - 1e-9
 
 
-def test_grpo_loop_learns_a_dense_synthetic_reward():
-    """Does the wired-up loop LEARN?  Tiny model, 4 prompts x 8 rollouts of 8 tokens, reward = share of sampled token ids below 512 (0.5 for
-    the random-init policy): rollout -> reward -> old log-probs -> GRPO advantages -> update_policy, 32 times.  The sampled share must rise
-    clearly — a sign error in the advantage, the ratio, the loss gradient or the optimizer would drive it the other way or nowhere."""
+def _learn(n_pr, G, R, P, micro, steps, fp8=False):
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -207,18 +204,18 @@ def test_grpo_loop_learns_a_dense_synthetic_reward():
     store = mdl.ParamStore(cfg, trainable=True)
     store.load_hf_state_dict({k: torch.from_numpy(v) for k, v in tiny.make_params().items()})
     store.refresh_transposes()
-    n_pr, G, R = 4, 8, 8
-    eng = PolicyEngine(cfg, store, ActorHyper(micro_batch_size_per_device_for_update=4, global_batch_size_per_device=n_pr * G, lr=1e-3, use_kl_loss=False,
+    eng = PolicyEngine(cfg, store, ActorHyper(micro_batch_size_per_device_for_update=micro, global_batch_size_per_device=n_pr * G, lr=1e-3, use_kl_loss=False,
                                               max_grad_norm=1.0))
     eng.sched_steps = 1                                           # past the reference's lr = 0 first call
+    if fp8:
+        eng.model.enable_fp8(True, dgrad=True)
     gen = Generator(eng.model)
     rs = np.random.RandomState(0)
-    P = 16
     ids = rs.randint(0, 900, (n_pr, P)).astype(np.int64)
     mask = np.ones((n_pr, P), dtype=np.int64)
     pos = np.broadcast_to(np.arange(P), (n_pr, 3, P)).copy()
     shares = []
-    for step in range(32):
+    for step in range(steps):
         resp = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=1.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID, seed=100 + step,
                             forced_lengths=np.full(n_pr * G, R), ignore_eos=True)
         out = assemble_rollout_batch(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), resp.cpu(), G, tiny.EOS_ID)
@@ -234,5 +231,22 @@ def test_grpo_loop_learns_a_dense_synthetic_reward():
         data["advantages"] = adv
         eng.update_policy(data, 1.0)
     first, last = float(np.mean(shares[:5])), float(np.mean(shares[-5:]))
-    print(f"share of sampled ids < 512: first five steps {first:.3f}, last five {last:.3f}; trajectory {np.round(shares, 3).tolist()}")
+    print(f"share of sampled ids < 512 (fp8={fp8}): first five steps {first:.3f}, last five {last:.3f}; trajectory {np.round(shares, 3).tolist()}")
+    return first, last, shares, eng
+
+
+def test_grpo_loop_learns_a_dense_synthetic_reward():
+    """Does the wired-up loop LEARN?  Tiny model, 4 prompts x 8 rollouts of 8 tokens, reward = share of sampled token ids below 512 (0.5 for
+    the random-init policy): rollout -> reward -> old log-probs -> GRPO advantages -> update_policy, 32 times.  The sampled share must rise
+    clearly — a sign error in the advantage, the ratio, the loss gradient or the optimizer would drive it the other way or nowhere."""
+    first, last, shares, _ = _learn(n_pr=4, G=8, R=8, P=16, micro=4, steps=32)
     assert 0.35 < first < 0.65 and last > first + 0.10, shares          # (lr 3e-4, 24 steps: 0.450 -> 0.533 on MI355X)
+
+
+def test_grpo_loop_learns_in_fp8_mode():
+    """The same loop with the LM projections on the MX-fp8 path, forward AND input gradients (BASELINE config #5's arithmetic): passes of
+    more than 256 packed tokens so that the fp8 tiles really run (8 prompts x 8 rollouts, 48-token prompts, 16-token responses).  fp8 is not
+    a parity mode; what it must do is train."""
+    first, last, shares, eng = _learn(n_pr=8, G=8, R=16, P=48, micro=64, steps=32, fp8=True)
+    assert eng.model.fp8 and eng.model.fp8_dgrad and eng.model.p.wqt is not None
+    assert 0.35 < first < 0.65 and last > first + 0.10, shares

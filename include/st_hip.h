@@ -276,7 +276,8 @@ int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width
  * st_gemm_mxfp8_nt: out[M,N] (bf16) = dequant(A)[M,K] dequant(B)[N,K]^T (+bias)(+residual), fp32 accumulation on the block-scaled
  *   MFMAs (the only fp8 MFMAs that run at twice the bf16 rate on gfx950): the 4-wave hand-scheduled 256x256 tile on
  *   v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_mx4.hip; default) or the 8-wave tile on v_mfma_scale_f32_16x16x128_f8f6f4 (gemm_fp8.hip).
- * st_gemm_mxfp8_select: waves = 4 | 8 picks the tile (A/B runs, tests; ST_FP8_TILE=8 sets the initial value). */
+ * st_gemm_mxfp8_select: waves = 4 | 8 picks the tile (A/B runs, tests; ST_FP8_TILE=8 sets the initial value);
+ *   50 / 52 / 56 = the 4-wave tile on its K-tile schedules 0 / 2 / 6 (same results; tools/mx4_ksweep.py); anything else is refused. */
 int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int K,
                       st_stream_t stream);
 int st_gemm_mxfp8_select(int waves);

@@ -177,6 +177,9 @@ static int fp8_tile_waves() {
 extern "C" {
 
 int st_gemm_mxfp8_select(int waves) {
+    // 41..44 are timing experiments with WRONG results: only a process that asks for them by name (tools/mx4_ksweep.py) may select them
+    static const bool experiments = [] { const char* e = getenv("ST_FP8_TIMING_EXPERIMENTS"); return e && e[0] == '1'; }();
+    if (waves >= 41 && waves <= 44 && !experiments) return ST_EINVAL;
     if (waves != 4 && waves != 8 && !(waves >= 41 && waves <= 44) && waves != 50 && waves != 52 && waves != 56) return ST_EINVAL;
     g_fp8_tile = waves;
     return 0;

@@ -2,6 +2,7 @@
 Times st_gemm_mxfp8_nt on the real kernel and on its timing-experiment instantiations (results wrong by construction): no LDS-DMA in the
 loop / no barriers / no fragment + scale reads / MFMAs only.  One full round of tiles (256 CUs) unless a shape is given."""
 import os, sys, torch
+os.environ["ST_FP8_TIMING_EXPERIMENTS"] = "1"      # the wrong-result instantiations are refused otherwise
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialthinker_amd import ops
 M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 4096, 8192)

@@ -79,6 +79,8 @@ def parse():
                          "scaled) MFMA path, everything else (attention, lm_head, ViT, backward, decode) bf16")
     ap.add_argument("--fp8-dgrad", action="store_true", help="with --dtype fp8: the input-gradient GEMMs dX = dY W of the LM layers in MX-fp8 too "
                     "(transposed fp8 weight copies, dY quantised on the fly); weight gradients stay bf16")
+    ap.add_argument("--fp8-wgrad", action="store_true", help="with --dtype fp8: the weight-gradient GEMMs dW = dY^T X of the LM layers in MX-fp8 too "
+                    "(both operands quantised token-minor on the fly)")
     ap.add_argument("--through-api", action="store_true",
                     help="the same synthetic step through the kept API: `python -m verl.trainer.main` (config merge, RLHF dataloader, FSDPWorker "
                          "methods, DataProto .cpu() round trips, tokenizer decode + CustomRewardManager, RayPPOTrainer.fit) instead of calling the "
@@ -586,7 +588,7 @@ def main():
     if a.tokens_grad is not None:
         actor.tokens_per_pass_grad = a.tokens_grad
     if a.dtype == "fp8":
-        actor.model.enable_fp8(True, dgrad=a.fp8_dgrad)
+        actor.model.enable_fp8(True, dgrad=a.fp8_dgrad, wgrad=a.fp8_wgrad)
         ref.model.enable_fp8(True)
     gen = Generator(actor.model)
     rs = np.random.RandomState(a.seed + rank)
@@ -792,8 +794,9 @@ def main():
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.dtype == "bf16" else ("fp8 (MX e4m3 forward" + (" + input-gradient" if a.fp8_dgrad else "") + " projection GEMMs; bf16 attention / lm_head / "
-                                                            + ("weight gradients" if a.fp8_dgrad else "backward") + " / decode)"),
+            "dtype": "bf16" if a.dtype == "bf16" else ("fp8 (MX e4m3 forward" + (" + input-gradient" if a.fp8_dgrad else "") + (" + weight-gradient" if a.fp8_wgrad else "")
+                                                            + " projection GEMMs; bf16 attention / lm_head / "
+                                                            + ("rest of the backward" if (a.fp8_dgrad or a.fp8_wgrad) else "backward") + " / decode)"),
             "data": f"synthetic (random-init weights at real shapes; prompts: {tb + ta + 2} text + {n_img} image tokens from "
                                      f"{grid[1] * grid[2]} random patches; response lengths ~ clip(N(512,128),64,cap) enforced by forcing EOS; templated reward strings)",
             "config": {"workload": f"{name} dense spatial-reward GRPO step (gen + reward + old/ref log-probs + advantage + update), G={G}, "

@@ -280,6 +280,13 @@ int st_kv_append(const st_bf16* qkv, int64_t ld, int col_k, int col_v, int width
  *   50 / 52 / 56 = the 4-wave tile on its K-tile schedules 0 / 2 / 6 (same results; tools/mx4_ksweep.py); anything else is refused. */
 int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int K,
                       st_stream_t stream);
+/* st_mxfp8_quantize_t: the quantisation of x^T without materialising it — x (R, C) bf16 -> qT (C, R) bytes + scales[R/128][scale_rows >= C]
+ *   (MX blocks of 32 consecutive ROWS of x): the operands of the weight-gradient products dW = dY^T X.  R % 128 == 0, C % 8 == 0.
+ * st_gemm_mxfp8_nt_f32: out[M,N] (fp32) = or += dequant(A)[M,K] dequant(B)[N,K]^T on the 4-wave tile. */
+int st_mxfp8_quantize_t(const st_bf16* x, int64_t ldx, uint8_t* qT, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int C,
+                        st_stream_t stream);
+int st_gemm_mxfp8_nt_f32(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                         const uint32_t* SB, int64_t sb_rows, float* out, int64_t ldc, int accumulate, int M, int N, int K, st_stream_t stream);
 int st_gemm_mxfp8_select(int waves);
 int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
                      const uint32_t* SB, int64_t sb_rows, const st_bf16* bias, const st_bf16* residual, int64_t ldr, st_bf16* out,

@@ -44,6 +44,59 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_kernel(const uint16_t* __r
     if (live && (lane & 15) == 0) scales[(int64_t)(k0 >> 7) * scale_rows + r] = sd;
 }
 
+// Transposing quantiser (weight-gradient GEMMs, dW = dY^T X: the contraction runs over the TOKEN index, so both operands are needed
+// token-minor with MX blocks of 32 consecutive tokens): x (R, C) bf16 row-major -> qT (C, R) e4m3 bytes + scales S[R/128][Cs] dwords (byte j of
+// S[kt][c] = scale of rows 128 kt + 32 j .. + 31 of column c) = st_mxfp8_quantize of the transposed matrix, without materialising it.
+// R % 128 == 0 (packed token counts are padded to 128; the padding rows are zero).  One workgroup per 128 rows x 64 columns: the tile passes
+// through LDS, then thread (column c = t & 63, block j = t >> 6) owns one whole MX block — no cross-lane reduction — and writes its 32 bytes.
+// (A 128 x 128 tile with two columns per thread — one LDS dword per row — measured 20 % SLOWER in the bench: 33 KiB of LDS and 64 live
+// values per thread cost more occupancy than the halved LDS instruction count buys.)
+__global__ __launch_bounds__(256) void mxfp8_quantize_t_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ qT, int64_t ldq,
+                                                              uint32_t* __restrict__ scales, int64_t scale_rows, int R, int C) {
+    __shared__ uint16_t tile[128][64 + 2];                    // +2: rows 132 bytes apart; a wave's column reads (64 consecutive columns of one row) are conflict-free
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 64;
+    {
+        const int row = t >> 1, cb = (t & 1) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + cb + k * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < C) v = *reinterpret_cast<const uint4*>(x + (int64_t)(r0 + row) * ldx + c);       // C % 8 == 0: all-in or all-out
+            uint32_t* d = reinterpret_cast<uint32_t*>(&tile[row][cb + k * 8]);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+    const int c = t & 63, j = t >> 6;
+    float f[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        f[i] = bf2f(tile[j * 32 + i][c]);
+        amax = fmaxf(amax, fabsf(f[i]));
+    }
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+    e = e < 0 ? 0 : (e > 254 ? 254 : e);
+    const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+    uint32_t w[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(f[4 * h + i] * inv, -448.f), 448.f);
+        int packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], packed, true);
+        w[h] = (uint32_t)packed;
+    }
+    if (c0 + c < C) {
+        uint4* dst = reinterpret_cast<uint4*>(qT + (int64_t)(c0 + c) * ldq + r0 + j * 32);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        reinterpret_cast<uint8_t*>(scales + (int64_t)blockIdx.y * scale_rows + c0 + c)[j] = (uint8_t)e;
+    }
+}
+
 // ------------------------------------------------------------------------------ GEMM
 #define Q_BM 256
 #define Q_BN 256
@@ -168,6 +221,8 @@ int st_launch_gemm_mx4(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_
                        int K, int dbg, hipStream_t s);
 int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
                               int64_t sb_rows, void* out, int64_t ldc, uint32_t* sq, int64_t sq_rows, int M, int N, int K, hipStream_t s);
+int st_launch_gemm_mx4_f32(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
+                           int64_t sb_rows, float* out, int64_t ldc, int accumulate, int M, int N, int K, hipStream_t s);
 static int g_fp8_tile = -1;
 static int fp8_tile_waves() {
     if (g_fp8_tile < 0) { const char* e = getenv("ST_FP8_TILE"); g_fp8_tile = (e && atoi(e) == 8) ? 8 : 4; }
@@ -195,6 +250,28 @@ int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, ui
                        scales, scale_rows, R, K);
     ST_CHECK_LAUNCH();
     return 0;
+}
+
+int st_mxfp8_quantize_t(const st_bf16* x, int64_t ldx, uint8_t* qT, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int C,
+                        st_stream_t stream) {
+    if (!x || !qT || !scales || R <= 0 || C <= 0 || (R % 128) || (C & 7) || (ldx & 7) || (ldq & 15) || ldx < C || ldq < R || scale_rows < C ||
+        (((uintptr_t)x) & 15) || (((uintptr_t)qT) & 15))
+        return ST_EINVAL;
+    hipLaunchKernelGGL(mxfp8_quantize_t_kernel, dim3(st_cdiv(C, 64), R / 128), dim3(256), 0, (hipStream_t)stream, x, ldx, qT, ldq, scales,
+                       scale_rows, R, C);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_gemm_mxfp8_nt_f32(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
+                         const uint32_t* SB, int64_t sb_rows, float* out, int64_t ldc, int accumulate, int M, int N, int K, st_stream_t stream) {
+    if (!A || !B || !SA || !SB || !out || M <= 0 || N <= 0 || K <= 0 || (K % 128) || (lda & 15) || (ldb & 15) || lda < K || ldb < K ||
+        ldc < N || sa_rows < M || sb_rows < N || (sa_rows & 3) || (sb_rows & 3) || sa_rows < 4 || sb_rows < 4 || (((uintptr_t)A) & 15) ||
+        (((uintptr_t)B) & 15) || (((uintptr_t)SA) & 15) || (((uintptr_t)SB) & 15))
+        return ST_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    StProfScope ps(ST_K_GEMM_FP8, s, 2.0 * (double)M * (double)N * (double)K);
+    return st_launch_gemm_mx4_f32(A, lda, SA, sa_rows, B, ldb, SB, sb_rows, out, ldc, accumulate, M, N, K, s);
 }
 
 int st_gemm_mxfp8_nt(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,

@@ -116,13 +116,15 @@ template <int V> __host__ __device__ constexpr int q4_copy_at(int sl) {         
 // SQ[tile column][row] = the scale dword of the tile's 128 output columns (= one K-tile of the next GEMM), exactly what st_mxfp8_quantize
 // makes of the bf16 result (same rounding to bf16 first).
 // DBG (timing experiments only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no barriers, 3 = no fragment / scale reads, 4 = MFMAs only
-template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false, bool QOUT = false, int DBG = 0, int SV = Q4_SCHED>
+// OUTF: 0 = bf16 result, 1 = fp32 result (C is a float pointer, ldc in floats), 2 = fp32 result accumulated into C (the weight gradients)
+template <bool HAS_BIAS, bool HAS_RES, bool SWIGLU = false, bool QOUT = false, int DBG = 0, int SV = Q4_SCHED, int OUTF = 0>
 __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict__ A, int64_t lda, const uint32_t* __restrict__ SA, int64_t sa_rows,
                                                       const uint8_t* __restrict__ B, int64_t ldb, const uint32_t* __restrict__ SB, int64_t sb_rows,
                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ res, int64_t ldr,
                                                       uint16_t* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n,
                                                       uint32_t* __restrict__ SQ, int64_t sq_rows) {
     static_assert(!QOUT || SWIGLU, "fp8 output: SwiGLU tiles only");
+    static_assert(OUTF == 0 || (!SWIGLU && !HAS_BIAS && !HAS_RES), "fp32 results: plain products");
     static_assert(Q4Sched<SV>::BAR1 >= (24 + Q4Sched<SV>::RD1 - 1) / Q4Sched<SV>::RD1 - 1 && Q4Sched<SV>::SDMA >= Q4Sched<SV>::BAR1 &&
                   Q4Sched<SV>::dma_slot(0) >= Q4Sched<SV>::SDMA && Q4Sched<SV>::dma_slot(15) <= 31 && Q4Sched<SV>::RD0 > Q4Sched<SV>::BAR2 &&
                   Q4Sched<SV>::BAR2 >= 16 && (31 - Q4Sched<SV>::RD0 + 1) * Q4Sched<SV>::RD0N >= 24, "K-tile schedule");
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
     // ---- epilogue through LDS: 2 passes of 256 rows x 128 columns of fp32 (rows padded to 528 bytes), as gemm_asm4.hip.
     // Swapped operands (B first): lane holds m = mi*32 + (lane & 31) and, per register group q, n = ni*32 + 8q + 4g + 0..3
     constexpr int ROWB = 128 * 4 + 16;
-    const bool interior = m0 + Q4_BM <= M && n0 + (SWIGLU ? Q4_BN / 2 : Q4_BN) <= N && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+    const bool interior = m0 + Q4_BM <= M && n0 + (SWIGLU ? Q4_BN / 2 : Q4_BN) <= N && (ldc & (OUTF ? 3 : 7)) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
                           (!HAS_BIAS || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                           (!HAS_RES || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
     __syncthreads();                                                 // every wave is done with the operand slots; no DMA in flight
@@ -400,6 +402,30 @@ __global__ __launch_bounds__(256) void gemm_mx4_kernel(const uint8_t* __restrict
         }
         const int c8 = (t & 15) * 8;
         const int n = n0 + (c8 >> 6) * 128 + p * 64 + (c8 & 63);
+        if constexpr (OUTF != 0) {
+            float* Cf = reinterpret_cast<float*>(C);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 16 + (t >> 4), m = m0 + row;
+                if (m >= M || n >= N) continue;
+                float4 v0 = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4);
+                float4 v1 = *reinterpret_cast<const float4*>(smem + row * ROWB + c8 * 4 + 16);
+                float* cp = Cf + (int64_t)m * ldc + n;
+                if (interior || (n + 7 < N && (reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
+                    if constexpr (OUTF == 2) {
+                        const float4 o0 = *reinterpret_cast<const float4*>(cp), o1 = *reinterpret_cast<const float4*>(cp + 4);
+                        v0.x += o0.x; v0.y += o0.y; v0.z += o0.z; v0.w += o0.w; v1.x += o1.x; v1.y += o1.y; v1.z += o1.z; v1.w += o1.w;
+                    }
+                    *reinterpret_cast<float4*>(cp) = v0;
+                    *reinterpret_cast<float4*>(cp + 4) = v1;
+                } else {
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    for (int r = 0; r < 8; ++r) if (n + r < N) cp[r] = (OUTF == 2 ? cp[r] : 0.f) + v[r];
+                }
+            }
+            if (p == 0) __syncthreads();
+            continue;
+        }
         if (interior) {
             float bvals[8];
             if constexpr (HAS_BIAS) unpack8(*reinterpret_cast<const uint4*>(bias + n), bvals);
@@ -500,6 +526,24 @@ int st_launch_gemm_mx4_swiglu(const uint8_t* A, int64_t lda, const uint32_t* SA,
     } while (0)
     if (sq) Q4SW(true); else Q4SW(false);
 #undef Q4SW
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[M,N] (fp32) = or += dequant(A) dequant(B)^T: the weight-gradient products (A = dY^T, B = X^T, both from st_mxfp8_quantize_t)
+int st_launch_gemm_mx4_f32(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb, const uint32_t* SB,
+                           int64_t sb_rows, float* out, int64_t ldc, int accumulate, int M, int N, int K, hipStream_t s) {
+    const int tiles_m = st_cdiv(M, Q4_BM), tiles_n = st_cdiv(N, Q4_BN);
+#define Q4F(OF)                                                                                                                   \
+    do {                                                                                                                          \
+        auto kern = gemm_mx4_kernel<false, false, false, false, 0, Q4_SCHED, OF>;                                                 \
+        static bool configured = false;                                                                                           \
+        if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_SMEM); configured = true; } \
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Q4_SMEM, s, A, lda, SA, sa_rows, B, ldb, SB, sb_rows, (const uint16_t*)nullptr, \
+                           (const uint16_t*)nullptr, (int64_t)0, reinterpret_cast<uint16_t*>(out), ldc, M, N, K, tiles_m, tiles_n, (uint32_t*)nullptr, (int64_t)0); \
+    } while (0)
+    if (accumulate) Q4F(2); else Q4F(1);
+#undef Q4F
     ST_CHECK_LAUNCH();
     return 0;
 }

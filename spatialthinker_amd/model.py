@@ -373,18 +373,20 @@ class Qwen25VL:
         self.unfused_swiglu_with_grad = os.environ.get("ST_SWIGLU_UNFUSED_GRAD", "1") != "0"      # see _lm_layer_fwd
         self.fp8 = False                 # config #5: the LM's four projection GEMMs run forward in MX-fp8 (enable_fp8)
         self.fp8_dgrad = False           # ... and their input-gradient GEMMs too
+        self.fp8_wgrad = False           # ... and their weight-gradient GEMMs
 
-    def enable_fp8(self, on: bool = True, dgrad: bool = False):
+    def enable_fp8(self, on: bool = True, dgrad: bool = False, wgrad: bool = False):
         """Forward GEMMs of the LM layers (qkv, o, gate/up, down — 93 % of the forward FLOPs) on the block-scaled fp8 MFMA path:
         activations are quantised on the fly (one HBM pass each), weights once per optimizer step.  Attention, norms, the lm_head,
         the ViT and the weight gradients stay bf16 (straight-through: gradients are those of the bf16 layer evaluated at the fp8
         forward's activations).  dgrad=True also runs the four input-gradient GEMMs dX = dY W of every LM layer in MX-fp8 (dY quantised
-        on the fly along its feature dimension, a transposed fp8 copy of W); dW = dY^T X contracts over tokens and stays bf16.
-        Tolerance: DESIGN.md §4 (fp8)."""
+        on the fly along its feature dimension, a transposed fp8 copy of W); wgrad=True the weight-gradient GEMMs dW = dY^T X as well
+        (both operands quantised token-minor on the fly).  Tolerance: DESIGN.md §4 (fp8)."""
         if on and (self.cfg.hidden_size % 128 or self.cfg.intermediate_size % 128):
             raise ValueError("fp8 mode needs hidden and intermediate sizes that are multiples of 128 (MX K-tiles)")
         self.fp8 = bool(on)
         self.fp8_dgrad = bool(on and dgrad)
+        self.fp8_wgrad = bool(on and wgrad)
         self.p.fp8_dgrad = self.fp8_dgrad
         if on and (not getattr(self.p, "wq", None) or (self.fp8_dgrad and not getattr(self.p, "wqt", None))):
             self.p.refresh_fp8()
@@ -583,9 +585,15 @@ class Qwen25VL:
         self._dw(g["v.patch_embed"], dx, pxw, None)
 
     # ---------------------------------------------------------------- helpers
-    def _dw(self, gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gb: Optional[torch.Tensor]):
-        """gw (N,K) fp32 += dy(M,N)^T x(M,K); gb (N,) += column sums of dy.  M is a multiple of 64 (padded rows are zero)."""
-        if ops.layout_gemm_ok(dy.shape[1], x.shape[1], dy.shape[0]):
+    def _dw(self, gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gb: Optional[torch.Tensor], fp8: bool = False):
+        """gw (N,K) fp32 += dy(M,N)^T x(M,K); gb (N,) += column sums of dy.  M is a multiple of 64 (padded rows are zero).
+        fp8 (enable_fp8(wgrad=True), LM projections): both operands quantised token-minor on the fly (st_mxfp8_quantize_t: MX blocks of 32
+        consecutive packed tokens), the product on the 4-wave fp8 tile accumulating into the fp32 gradient."""
+        if fp8 and dy.shape[0] > 256 and dy.shape[0] % 128 == 0:
+            dq, ds = ops.mxfp8_quantize_t(dy)
+            xq, xs = ops.mxfp8_quantize_t(x)
+            ops.gemm_mxfp8_nt_f32(dq, ds, xq, xs, gw, accumulate=True)
+        elif ops.layout_gemm_ok(dy.shape[1], x.shape[1], dy.shape[0]):
             # both operands as they lie in memory (token index = contraction = row): transpose reads inside the tile, no transposed
             # copies of dY / X in HBM (+13 % on the layer's dW GEMMs vs transposes + NT, tools/gemm_layout_ab.py)
             ops.gemm_tn(dy, x, gw, accumulate=True)
@@ -670,20 +678,20 @@ class Qwen25VL:
             m = ops.swiglu_fwd(gu)
             h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
             h1, _ = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps, want_rstd=False)
-        self._dw(g[p + "down_w"], dx2, m, None)
+        self._dw(g[p + "down_w"], dx2, m, None, fp8=self.fp8_wgrad)
         dm = self._dgrad(dx2, p + "down_w")
         dgu = ops.swiglu_bwd(gu, dm)
-        self._dw(g[p + "gu_w"], dgu, h2, None)
+        self._dw(g[p + "gu_w"], dgu, h2, None, fp8=self.fp8_wgrad)
         dh2 = self._dgrad(dgu, p + "gu_w")
         dx1 = ops.rmsnorm_bwd(x1, w[p + "post_norm"], r2, dh2, dres=dx2, dw_accum=g[p + "post_norm"])
-        self._dw(g[p + "o_w"], dx1, a, None)
+        self._dw(g[p + "o_w"], dx1, a, None, fp8=self.fp8_wgrad)
         da = self._dgrad(dx1, p + "o_w")
         dqkv = torch.zeros_like(qkv)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
                          self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
         ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
-        self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
+        self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"], fp8=self.fp8_wgrad)
         dh1 = self._dgrad(dqkv, p + "qkv_w")
         return ops.rmsnorm_bwd(x0, w[p + "in_norm"], r1, dh1, dres=dx1, dw_accum=g[p + "in_norm"])
 

@@ -382,6 +382,28 @@ def mxfp8_quantize(x):
     return q, sc
 
 
+def mxfp8_quantize_t(x):
+    """MX-fp8 of x^T without materialising it: x (R, C) bf16, R % 128 == 0 -> (qT (C, R) uint8, scales (R/128, C_pad4) int32): MX blocks run
+    along the ROWS of x (the token index) — the operands of the weight-gradient products."""
+    _chk(x, BF16, "x")
+    R, C = x.shape
+    qT = torch.empty(C, R, dtype=torch.uint8, device=x.device)
+    rows = (C + 3) // 4 * 4
+    sc = torch.zeros(R // 128, rows, dtype=torch.int32, device=x.device)
+    lib().st_mxfp8_quantize_t(_p(x), x.stride(0), _p(qT), qT.stride(0), _p(sc), rows, R, C, _s())
+    return qT, sc
+
+
+def gemm_mxfp8_nt_f32(aq, sa, bq, sb, out_f32, accumulate=False):
+    """out_f32[M,N] = or += dequant(aq, sa) @ dequant(bq, sb)^T (fp32 result: the weight gradients)."""
+    M, K = aq.shape
+    N = bq.shape[0]
+    assert bq.shape[1] == K and sa.shape[0] == K // 128 and sb.shape[0] == K // 128 and out_f32.shape == (M, N)
+    lib().st_gemm_mxfp8_nt_f32(_p(aq), aq.stride(0), _p(sa), sa.shape[1], _p(bq), bq.stride(0), _p(sb), sb.shape[1], _p(out_f32),
+                               out_f32.stride(0), int(accumulate), M, N, K, _s())
+    return out_f32
+
+
 _fp8_tile = 8 if os.environ.get("ST_FP8_TILE", "") == "8" else 4
 
 

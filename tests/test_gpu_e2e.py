@@ -208,7 +208,7 @@ def _learn(n_pr, G, R, P, micro, steps, fp8=False):
                                               max_grad_norm=1.0))
     eng.sched_steps = 1                                           # past the reference's lr = 0 first call
     if fp8:
-        eng.model.enable_fp8(True, dgrad=True)
+        eng.model.enable_fp8(True, dgrad=True, wgrad=True)
     gen = Generator(eng.model)
     rs = np.random.RandomState(0)
     ids = rs.randint(0, 900, (n_pr, P)).astype(np.int64)
@@ -244,9 +244,9 @@ def test_grpo_loop_learns_a_dense_synthetic_reward():
 
 
 def test_grpo_loop_learns_in_fp8_mode():
-    """The same loop with the LM projections on the MX-fp8 path, forward AND input gradients (BASELINE config #5's arithmetic): passes of
+    """The same loop with the LM projections on the MX-fp8 path — forward, input gradients AND weight gradients (BASELINE config #5's arithmetic): passes of
     more than 256 packed tokens so that the fp8 tiles really run (8 prompts x 8 rollouts, 48-token prompts, 16-token responses).  fp8 is not
     a parity mode; what it must do is train."""
     first, last, shares, eng = _learn(n_pr=8, G=8, R=16, P=48, micro=64, steps=32, fp8=True)
-    assert eng.model.fp8 and eng.model.fp8_dgrad and eng.model.p.wqt is not None
+    assert eng.model.fp8 and eng.model.fp8_dgrad and eng.model.fp8_wgrad and eng.model.p.wqt is not None
     assert 0.35 < first < 0.65 and last > first + 0.10, shares

@@ -102,6 +102,41 @@ def test_swiglu_epilogue_of_the_fp8_tile_matches_the_unfused_pair(ops, shape):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(128, 64), (384, 200), (1024, 3584), (256, 37888)])
+def test_transposing_quantiser_matches_quantiser_of_the_transpose(ops, shape):
+    R, C = shape
+    rs = np.random.RandomState(R + C)
+    x = _bf(rs.standard_normal((R, C)) * np.exp(rs.uniform(-6, 4, (R, 1))) * np.exp(rs.uniform(-2, 2, (1, C)))).cuda()
+    x[R // 2:R // 2 + 32, 3] = 0                                  # an all-zero block
+    want = ops.mxfp8_quantize(x.t().contiguous())
+    got = ops.mxfp8_quantize_t(x)
+    assert torch.equal(got[0], want[0])
+    assert torch.equal(got[1][:, :C], want[1][:, :C])
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 520, 384), (3584, 4608, 2048)])
+def test_fp32_accumulating_gemm_of_the_fp8_tile(ops, shape):
+    """st_gemm_mxfp8_nt_f32 (the weight-gradient form: fp32 result, = or +=) against the fp32 product of the de-quantised operands."""
+    M, N, K = shape
+    rs = np.random.RandomState(M + N + K + 7)
+    blk = lambda R: np.repeat(2.0 ** rs.randint(-3, 4, (R, K // 32)), 32, axis=1)
+    a = _bf(rs.standard_normal((M, K)) * blk(M)).cuda()
+    b = _bf(rs.standard_normal((N, K)) * blk(N) * (1 + np.arange(N)[:, None] / N)).cuda()
+    aq, sa = ops.mxfp8_quantize(a)
+    bq, sb = ops.mxfp8_quantize(b)
+    qa, sba = MX.quantize(a.float().cpu().numpy())
+    qb, sbb = MX.quantize(b.float().cpu().numpy())
+    want = torch.from_numpy(MX.dequantize(qa, sba)).cuda() @ torch.from_numpy(MX.dequantize(qb, sbb)).cuda().t()
+    scale = float(want.abs().max())
+    out = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm_mxfp8_nt_f32(aq, sa, bq, sb, out, accumulate=False)
+    assert float((out - want).abs().max()) < scale * 2 ** -12
+    base = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).cuda() * scale
+    out2 = base.clone()
+    ops.gemm_mxfp8_nt_f32(aq, sa, bq, sb, out2, accumulate=True)
+    assert float((out2 - (base + want)).abs().max()) < scale * 2 ** -12
+
+
 def _same_mx(got, want, R):
     assert torch.equal(got[0], want[0])
     assert torch.equal(got[1][:, :R], want[1][:, :R])
@@ -190,8 +225,8 @@ def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
     li = dict(old_log_probs=dv(old), ref_log_probs=dv(old), advantages=dv(adv), response_mask=dv(rmask, torch.int64))
     kw = dict(clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=1.0)
     res = {}
-    for mode in ("bf16", "fp8", "fp8+dgrad"):
-        eng.enable_fp8(mode != "bf16", dgrad=mode == "fp8+dgrad")
+    for mode in ("bf16", "fp8", "fp8+dgrad", "fp8+dgrad+wgrad"):
+        eng.enable_fp8(mode != "bf16", dgrad="dgrad" in mode, wgrad="wgrad" in mode)
         store.grad.zero_()
         lp_e, _ = eng.forward_backward(b, li, 1.0, **kw)
         grads = store.export_hf(store.g)
@@ -215,3 +250,9 @@ def test_7b_dimension_layer_fp8_forward_vs_bf16_and_oracle():
     assert any(res["fp8+dgrad"][1][n_] != res["fp8"][1][n_] for n_ in res["fp8"][1])       # the fp8 dgrad path really ran
     for n_ in res["bf16"][1]:
         assert res["fp8+dgrad"][1][n_] <= 0.60, n_
+    # ... and fp8 weight gradients (token-minor MX blocks): only the LM's weight gradients change
+    assert torch.equal(res["fp8+dgrad+wgrad"][2], res["fp8"][2])
+    lm = [n_ for n_ in res["fp8"][1] if "language_model" in n_]
+    assert lm and all(res["fp8+dgrad+wgrad"][1][n_] != res["fp8+dgrad"][1][n_] for n_ in lm)
+    for n_ in res["bf16"][1]:
+        assert res["fp8+dgrad+wgrad"][1][n_] <= 0.70, n_

@@ -1,5 +1,5 @@
 // gemm_mx4.hip — the block-scaled fp8 GEMM (gemm_fp8.hip: e4m3 elements, one e8m0 scale per 32 consecutive k) on the FOUR-wave
-// hand-scheduled tile of gemm_asm4.hip:   C[M,N] (bf16) = dequant(Aq)[M,K] * dequant(Bq)[N,K]^T (+bias)(+residual).
+// hand-scheduled tile of gemm_asm4.hip:   C[M,N] = dequant(Aq)[M,K] * dequant(Bq)[N,K]^T  (bf16 (+bias)(+residual), SwiGLU, fp8 or fp32 results).
 //
 // Why a second fp8 kernel: the 8-wave fp8 tile of gemm_fp8.hip ran 1.48 PF/s in situ next to 1.38 PF/s of the bf16 4-wave tile — the
 // fp8 mode paid for its quantiser passes and gained nothing (profiles/r03_notes.md).  The 4-wave tile's K loop carries over unchanged
@@ -16,13 +16,16 @@
 //     dwords travel with the operands (two 256-byte LDS-DMA copies per wave and K-tile); a lane reads its rows' dwords once per k-step
 //     and shifts them right by 8g: byte 0 is then the scale of block g (k-step 0) and byte 2 that of block 2+g (k-step 1), selected by
 //     the instruction's op_sel.
-//   * schedule per K-tile and wave (32 MFMA slots of 64 cycles; every other instruction sits behind one of them):
-//       0..3    the 16 fragment reads + 8 scale reads of k-step 1 (this tile's slot)
-//       6       lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot
-//       7..30   the 18 LDS-DMA copies of tile t+2 into that slot (2 scale copies, then 16 operand copies on two of every three slots:
-//               ~96 cycles apart, as in the bf16 tile — the four waves share one texture addresser)
-//       25      vmcnt(14) + barrier #2: tile t+1 has landed for every wave
-//       26..30  the 16 fragment reads + 8 scale reads of (t+1, k-step 0)
+//   * schedule per K-tile and wave (32 MFMA slots of 64 cycles; every other instruction sits behind one of them) = compile-time data
+//     (Q4Sched below; default schedule 6):
+//       0..7    the 16 fragment reads + 8 scale reads of k-step 1 (this tile's slot), three per slot
+//       11      lgkmcnt(0) + barrier #1: every wave is done reading this tile's slot
+//       11..27  the 18 LDS-DMA copies of tile t+2 into that slot (2 scale copies, then one operand copy per slot: a 64-cycle MFMA hides
+//               the ~50-cycle issue that costs the bf16 tile 20 % of its K loop)
+//       21      vmcnt + barrier #2: tile t+1 has landed for every wave (the copies issued so far stay in flight)
+//       22..29  the 16 fragment reads + 8 scale reads of (t+1, k-step 0), three per slot
+//   * epilogues (through the idle operand LDS, 16-byte row-contiguous stores): bf16 (+bias)(+residual); bf16(silu(gate)) * up for the
+//     MLP's first product (SWIGLU); that result as the MX-fp8 operand of the down projection (QOUT); fp32 = / += (OUTF: weight gradients).
 // Roofline: MFMA-bound, 2*M*N*K flop per launch against the 5 PF dense fp8 peak.
 #include "common.h"
 #include <type_traits>

@@ -109,6 +109,10 @@ int st_swiglu_fwd(const st_bf16* gu, int64_t ldgu, st_bf16* out, int64_t ldo, in
 /* dgu = [dout*up*silu'(gate) | dout*silu(gate)], may alias gu. */
 int st_swiglu_bwd(const st_bf16* gu, int64_t ldgu, const st_bf16* dout, int64_t lddo, st_bf16* dgu,
                   int64_t lddgu, int T, int I, st_stream_t stream);
+/* st_swiglu_bwd that also writes m_out (T, I) = st_swiglu_fwd(gu), bit for bit, from the values it reads anyway (NULL: plain st_swiglu_bwd):
+ * the backward that did not keep the activation needs it for the down projection's weight gradient. */
+int st_swiglu_bwd_m(const st_bf16* gu, int64_t ldgu, const st_bf16* dout, int64_t lddo, st_bf16* dgu, int64_t lddgu, st_bf16* m_out,
+                    int64_t ldm, int T, int I, st_stream_t stream);
 /* exact (erf) GELU of the patch merger (HF :137-150), fwd and bwd (dx = dy * gelu'(x)). */
 int st_gelu_fwd(const st_bf16* x, st_bf16* y, int64_t n, st_stream_t stream);
 int st_gelu_bwd(const st_bf16* x, const st_bf16* dy, st_bf16* dx, int64_t n, st_stream_t stream);

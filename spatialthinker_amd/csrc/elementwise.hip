@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void swiglu_mxfp8_kernel(const uint16_t* __res
     if (live && (lane & 15) == 0) scales[(int64_t)(c >> 7) * scale_rows + t] = sd;
 }
 
+// m_out (optional): the forward's result silu(gate) * up, recomputed here from the gate | up values this kernel reads anyway — the
+// recompute_light backward needs it for the down projection's weight gradient and used to run st_swiglu_fwd (one more pass over gu) for it
 __global__ void swiglu_bwd_kernel(const uint16_t* __restrict__ gu, int64_t ldgu, const uint16_t* __restrict__ dout,
-                                  int64_t lddo, uint16_t* __restrict__ dgu, int64_t lddgu, int T, int I) {
+                                  int64_t lddo, uint16_t* __restrict__ dgu, int64_t lddgu, uint16_t* __restrict__ m_out, int64_t ldm, int T, int I) {
     const int chunks = I >> 3;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)T * chunks) return;
@@ -108,6 +110,12 @@ __global__ void swiglu_bwd_kernel(const uint16_t* __restrict__ gu, int64_t ldgu,
         const float sg = sigmoidf_(g[j]);
         du[j] = d[j] * (g[j] * sg);
         dg[j] = d[j] * u[j] * (sg * (1.f + g[j] * (1.f - sg)));
+    }
+    if (m_out) {                                              // before the stores below: dgu may alias gu
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bfround(g[j] * sigmoidf_(g[j])) * u[j];       // the expression of swiglu_fwd_kernel: bit-identical
+        *reinterpret_cast<uint4*>(m_out + (int64_t)t * ldm + c) = pack8(o);
     }
     *reinterpret_cast<uint4*>(dgu + (int64_t)t * lddgu + c) = pack8(dg);
     *reinterpret_cast<uint4*>(dgu + (int64_t)t * lddgu + I + c) = pack8(du);
@@ -596,11 +604,16 @@ int st_swiglu_mxfp8(const st_bf16* gu, int64_t ldgu, st_bf16* out, int64_t ldo, 
 
 int st_swiglu_bwd(const st_bf16* gu, int64_t ldgu, const st_bf16* dout, int64_t lddo, st_bf16* dgu, int64_t lddgu, int T,
                   int I, st_stream_t stream) {
-    if (!gu || !dout || !dgu || T < 0 || I <= 0 || (I & 7) || (ldgu & 7) || (lddo & 7) || (lddgu & 7)) return ST_EINVAL;
+    return st_swiglu_bwd_m(gu, ldgu, dout, lddo, dgu, lddgu, nullptr, 0, T, I, stream);
+}
+
+int st_swiglu_bwd_m(const st_bf16* gu, int64_t ldgu, const st_bf16* dout, int64_t lddo, st_bf16* dgu, int64_t lddgu, st_bf16* m_out,
+                    int64_t ldm, int T, int I, st_stream_t stream) {
+    if (!gu || !dout || !dgu || T < 0 || I <= 0 || (I & 7) || (ldgu & 7) || (lddo & 7) || (lddgu & 7) || (m_out && ((ldm & 7) || ldm < I))) return ST_EINVAL;
     if (T == 0) return 0;
     const int64_t n = (int64_t)T * (I / 8);
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(st_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gu, ldgu, dout, lddo, dgu,
-                       lddgu, T, I);
+                       lddgu, m_out, ldm, T, I);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -674,13 +674,14 @@ class Qwen25VL:
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
         x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved
-        if m is None:                                       # recompute the light activations (see _lm_layer_fwd)
-            m = ops.swiglu_fwd(gu)
+        dm = self._dgrad(dx2, p + "down_w")
+        if m is None:                                       # recompute the light activations (see _lm_layer_fwd): m in the pass that
+            dgu, m = ops.swiglu_bwd(gu, dm, want_m=True)    # forms dgu from the same gate | up values (bit-identical to swiglu_fwd)
             h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
             h1, _ = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps, want_rstd=False)
+        else:
+            dgu = ops.swiglu_bwd(gu, dm)
         self._dw(g[p + "down_w"], dx2, m, None, fp8=self.fp8_wgrad)
-        dm = self._dgrad(dx2, p + "down_w")
-        dgu = ops.swiglu_bwd(gu, dm)
         self._dw(g[p + "gu_w"], dgu, h2, None, fp8=self.fp8_wgrad)
         dh2 = self._dgrad(dgu, p + "gu_w")
         dx1 = ops.rmsnorm_bwd(x1, w[p + "post_norm"], r2, dh2, dres=dx2, dw_accum=g[p + "post_norm"])

@@ -121,11 +121,16 @@ def swiglu_fwd(gu, out=None):
     return o
 
 
-def swiglu_bwd(gu, dout, out=None):
+def swiglu_bwd(gu, dout, out=None, want_m=False):
+    """dgu of the SwiGLU; want_m: also the forward's result m = swiglu_fwd(gu) (bit-identical), recomputed in the same pass -> (dgu, m)."""
     T, I2 = gu.shape
     d = torch.empty_like(gu) if out is None else out
-    lib().st_swiglu_bwd(_p(gu), gu.stride(0), _p(dout), dout.stride(0), _p(d), d.stride(0), T, I2 // 2, _s())
-    return d
+    if not want_m:
+        lib().st_swiglu_bwd(_p(gu), gu.stride(0), _p(dout), dout.stride(0), _p(d), d.stride(0), T, I2 // 2, _s())
+        return d
+    m = torch.empty(T, I2 // 2, dtype=BF16, device=gu.device)
+    lib().st_swiglu_bwd_m(_p(gu), gu.stride(0), _p(dout), dout.stride(0), _p(d), d.stride(0), _p(m), m.stride(0), T, I2 // 2, _s())
+    return d, m
 
 
 def gelu_fwd(x):

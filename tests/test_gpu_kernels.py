@@ -207,6 +207,12 @@ def test_swiglu_gelu(ops):
     want.backward(do.float())
     dgu = ops.swiglu_bwd(gu.cuda(), do.cuda())
     assert rel_err(dgu.float().cpu().numpy(), torch.cat([g.grad, u.grad], -1).numpy()) < 2 ** -6
+    # the backward that recomputes the forward's result in the same pass (recompute_light): both outputs bit-identical to the two kernels
+    dgu2, m2 = ops.swiglu_bwd(gu.cuda(), do.cuda(), want_m=True)
+    assert torch.equal(dgu2, dgu) and torch.equal(m2, out)
+    gu_inplace = gu.cuda().clone()
+    dgu3, m3 = ops.swiglu_bwd(gu_inplace, do.cuda(), out=gu_inplace, want_m=True)          # dgu may alias gu
+    assert torch.equal(dgu3, dgu) and torch.equal(m3, out)
     x = bf(rs.standard_normal(4096) * 2)
     xg = x.float().clone().requires_grad_(True)
     y = torch.nn.functional.gelu(xg)

@@ -66,6 +66,16 @@ int st_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp
                  const int64_t* mask, int n, double clip_low, double clip_high, double clip_dual,
                  int kl_kind, double kl_coef, double grad_accum, float* g, float* metrics, st_stream_t stream);
 
+/* ---- critic (adv_estimator = gae; /root/reference/verl/workers/critic/dp_critic.py) -------------------------------------------------
+ * st_value_head_fwd: v[t] = bf16(hn[t] . w + b) — the `score = nn.Linear(H, 1)` head whose `output.logits` dp_critic.py:104-118 reads.
+ * st_value_head_bwd: dhn = dv (x) w (bf16), dw_accum += dv^T hn, db_accum += sum(dv) (fp32, deterministic).
+ * st_value_loss: core_algos.py:356-392 compute_value_loss + its gradient: g = d(vf_loss / grad_accum)/dvpreds;
+ *   metrics = [vf_loss, vf_clipfrac, masked_mean(vpreds), sum(mask)] (dp_critic.py:196-211). */
+int st_value_head_fwd(const st_bf16* hn, int64_t ldh, const st_bf16* w, const st_bf16* bias, float* out, int T, int H, st_stream_t stream);
+int st_value_head_bwd(const st_bf16* hn, int64_t ldh, const st_bf16* w, const float* dv, st_bf16* dhn, int64_t lddh, float* dw_accum,
+                      float* db_accum, int T, int H, st_stream_t stream);
+int st_value_loss(const float* vpreds, const float* returns, const float* values, const int64_t* mask, int n, double cliprange_value,
+                  double grad_accum, float* g, float* metrics, st_stream_t stream);
 /* ---- GRPO outcome advantage (verl/trainer/core_algos.py:137-175) ------------------------------
  * rewards (N, R) fp32, mask (N, R) int64, group (N,) int32 dense group index in [0, n_groups)
  * (the host maps uid strings to it).  score_i = sum_t rewards[i,t]; per group, members visited in

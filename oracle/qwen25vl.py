@@ -306,3 +306,33 @@ def response_log_probs(p, cfg: VLConfig, input_ids_2d, attention_mask_2d, positi
     full = torch.zeros(B * S, dtype=logp.dtype, device=logp.device)
     full[flat_idx] = logp
     return full.reshape(B, S)[:, -response_length - 1:-1]
+
+
+def response_values(p, cfg: VLConfig, input_ids_2d, attention_mask_2d, position_ids_3d, response_length: int, pixel_values=None, grid_thw=None):
+    """verl/workers/critic/dp_critic.py:52-125 restated (padding-free branch): the token-classification model's `logits` — score =
+    Linear(H, 1) (p["score.weight"] (1, H), p["score.bias"] (1,)) on the final-norm hidden state of every valid token — scattered back to
+    (B, S) and sliced [:, -R-1:-1]: the value of the state BEFORE each response token.  Returns (B, R) fp32."""
+    B, S = input_ids_2d.shape
+    valid = attention_mask_2d.bool()
+    flat_idx = valid.reshape(-1).nonzero()[:, 0]
+    ids = input_ids_2d.reshape(-1)[flat_idx]
+    pos = position_ids_3d.permute(1, 0, 2).reshape(3, -1)[:, flat_idx]
+    lens = valid.sum(-1)
+    cu = torch.cat([lens.new_zeros(1), lens.cumsum(0)])
+    lm = "model.language_model."
+    x = p[lm + "embed_tokens.weight"][ids]
+    if pixel_values is not None:
+        img = vision_tower(p, cfg, pixel_values, grid_thw)
+        mask = ids == cfg.image_token_id
+        x = x.clone()
+        x[mask] = img.to(x.dtype)
+    cos, sin = mrope_cos_sin(pos, cfg.head_dim, cfg.rope_theta, cfg.mrope_section)
+    cos, sin = cos.to(x.dtype), sin.to(x.dtype)
+    for i in range(cfg.num_layers):
+        x = lm_layer(p, cfg, i, x, cos, sin, cu)
+    h = rms_norm(x, p[lm + "norm.weight"], cfg.rms_eps)
+    v = (h @ p["score.weight"].reshape(-1, 1))[:, 0] + p["score.bias"].reshape(-1)[0]
+    full = torch.zeros(B * S, dtype=v.dtype, device=v.device)
+    full[flat_idx] = v
+    return full.reshape(B, S)[:, -response_length - 1:-1]
+

@@ -49,6 +49,7 @@ class ActorHyper:
     grad_exchange_dtype: str = "fp32"       # payload of the exchange: "fp32" (FSDP mp_reduce_dtype default) | "bf16"
     optim_strategy: str = "adamw_bf16"      # adamw_bf16 = AnyPrecisionAdamW (bf16 states + Kahan); adamw = torch.optim.AdamW(fused) semantics
     freeze_vision_tower: bool = False       # fsdp_workers.py:226-232: the ViT gets no gradient and no optimizer update
+    cliprange_value: float = 0.5            # critic only (verl/workers/critic/config.py:29)
 
 
 class _StagePool:
@@ -550,3 +551,68 @@ class PolicyEngine:
         metrics["actor/lr"] = self.current_lr()                   # lr AFTER scheduler.step(), as fsdp_workers.py:453-455
         release_cached_blocks()
         return dict(metrics)
+
+
+class CriticEngine(PolicyEngine):
+    """DataParallelPPOCritic (verl/workers/critic/dp_critic.py) on the same engine: the backbone with a score head (VLConfig.value_head),
+    the same pass planner / packing / gradient exchange / optimizer as the actor; only the head, the loss and the metric names differ."""
+
+    @staticmethod
+    def action_mask(attention_mask: torch.Tensor, R: int) -> torch.Tensor:
+        """attention_mask[:, -R-1:-1] (dp_critic.py:174,193): the mask of the INPUT token at each value position, shifted left by one."""
+        return torch.as_tensor(attention_mask)[:, -R - 1:-1]
+
+    def compute_values(self, data: Dict[str, Any], micro_batch_size: Optional[int] = None) -> torch.Tensor:
+        """dp_critic.py:140-175: (N, R) fp32 values of the states before each response token, times the action mask."""
+        N = data["input_ids"].shape[0]
+        mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
+        R = data["responses"].shape[1]
+        p_len, r_len, keys = self._row_stats(data, R)
+        passes = self._plan_passes(0, N, mb, max(1, int(self.fuse_experience)), self.tokens_per_pass_nograd, p_len, r_len, keys)
+        self.last_plan["experience"] = passes
+        outs = []
+        for (a, b_) in passes:
+            b = self._stage(data, slice(a, b_))
+            outs.append(self.model.values(b))
+        out = torch.cat(outs, 0)
+        del outs, b
+        release_cached_blocks()
+        return out * self.action_mask(data["attention_mask"], R).to(out.device, out.dtype)
+
+    def update_critic(self, data: Dict[str, Any]) -> Dict[str, List[float]]:
+        """dp_critic.py:177-225.  data: input_ids, attention_mask, position_ids, responses, values, returns, [multi_modal_inputs]."""
+        h = self.h
+        N = data["input_ids"].shape[0]
+        R = data["responses"].shape[1]
+        dev = self.store.device
+        metrics: Dict[str, List[float]] = defaultdict(list)
+        pending = []
+        mini, micro = h.global_batch_size_per_device, h.micro_batch_size_per_device_for_update
+        assert N % mini == 0 and mini % micro == 0, (N, mini, micro)
+        accum = mini // micro
+        p_len, r_len, keys = self._row_stats(data, R)
+        plan = self.last_plan["update"] = []
+        for _ in range(h.ppo_epochs):
+            for m0 in range(0, N, mini):
+                passes = self._plan_passes(m0, m0 + mini, micro, max(1, int(self.fuse_micro_batches)), self.tokens_per_pass_grad, p_len, r_len, keys)
+                plan.extend(passes)
+                for (s, e) in passes:
+                    sl = slice(s, e)
+                    red = self.grad_reducer() if (self.overlap_allreduce and e >= m0 + mini) else None
+                    b = self._stage(data, sl)
+                    to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
+                    loss_in = dict(values=to("values"), returns=to("returns"),
+                                   action_mask=self.action_mask(data["attention_mask"][sl], R).to(dev, I64))
+                    _, met = self.model.value_forward_backward(b, loss_in, cliprange_value=h.cliprange_value, grad_accum=float(accum), loss_rows=micro,
+                                                               on_final=red.ready if red is not None else None,
+                                                               train_vision=not h.freeze_vision_tower)
+                    pending.extend(met if met.dim() == 2 else [met])
+                norm = self.optimizer_step()
+                metrics["critic/grad_norm"].append(norm)
+        for met in torch.stack(pending).cpu().tolist():
+            metrics["critic/vf_loss"].append(met[0]); metrics["critic/vf_clipfrac"].append(met[1]); metrics["critic/vpred_mean"].append(met[2])
+        self.sched_steps += 1
+        metrics["critic/lr"] = self.current_lr()
+        release_cached_blocks()
+        return dict(metrics)
+

@@ -513,6 +513,39 @@ __global__ __launch_bounds__(1024) void grpo_loss_kernel(const float* __restrict
     }
 }
 
+// Clipped value loss of the critic (core_algos.py:356-392 compute_value_loss, called from dp_critic.py:196-203):
+//   loss = 0.5 * masked_mean(max((v - R)^2, (clamp(v, V - c, V + c) - R)^2)), clipfrac = masked_mean((v - R)^2 < (clamped - R)^2),
+// masked_mean(x) = sum(x * m) / (sum(m) + 1e-8); g = d(loss / grad_accum) / dv with torch's conventions (clamp passes the gradient inside
+// its bounds incl. the bounds, max splits it evenly on a tie — inside the clip range both branches are the same function).
+// metrics: [vf_loss, vf_clipfrac, masked_mean(v), sum(mask)].  Single workgroup: deterministic.
+__global__ __launch_bounds__(1024) void value_loss_kernel(const float* __restrict__ vpred, const float* __restrict__ returns,
+                                                         const float* __restrict__ values, const int64_t* __restrict__ mask, int n, float clip,
+                                                         float inv_accum, float* __restrict__ g, float* __restrict__ metrics) {
+    __shared__ float sh[16];
+    float msum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) msum += (float)mask[i];
+    const float M = block_sum_1024(msum, sh);
+    const float inv = 1.f / (M + 1e-8f);
+    float a_loss = 0.f, a_clip = 0.f, a_v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float mk = (float)mask[i];
+        const float v = vpred[i], R = returns[i], lo = values[i] - clip, hi = values[i] + clip;
+        const float vc = fminf(fmaxf(v, lo), hi);
+        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+        const float inside = (v >= lo && v <= hi) ? 1.f : 0.f;
+        const float g1 = v - R, g2 = (vc - R) * inside;                   // d(0.5 l1)/dv, d(0.5 l2)/dv
+        const float sel1 = l1 > l2 ? 1.f : (l1 == l2 ? 0.5f : 0.f);
+        a_loss += fmaxf(l1, l2) * mk;
+        a_clip += (l1 < l2 ? 1.f : 0.f) * mk;
+        a_v += v * mk;
+        g[i] = (sel1 * g1 + (1.f - sel1) * g2) * mk * inv * inv_accum;
+    }
+    const float L = 0.5f * block_sum_1024(a_loss, sh) * inv;
+    const float C = block_sum_1024(a_clip, sh) * inv;
+    const float V = block_sum_1024(a_v, sh) * inv;
+    if (threadIdx.x == 0) { metrics[0] = L; metrics[1] = C; metrics[2] = V; metrics[3] = M; }
+}
+
 // GRPO outcome advantage.  Stage A: one thread per row -> score.  Stage B: one thread per group scans the rows
 // in order (sequential fp32 sum for the mean, fp64 Welford for the unbiased std — torch CPU semantics).
 // Stage C: broadcast over the response mask.  Single workgroup per stage-B chunk keeps it deterministic.
@@ -780,6 +813,15 @@ int st_grpo_loss(const float* logp, const float* old_logp, const float* ref_logp
     const float lo = (float)log(1.0 - clip_low), hi = (float)log(1.0 + clip_high);
     hipLaunchKernelGGL(grpo_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, old_logp, ref_logp, adv, mask, n, lo,
                        hi, (float)clip_dual, kl_kind, (float)kl_coef, (float)(1.0 / grad_accum), g, metrics);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_value_loss(const float* vpreds, const float* returns, const float* values, const int64_t* mask, int n, double cliprange_value,
+                  double grad_accum, float* g, float* metrics, st_stream_t stream) {
+    if (!vpreds || !returns || !values || !mask || !g || !metrics || n <= 0 || !(grad_accum > 0.0)) return ST_EINVAL;
+    hipLaunchKernelGGL(value_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vpreds, returns, values, mask, n, (float)cliprange_value,
+                       (float)(1.0 / grad_accum), g, metrics);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -139,6 +139,67 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const uint16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Critic value head (dp_critic.py:52-125 reads `output.logits` of a token-classification model: score = nn.Linear(H, 1) on the final hidden
+// state, in the model's bf16): v[t] = bf16(sum_h hn[t][h] * w[h] + b).  One wave per row.
+// Backward: dhn[t][:] = bf16(dv[t] * w[:]); dw[:] += sum_t dv[t] * hn[t][:] (fp32, fixed row order per column: deterministic); db += sum dv.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void value_head_fwd_kernel(const uint16_t* __restrict__ hn, int64_t ldh, const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ bias, float* __restrict__ out, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    float acc = 0.f;
+    for (int i = lane * 8; i < H; i += 512) {
+        float f[8], wf[8];
+        unpack8(*reinterpret_cast<const uint4*>(hn + (int64_t)row * ldh + i), f);
+        unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += f[j] * wf[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = bfround(acc + (bias ? bf2f(bias[0]) : 0.f));
+}
+
+__global__ __launch_bounds__(256) void value_head_bwd_dx_kernel(const uint16_t* __restrict__ w, const float* __restrict__ dv, uint16_t* __restrict__ dhn,
+                                                               int64_t lddh, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float d = dv[row];
+    for (int i = lane * 8; i < H; i += 512) {
+        float wf[8];
+        unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[j] *= d;
+        *reinterpret_cast<uint4*>(dhn + (int64_t)row * lddh + i) = pack8(wf);
+    }
+}
+
+// one workgroup per 64 columns: thread (c = t & 63, lane group r = t >> 6) walks rows r, r + 4, ...; the four partial sums are added in a
+// fixed order.  Workgroup 0 also sums dv for the bias.
+__global__ __launch_bounds__(256) void value_head_bwd_dw_kernel(const uint16_t* __restrict__ hn, int64_t ldh, const float* __restrict__ dv,
+                                                               float* __restrict__ dw, float* __restrict__ db, int T, int H) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
+    float acc = 0.f, accb = 0.f;
+    if (c < H)
+        for (int t = r0; t < T; t += 4) {
+            const float d = dv[t];
+            acc += d * bf2f(hn[(int64_t)t * ldh + c]);
+            accb += d;
+        }
+    part[r0][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (r0 == 0 && c < H) dw[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (blockIdx.x == 0 && db) {                               // every column thread of a lane group holds the same bias partial
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) part[r0][0] = accb;
+        __syncthreads();
+        if (threadIdx.x == 0) db[0] += (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+    }
+}
+
 // RMSNorm forward feeding an MX-fp8 GEMM (config #5): the same row arithmetic, and the bf16 result is quantised in the same pass (e4m3 +
 // e8m0 block scales in the layout of st_mxfp8_quantize: bit-identical to st_rmsnorm_fwd followed by st_mxfp8_quantize); the bf16 result
 // itself is written only when the caller keeps it (y != nullptr: the weight-gradient GEMM of a pass with gradients).  H % 128 == 0:
@@ -304,6 +365,25 @@ int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, s
         hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, H);
     else
         hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_value_head_fwd(const st_bf16* hn, int64_t ldh, const st_bf16* w, const st_bf16* bias, float* out, int T, int H, st_stream_t stream) {
+    if (!hn || !w || !out || T < 0 || H <= 0 || (H & 7) || (ldh & 7) || ldh < H) return ST_EINVAL;
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(value_head_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, hn, ldh, w, bias, out, T, H);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_value_head_bwd(const st_bf16* hn, int64_t ldh, const st_bf16* w, const float* dv, st_bf16* dhn, int64_t lddh, float* dw_accum,
+                      float* db_accum, int T, int H, st_stream_t stream) {
+    if (!hn || !w || !dv || !dhn || !dw_accum || T < 0 || H <= 0 || (H & 7) || (ldh & 7) || (lddh & 7) || ldh < H || lddh < H) return ST_EINVAL;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(value_head_bwd_dx_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, w, dv, dhn, lddh, T, H);
+    hipLaunchKernelGGL(value_head_bwd_dw_kernel, dim3(st_cdiv(H, 64)), dim3(256), 0, s, hn, ldh, dv, dw_accum, db_accum, T, H);
     ST_CHECK_LAUNCH();
     return 0;
 }

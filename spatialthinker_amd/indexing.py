@@ -173,7 +173,7 @@ class PackedBatch:
 
 
 def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: np.ndarray, response_length: int, *,
-               image_token_id: int, pad_multiple: int = 128, groups: Optional[Sequence[int]] = None) -> PackedBatch:
+               image_token_id: int, pad_multiple: int = 128, groups: Optional[Sequence[int]] = None, value_rows: bool = False) -> PackedBatch:
     """The padding-free transformation of verl/workers/actor/dp_actor.py:86-104,136-139 done once on
     the host: valid tokens are concatenated; log-probs are only needed at [:, -R-1:-1] of every row,
     and only where the response mask is set, so the lm_head runs on exactly those rows.
@@ -245,8 +245,10 @@ def pack_batch(input_ids: np.ndarray, attention_mask: np.ndarray, position_ids: 
     # per-row cumulative lengths keep their historical meaning (full sequence lengths): metrics / FLOP counters use them
     cu = np.concatenate([[0], np.cumsum(lens_full)]).astype(np.int32)
     # response slot j of row b sits at column S-R+j; its log-prob comes from the logits of column S-R+j-1
+    # value_rows (critic, dp_critic.py:113,174,193): every slot whose INPUT token is valid — attention_mask[:, -R-1:-1] — i.e. one more than
+    # the response mask per row: the state after the last response token, whose value the GAE recursion reads (core_algos.py:100-110)
     cols = np.arange(Pc, S)
-    valid = mask[:, cols] & mask[:, cols - 1]
+    valid = mask[:, cols - 1] if value_rows else (mask[:, cols] & mask[:, cols - 1])
     bb, jj = np.nonzero(valid)
     logit_rows = packed_row[bb, cols[jj] - 1]
     labels = ids[bb, cols[jj]].astype(np.int64)

@@ -47,6 +47,7 @@ class VLConfig:
     rope_theta: float = 1e6
     mrope_section: List[int] = field(default_factory=lambda: [16, 24, 24])
     tie_word_embeddings: bool = False
+    value_head: bool = False            # critic: score = Linear(H, 1) on the final hidden state instead of the lm_head (token classification)
     v_depth: int = 32
     v_hidden: int = 1280
     v_heads: int = 16
@@ -163,7 +164,10 @@ def param_layout(c: VLConfig) -> "Dict[str, Tuple[int, ...]]":
         L.update({p + "in_norm": (H,), p + "qkv_w": (c.qkv_width, H), p + "qkv_b": (c.qkv_width,), p + "o_w": (H, H),
                   p + "post_norm": (H,), p + "gu_w": (2 * I, H), p + "down_w": (H, I)})
     L["final_norm"] = (H,)
-    if not c.tie_word_embeddings:
+    if c.value_head:
+        L["score_w"] = (H,)
+        L["score_b"] = (8,)                 # element 0 is the bias (8: keeps the slice a whole 16-byte vector)
+    elif not c.tie_word_embeddings:
         L["lm_head"] = (V, H)
     return L
 
@@ -276,7 +280,12 @@ class ParamStore:
             put(p + "gu_w", torch.cat([sd[s + "mlp.gate_proj.weight"].float(), sd[s + "mlp.up_proj.weight"].float()], 0))
             put(p + "down_w", sd[s + "mlp.down_proj.weight"])
         put("final_norm", sd["model.language_model.norm.weight"])
-        if not c.tie_word_embeddings:
+        if c.value_head:                                        # a policy checkpoint has no score head: it starts at zero (values = 0)
+            if "score.weight" in sd:
+                put("score_w", sd["score.weight"].reshape(-1))
+                if "score.bias" in sd:
+                    bias = torch.zeros(8); bias[0] = float(sd["score.bias"].reshape(-1)[0]); put("score_b", bias)
+        elif not c.tie_word_embeddings:
             put("lm_head", sd["lm_head.weight"])
         if self.trainable and target is None:
             if getattr(self, "master", None) is not None:        # fp32 master mode: the master takes the checkpoint's own precision
@@ -313,7 +322,10 @@ class ParamStore:
                         s + "self_attn.o_proj.weight": src[p + "o_w"], s + "mlp.gate_proj.weight": src[p + "gu_w"][:I],
                         s + "mlp.up_proj.weight": src[p + "gu_w"][I:], s + "mlp.down_proj.weight": src[p + "down_w"]})
         out["model.language_model.norm.weight"] = src["final_norm"]
-        if not c.tie_word_embeddings:
+        if c.value_head:
+            out["score.weight"] = src["score_w"].reshape(1, -1)
+            out["score.bias"] = src["score_b"][:1]
+        elif not c.tie_word_embeddings:
             out["lm_head.weight"] = src["lm_head"]
         return out
 
@@ -422,7 +434,7 @@ class Qwen25VL:
         j-th image-bearing sample (one image per sample); the features are gathered per sample and their gradients summed."""
         c, dev = self.cfg, self.p.device
         pk = ix.pack_batch(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, image_token_id=c.image_token_id,
-                           groups=groups)
+                           groups=groups, value_rows=c.value_head)
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
         pos = t(pk.pos, I32)
         cos, sin = ops.mrope_table(pos, self.inv_freq, c.head_dim, c.mrope_section)
@@ -758,6 +770,81 @@ class Qwen25VL:
         out = torch.zeros(b.pk.B * b.pk.R, dtype=F32, device=x.device)
         out.index_copy_(0, b.out_index, logp[:len(b.out_index)])
         return out.view(b.pk.B, b.pk.R)
+
+    # ---------------------------------------------------------------- critic (cfg.value_head): dp_critic.py
+    def _value_head_fwd(self, x: torch.Tensor, b: DeviceBatch):
+        """values at the rows that PRECEDE a response token (`values[:, -R-1:-1]`, dp_critic.py:113,125 — the rows the actor's lm_head runs on)."""
+        c, w = self.cfg, self.p.w
+        xr = ops.rows_gather(x, b.logit_rows)
+        hn, rn = ops.rmsnorm_fwd(xr, w["final_norm"], c.rms_eps)
+        v = ops.value_head_fwd(hn, w["score_w"], w["score_b"])
+        return xr, hn, rn, v
+
+    @torch.no_grad()
+    def values(self, b: DeviceBatch) -> torch.Tensor:
+        """(B, R) fp32 value predictions — DataParallelPPOCritic._forward_micro_batch (dp_critic.py:52-125), no-grad use."""
+        assert self.cfg.value_head
+        x = self._embed(b, None)
+        for i in range(self.cfg.num_layers):
+            x = self._lm_layer_fwd(i, x, b, None)
+        *_, v = self._value_head_fwd(x, b)
+        out = torch.zeros(b.pk.B * b.pk.R, dtype=F32, device=x.device)
+        out.index_copy_(0, b.out_index, v[:len(b.out_index)])
+        return out.view(b.pk.B, b.pk.R)
+
+    @torch.no_grad()
+    def value_forward_backward(self, b: DeviceBatch, loss_inputs: dict, *, cliprange_value: float, grad_accum: float, loss_rows: Optional[int] = None,
+                               on_final=None, train_vision: bool = True):
+        """One micro-batch of update_critic (dp_critic.py:184-205): forward, clipped value loss, backward into the flat fp32 gradient
+        buffer (accumulating).  loss_inputs: values, returns (B, R) fp32 and action_mask (B, R) int64 = attention_mask[:, -R-1:-1].
+        Returns (vpreds (B, R), metrics (4,) or (k, 4) device: vf_loss, vf_clipfrac, masked mean of vpreds, mask count)."""
+        c, g = self.cfg, self.p.g
+        assert c.value_head
+        off = self.p.offsets
+        layer_lo = lambda i: off[f"l.{i}.in_norm"] if i < c.num_layers else off["final_norm"]
+        vit_saved: Optional[list] = [] if train_vision else None
+        x = self._embed(b, vit_saved)
+        saved = []
+        for i in range(c.num_layers):
+            x = self._lm_layer_fwd(i, x, b, saved)
+        xr, hn, rn, v = self._value_head_fwd(x, b)
+        Tr, n = len(b.out_index), b.pk.B * b.pk.R
+        vp_full = torch.zeros(n, dtype=F32, device=x.device)
+        vp_full.index_copy_(0, b.out_index, v[:Tr])
+        flat = lambda k: loss_inputs[k].reshape(-1).contiguous()
+        val_f, ret_f, msk_f = flat("values").float(), flat("returns").float(), flat("action_mask").to(I64)
+        loss_rows = loss_rows or b.pk.B
+        if loss_rows >= b.pk.B:
+            gfull, metrics = ops.value_loss(vp_full, ret_f, val_f, msk_f, cliprange_value=cliprange_value, grad_accum=grad_accum)
+        else:                                                   # several reference micro-batches in one pass: each keeps its own masked means
+            gs, ms = [], []
+            for r0 in range(0, b.pk.B, loss_rows):
+                sl = slice(r0 * b.pk.R, min(b.pk.B, r0 + loss_rows) * b.pk.R)
+                g_i, m_i = ops.value_loss(vp_full[sl], ret_f[sl], val_f[sl], msk_f[sl], cliprange_value=cliprange_value, grad_accum=grad_accum)
+                gs.append(g_i); ms.append(m_i)
+            gfull, metrics = torch.cat(gs), torch.stack(ms)
+        grow = torch.zeros(b.Tr_pad, dtype=F32, device=x.device)
+        grow[:Tr] = gfull.index_select(0, b.out_index)
+        dhn = ops.value_head_bwd(hn, self.p.w["score_w"], grow, g["score_w"], g["score_b"])
+        dxr = ops.rmsnorm_bwd(xr, self.p.w["final_norm"], rn, dhn, dw_accum=g["final_norm"])
+        if on_final is not None:                               # final_norm + score head close the buffer (param_layout)
+            on_final(off["final_norm"], self.p.numel)
+        dx = torch.zeros_like(x)
+        if b.logit_dup is not None:
+            ops.rows_scatter_(dx, b.logit_distinct, ops.rows_gather_sum(dxr, b.logit_dup))
+        else:
+            ops.rows_scatter_(dx, b.logit_rows[:Tr], dxr[:Tr])
+        for i in reversed(range(c.num_layers)):
+            dx = self._lm_layer_bwd(i, dx, b, saved.pop())
+            if on_final is not None:
+                on_final(layer_lo(i), layer_lo(i + 1))
+        ops.embed_grad_(g["embed"], b.embed_ids, dx)
+        if b.vis is not None and train_vision:
+            d_img = ops.rows_gather(dx, b.image_rows)
+            if b.vis["dup_idx"] is not None:
+                d_img = ops.rows_gather_sum(d_img, b.vis["dup_idx"])
+            self._vit_backward(b, vit_saved, d_img)
+        return vp_full.view(b.pk.B, b.pk.R), metrics
 
     @torch.no_grad()
     def forward_backward(self, b: DeviceBatch, loss_inputs: dict, temperature: float = 1.0, **loss_kw):

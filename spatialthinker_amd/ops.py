@@ -71,6 +71,36 @@ def grpo_loss(logp, old_logp, ref_logp, adv, mask, *, clip_low=0.2, clip_high=0.
     return g, met
 
 
+def value_loss(vpreds, returns, values, mask, *, cliprange_value=0.5, grad_accum=1.0):
+    """Clipped value loss of the critic (core_algos.compute_value_loss) + gradient: flattened (n,) fp32 inputs, mask int64 ->
+    (g (n,) f32 = d(vf_loss / grad_accum)/dvpreds, metrics (4,) f32 on device = [vf_loss, vf_clipfrac, masked_mean(vpreds), sum(mask)])."""
+    for t, nm in ((vpreds, "vpreds"), (returns, "returns"), (values, "values")):
+        _chk(t, F32, nm)
+    _chk(mask, I64, "mask")
+    n = vpreds.numel()
+    g = torch.empty(n, dtype=F32, device=vpreds.device)
+    met = torch.empty(4, dtype=F32, device=vpreds.device)
+    lib().st_value_loss(_p(vpreds), _p(returns), _p(values), _p(mask), n, float(cliprange_value), float(grad_accum), _p(g), _p(met), _s())
+    return g, met
+
+
+def value_head_fwd(hn, w, bias=None):
+    """v (T,) fp32 = bf16(hn @ w + bias): the token-classification score head (nn.Linear(H, 1)) of the critic."""
+    T, H = hn.shape
+    out = torch.empty(T, dtype=F32, device=hn.device)
+    lib().st_value_head_fwd(_p(hn), hn.stride(0), _p(w), _p(bias), _p(out), T, H, _s())
+    return out
+
+
+def value_head_bwd(hn, w, dv, dw_accum, db_accum=None):
+    """dhn (T, H) bf16 = dv (x) w;  dw_accum (H,) f32 += dv^T hn;  db_accum (>= 1,) f32 [0] += sum(dv)."""
+    T, H = hn.shape
+    _chk(dv, F32, "dv")
+    dhn = torch.empty(T, H, dtype=BF16, device=hn.device)
+    lib().st_value_head_bwd(_p(hn), hn.stride(0), _p(w), _p(dv), _p(dhn), dhn.stride(0), _p(dw_accum), _p(db_accum), T, H, _s())
+    return dhn
+
+
 def grpo_advantage(rewards, mask, group, n_groups: int, eps: float = 1e-6):
     _chk(rewards, F32, "rewards"); _chk(mask, I64, "mask"); _chk(group, I32, "group")
     N, R = rewards.shape

@@ -62,11 +62,16 @@ def hf_config_dict(cfg: VLConfig, special: Dict[str, int]) -> dict:
     }
 
 
-def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7, master_fp32: bool = False) -> Tuple[VLConfig, ParamStore, Dict[str, int]]:
+def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7, master_fp32: bool = False,
+               value_head: bool = False) -> Tuple[VLConfig, ParamStore, Dict[str, int]]:
     """master_fp32: enable the fp32 master BEFORE the weights are loaded, so that an fp32 checkpoint's own values reach the master (the
-    reference keeps them: fp32 shards under MixedPrecision(param_dtype=bf16)); enabling it afterwards would start from bf16-rounded weights."""
+    reference keeps them: fp32 shards under MixedPrecision(param_dtype=bf16)); enabling it afterwards would start from bf16-rounded weights.
+    value_head: the critic's model (fsdp_workers.py:212-224 loads AutoModelForTokenClassification with num_labels = 1): the backbone with
+    score = Linear(H, 1) instead of the lm_head; a checkpoint without `score.*` gets the head HF would initialise (normal(0, 0.02), zero bias)."""
+    import dataclasses
     if model_path.startswith("random:"):
         cfg, special = synthetic_config(model_path)
+        cfg = dataclasses.replace(cfg, value_head=True) if value_head else cfg
         store = ParamStore(cfg, device=device, trainable=trainable)
         store.init_random(seed=seed)
         if master_fp32:
@@ -77,6 +82,7 @@ def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7, m
     with open(os.path.join(model_path, "config.json")) as f:
         hf = json.load(f)
     cfg = VLConfig.from_hf_dict(hf)
+    cfg = dataclasses.replace(cfg, value_head=True) if value_head else cfg
     store = ParamStore(cfg, device=device, trainable=trainable)
     if master_fp32:
         store.enable_fp32_master()
@@ -92,6 +98,10 @@ def load_model(model_path: str, trainable: bool, device="cuda", seed: int = 7, m
         elif k.startswith("model.") and not k.startswith(("model.visual.", "model.language_model.")):
             k = "model.language_model." + k[len("model."):]
         norm[k] = v
+    if value_head and "score.weight" not in norm:
+        g = torch.Generator().manual_seed(seed)
+        norm["score.weight"] = torch.randn(1, cfg.hidden_size, generator=g) * 0.02
+        norm["score.bias"] = torch.zeros(1)
     store.load_hf_state_dict(norm)
     gen = {}
     gp = os.path.join(model_path, "generation_config.json")

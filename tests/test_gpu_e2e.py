@@ -55,6 +55,36 @@ def test_main_runs_two_grpo_steps(tmp_path):
     assert f"Load from checkpoint: {ck}" in p2.stdout
 
 
+def test_main_runs_ppo_with_the_critic_adv_estimator_gae(tmp_path):
+    """algorithm.adv_estimator=gae: a second worker in the `critic` role (backbone + score head), values -> GAE -> update_critic
+    -> update_actor, the critic's checkpoint next to the actor's (ray_trainer.py:428-434, 644-675, 483-517)."""
+    cmd = [sys.executable, "-m", "verl.trainer.main", "data.train_files=synthetic:stvqa@train", "data.val_files=synthetic:stvqa@val", "data.val_batch_size=8",
+           "worker.rollout.val_override_config={'temperature': 0.5, 'n': 1}", "data.rollout_batch_size=4",
+           "data.max_prompt_length=64", "data.max_response_length=16", "worker.actor.model.model_path=random:tiny",
+           "worker.actor.global_batch_size=2", "worker.actor.micro_batch_size_per_device_for_update=4",
+           "worker.actor.micro_batch_size_per_device_for_experience=8", "worker.actor.optim.strategy=adamw_bf16", "worker.actor.fsdp.torch_dtype=bf16",
+           "worker.critic.global_batch_size=2", "worker.critic.micro_batch_size_per_device_for_update=4", "worker.critic.micro_batch_size_per_device_for_experience=8",
+           "worker.critic.optim.strategy=adamw_bf16", "worker.critic.fsdp.torch_dtype=bf16", "worker.critic.optim.lr=1.0e-5",
+           "worker.rollout.n=4", "worker.reward.score_function=spatial_sgg", "algorithm.adv_estimator=gae", "algorithm.gamma=1.0", "algorithm.lam=0.95",
+           "algorithm.use_kl_loss=false", "algorithm.kl_penalty=kl", "algorithm.kl_coef=1.0e-3", "trainer.max_steps=2",
+           "trainer.total_episodes=1", "trainer.n_gpus_per_node=1", "trainer.val_before_train=false", "trainer.logger=['console']",
+           f"trainer.save_checkpoint_path={tmp_path}/ckpt"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("step ") and "actor/pg_loss" in l]
+    assert len(lines) == 2, p.stdout[-2000:]
+    for key in ("critic/vf_loss", "critic/vf_clipfrac", "critic/vpred_mean", "critic/grad_norm", "critic/lr", "perf/mfu_critic", "timing_s/values",
+                "timing_s/update_critic", "critic/values/mean", "critic/vf_explained_var", "critic/returns/mean", "actor/pg_loss", "critic/kl"):
+        assert key in lines[-1], key
+    last = (tmp_path / "ckpt" / "latest_global_step.txt").read_text()
+    for f in ("critic/huggingface/model.safetensors", "critic/optim_world_size_1_rank_0.pt", "actor/huggingface/model.safetensors"):
+        assert os.path.exists(tmp_path / "ckpt" / f"global_step_{last}" / f), f
+    from safetensors.torch import load_file
+    sd = load_file(str(tmp_path / "ckpt" / f"global_step_{last}" / "critic" / "huggingface" / "model.safetensors"))
+    assert "score.weight" in sd and tuple(sd["score.weight"].shape) == (1, 256) and "lm_head.weight" not in sd
+
+
 def test_reference_default_dtype_pair_fp32_master_weights(tmp_path):
     """worker.actor.fsdp.torch_dtype left UNSET + optim.strategy=adamw — the reference's own defaults (fsdp_workers.py:186-189, actor/config.py:41):
     fp32 master weights and moments behind the bf16 compute copy.  Two steps through the CLI, a checkpoint that carries the master, a

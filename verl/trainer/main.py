@@ -74,7 +74,8 @@ def main():
     trainer = RayPPOTrainer(cfg, tokenizer, processor, None, None, reward_fn, reward_fn, dataset(cfg.data.train_files, True), dataset(cfg.data.val_files, False))
     role = "actor_rollout" if cfg.algorithm.disable_kl else "actor_rollout_ref"      # colocated roles (ray/base.py:453-493)
     wg = SPMDWorkerGroup(FSDPWorker(cfg.worker, role))
-    trainer.set_worker_groups(wg, wg)
+    critic_wg = SPMDWorkerGroup(FSDPWorker(cfg.worker, "critic")) if cfg.algorithm.adv_estimator == "gae" else None      # ray_trainer.py:428-434
+    trainer.set_worker_groups(wg, wg, critic_wg)
     trainer.init_workers()
     trainer.fit()
 

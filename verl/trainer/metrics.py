@@ -29,7 +29,12 @@ def compute_data_metrics(batch: DataProto, use_critic: bool = False, gather=None
     out.update(_stats("critic/score", g(b["token_level_scores"].sum(-1))))
     out.update(_stats("critic/rewards", g(b["token_level_rewards"].sum(-1))))
     out.update(_stats("critic/advantages", g(torch.masked_select(b["advantages"], resp_mask))))
-    out.update(_stats("critic/returns", g(torch.masked_select(b["returns"], resp_mask))))
+    valid_returns = g(torch.masked_select(b["returns"], resp_mask))
+    out.update(_stats("critic/returns", valid_returns))
+    if use_critic:                                             # metrics.py:46-50,69-80
+        valid_values = g(torch.masked_select(b["values"], resp_mask))
+        out.update(_stats("critic/values", valid_values))
+        out["critic/vf_explained_var"] = (1.0 - torch.var(valid_returns - valid_values) / (torch.var(valid_returns) + 1e-5)).item()
     out.update(_stats("response_length", rlen))
     out["response_length/clip_ratio"] = (rlen == R).float().mean().item()
     out.update(_stats("prompt_length", plen))

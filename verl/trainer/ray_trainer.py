@@ -144,10 +144,9 @@ class RayPPOTrainer:
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
         a = config.algorithm
-        if a.adv_estimator == "gae":
-            raise NotImplementedError("adv_estimator=gae needs the critic worker, which is outside the GRPO path (SURVEY 8f-4); "
-                                      "grpo, rloo, remax and reinforce_plus_plus are built")
         AdvantageEstimator(a.adv_estimator)
+        self.use_critic = a.adv_estimator == "gae"               # ray_trainer.py:230-233
+        self.critic_wg = None
         self.use_reference_policy = not a.disable_kl
         self.kl_ctrl = core_algos.get_kl_controller(a) if self.use_reference_policy else core_algos.FixedKLController(0.0)
         d, act = config.data, config.worker.actor
@@ -156,6 +155,12 @@ class RayPPOTrainer:
             raise ValueError("Rollout batch size must be divisible by global batch size.")
         if (d.rollout_batch_size * config.worker.rollout.n) % act.micro_batch_size_per_device_for_experience != 0:
             raise ValueError("Rollout batch size * rollout.n must be divisible by actor micro batch size for experience.")
+        if self.use_critic:                                       # ray_trainer.py:248-257
+            cr = config.worker.critic
+            if d.rollout_batch_size % cr.global_batch_size != 0:
+                raise ValueError("Rollout batch size must be divisible by critic global batch size.")
+            if (d.rollout_batch_size * config.worker.rollout.n) % cr.micro_batch_size_per_device_for_experience != 0:
+                raise ValueError("Rollout batch size * rollout.n must be divisible by critic micro batch size for experience.")
         if a.adv_estimator in ("grpo", "rloo") and config.worker.rollout.n == 1:
             raise ValueError("GRPO and RLOO algorithm need `config.worker.rollout.n > 1`.")
         if d.rollout_batch_size % self.world != 0:
@@ -177,13 +182,18 @@ class RayPPOTrainer:
         t = config.trainer
         self.training_steps = t.max_steps if t.max_steps is not None else len(self.train_dataloader) * t.total_episodes
         act.optim.training_steps = self.training_steps
+        config.worker.critic.optim.training_steps = self.training_steps
         self.global_step = 0
         self.logger = ConsoleTracker(t.logger)
 
-    def set_worker_groups(self, actor_rollout_wg, ref_policy_wg):
-        self.actor_rollout_wg, self.ref_policy_wg = actor_rollout_wg, ref_policy_wg
+    def set_worker_groups(self, actor_rollout_wg, ref_policy_wg, critic_wg=None):
+        self.actor_rollout_wg, self.ref_policy_wg, self.critic_wg = actor_rollout_wg, ref_policy_wg, critic_wg
+        if self.use_critic and critic_wg is None:
+            raise ValueError("adv_estimator=gae needs a critic worker group (FSDPWorker(config.worker, 'critic'))")
 
     def init_workers(self):
+        if self.use_critic:                                       # ray_trainer.py:467-469: the critic first
+            self.critic_wg.init_model()
         if self.use_reference_policy and self.ref_policy_wg is not self.actor_rollout_wg:
             self.ref_policy_wg.init_model()
         self.actor_rollout_wg.init_model()
@@ -321,6 +331,9 @@ class RayPPOTrainer:
         path = os.path.join(root, f"global_step_{self.global_step}")
         os.makedirs(os.path.join(path, "actor"), exist_ok=True)
         self.actor_rollout_wg.save_checkpoint(os.path.join(path, "actor"))
+        if self.use_critic:
+            os.makedirs(os.path.join(path, "critic"), exist_ok=True)
+            self.critic_wg.save_checkpoint(os.path.join(path, "critic"))
         if self.rank == 0:
             # dataloader.pt holds the loader's bare state_dict, as the reference writes it (ray_trainer.py:498-500); the adaptive KL
             # coefficient (driver state the reference loses on resume) rides along as one extra key
@@ -338,6 +351,8 @@ class RayPPOTrainer:
         print(f"Load from checkpoint: {p}.")
         self.global_step = int(p.strip(os.path.sep).split("global_step_")[-1])
         self.actor_rollout_wg.load_checkpoint(os.path.join(p, "actor"))
+        if self.use_critic:
+            self.critic_wg.load_checkpoint(os.path.join(p, "critic"))
         dl = os.path.join(p, "dataloader.pt")
         if os.path.exists(dl):
             try:
@@ -409,6 +424,9 @@ class RayPPOTrainer:
                     if self.use_reference_policy:
                         with _timer("ref", timing_raw):
                             batch = batch.union(self.ref_policy_wg.compute_ref_log_probs(batch))
+                    if self.use_critic:                                   # ray_trainer.py:644-648
+                        with _timer("values", timing_raw):
+                            batch = batch.union(self.critic_wg.compute_values(batch))
                     with _timer("adv", timing_raw):
                         if not cfg.algorithm.use_kl_loss and self.use_reference_policy:
                             batch, kl_metrics = apply_kl_penalty(batch, self.kl_ctrl, cfg.algorithm.kl_penalty, gather=self._gather_list)
@@ -426,6 +444,10 @@ class RayPPOTrainer:
                             batch = compute_advantage(batch, est, cfg.algorithm.gamma, cfg.algorithm.lam)
                     if pending_order is not None:                         # mini-batch balance: only update_actor's split depends on it
                         batch.reorder(pending_order)
+                    if self.use_critic:                                   # ray_trainer.py:669-675
+                        with _timer("update_critic", timing_raw):
+                            critic_out = self.critic_wg.update_critic(batch)
+                        metrics.update(reduce_metrics(self._gather_metric_lists(critic_out.non_tensor_batch)))
                     if cfg.trainer.critic_warmup <= self.global_step:
                         with _timer("update_actor", timing_raw):
                             actor_out = self.actor_rollout_wg.update_actor(batch)
@@ -439,7 +461,7 @@ class RayPPOTrainer:
                             self._save_checkpoint()
                 # the driver's view (ray_trainer.py:697-703): data metrics over every rank's rows, the slowest rank's phase times,
                 # the token count over all GPUs
-                metrics.update(compute_data_metrics(batch, gather=self._gather_list))
+                metrics.update(compute_data_metrics(batch, use_critic=self.use_critic, gather=self._gather_list))
                 timing_all = self._gather(timing_raw)
                 timing_max = {k: max(t[k] for t in timing_all if k in t) for k in timing_raw}
                 batch.meta_info["global_token_num"] = self._gather_list(batch.meta_info["global_token_num"])

@@ -18,7 +18,7 @@ import psutil
 import torch
 import torch.distributed as dist
 
-from spatialthinker_amd.actor import ActorHyper, PolicyEngine
+from spatialthinker_amd.actor import ActorHyper, CriticEngine, PolicyEngine
 from spatialthinker_amd.pretrained import load_model, save_hf
 from spatialthinker_amd.rollout import Generator
 
@@ -42,8 +42,7 @@ class FSDPWorker:
         self._is_actor = role in ("actor", "actor_rollout", "actor_rollout_ref")
         self._is_rollout = role in ("rollout", "actor_rollout", "actor_rollout_ref")
         self._is_ref = role in ("ref", "actor_rollout_ref")
-        if role == "critic":
-            raise NotImplementedError("the critic is only used by adv_estimator=gae, outside the GRPO path")
+        self._is_critic = role == "critic"
         # options of the reference this engine does not implement are rejected, never silently ignored
         if int(getattr(self.config.actor, "ulysses_sequence_parallel_size", 1)) > 1:
             raise NotImplementedError(
@@ -55,6 +54,10 @@ class FSDPWorker:
                   "dp_actor.py:86-138; the log-probs are the same function of the same tokens, only the padded rows are never computed", flush=True)
         if self._is_actor:
             self._init_batch_sizes(self.config.actor)
+        if self._is_critic:
+            if int(getattr(self.config.critic, "ulysses_sequence_parallel_size", 1)) > 1:
+                raise NotImplementedError("worker.critic.ulysses_sequence_parallel_size > 1: Ulysses sequence parallelism is not built — set it to 1")
+            self._init_batch_sizes(self.config.critic)
 
     def _init_batch_sizes(self, cfg):
         """fsdp_workers.py:130-147: global batch is counted in rollouts, then split over the ranks."""
@@ -73,9 +76,39 @@ class FSDPWorker:
     # ------------------------------------------------------------------------------------------------
     @register(dispatch_mode=Dispatch.ONE_TO_ALL)
     def init_model(self):
-        mc = self.config.actor.model
+        mc = self.config.critic.model if self._is_critic else self.config.actor.model
+        if self._is_critic and not mc.model_path:               # the shipped configs leave worker.critic.model empty: the actor's backbone
+            mc = self.config.actor.model
         self.tokenizer = get_tokenizer(mc.tokenizer_path or mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
         self.processor = get_processor(mc.tokenizer_path or mc.model_path, trust_remote_code=mc.trust_remote_code, use_fast=True)
+        if self._is_critic:
+            # fsdp_workers.py:212-224 builds AutoModelForTokenClassification(num_labels = 1) — a mapping transformers does not have for
+            # qwen2_5_vl, so the reference cannot construct this model; here the same backbone carries a score = Linear(H, 1) head
+            cr = self.config.critic
+            if cr.optim.strategy not in ("adamw_bf16", "adamw"):
+                raise NotImplementedError(f"Optimizer {cr.optim.strategy} not supported.")
+            dt = (cr.fsdp.torch_dtype or "fp32").lower()
+            master = dt not in ("bf16", "bfloat16")
+            if master and cr.optim.strategy != "adamw":
+                raise NotImplementedError("worker.critic.fsdp.torch_dtype=fp32 needs optim.strategy=adamw (fp32 master weights); "
+                                          "adamw_bf16 goes with torch_dtype=bf16")
+            cfg, store, special = load_model(mc.model_path, trainable=True, master_fp32=master, value_head=True)
+            hyper = ActorHyper(micro_batch_size_per_device_for_update=cr.micro_batch_size_per_device_for_update,
+                               micro_batch_size_per_device_for_experience=cr.micro_batch_size_per_device_for_experience,
+                               global_batch_size_per_device=cr.global_batch_size_per_device, max_grad_norm=cr.max_grad_norm,
+                               ppo_epochs=cr.ppo_epochs, lr=cr.optim.lr, betas=tuple(cr.optim.betas), weight_decay=cr.optim.weight_decay,
+                               lr_warmup_steps=int(cr.optim.lr_warmup_ratio * max(cr.optim.training_steps, 0)), optim_strategy=cr.optim.strategy,
+                               freeze_vision_tower=bool(mc.freeze_vision_tower), cliprange_value=cr.cliprange_value,
+                               grad_exchange_dtype="bf16" if str(cr.fsdp.mp_reduce_dtype).lower() in ("bf16", "bfloat16") else "fp32")
+            self.model_config, self.special = cfg, special
+            self.critic = self.actor = CriticEngine(cfg, store, hyper)      # (save / load_checkpoint address the trainable engine as self.actor)
+            self.flops_counter = FlopsCounter(cfg)
+            if self.world_size > 1:
+                dist.broadcast(store.flat, src=0)
+                if store.master is not None:
+                    dist.broadcast(store.master, src=0)
+                store.refresh_transposes()
+            return
         if self._is_actor:
             a = self.config.actor
             if a.optim.strategy not in ("adamw_bf16", "adamw"):
@@ -206,13 +239,31 @@ class FSDPWorker:
         metrics["perf/cpu_memory_used_gb"] = psutil.virtual_memory().used / (1024 ** 3)
         return DataProto(non_tensor_batch={k: np.array([v] if np.isscalar(v) else v) for k, v in metrics.items()})
 
+    @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+    def compute_values(self, data: DataProto) -> DataProto:
+        """fsdp_workers.py:558-575."""
+        assert self._is_critic
+        v = self.critic.compute_values(self._as_dict(data)).cpu()
+        return DataProto.from_dict(tensors={"values": v})
+
+    @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+    def update_critic(self, data: DataProto) -> DataProto:
+        """fsdp_workers.py:577-616."""
+        assert self._is_critic
+        t0 = time.perf_counter()
+        metrics = self.critic.update_critic(self._as_dict(data))
+        torch.cuda.synchronize()
+        est, promised = self.flops_counter.estimate_flops(data.meta_info["global_token_num"], time.perf_counter() - t0)
+        metrics["perf/mfu_critic"] = est * self.config.actor.ppo_epochs / promised          # (the reference multiplies by the ACTOR's epochs, :594-596)
+        return DataProto(non_tensor_batch={k: np.array([v] if np.isscalar(v) else v) for k, v in metrics.items()})
+
     # ------------------------------------------------------------------------------------------------
     @register(dispatch_mode=Dispatch.ONE_TO_ALL)
     def save_checkpoint(self, path: str):
         """Replicas are identical, so rank 0 writes ONE HF-loadable directory (weights + config + generation config + tokenizer /
         processor files, as fsdp_checkpoint_manager.py:96-131 puts under actor/huggingface) and ONE optimizer / scheduler / RNG-
         position file (the reference writes a shard per rank: model_world_size_W_rank_r.pt etc., :52-95)."""
-        assert self._is_actor
+        assert self._is_actor or self._is_critic
         if self.rank == 0:
             st = self.actor.store
             save_hf(st, os.path.join(path, "huggingface"), tokenizer=getattr(self, "tokenizer", None), processor=getattr(self, "processor", None))

@@ -443,6 +443,38 @@ def gen_model():
          hidden_last_token=np.stack(hid), **taps)
 
 
+def gen_values():
+    """The critic's values (dp_critic.py:52-125) from HF itself: the tiny Qwen2.5-VL backbone's last hidden state (after the final norm, what
+    a *ForTokenClassification model feeds its head — e.g. Qwen2ForTokenClassification.forward: `logits = self.score(dropout(sequence_output))`)
+    through a torch.nn.Linear(H, 1) with fixed weights, scattered back to (B, S) and sliced [:, -R-1:-1].  transformers has no
+    token-classification class for qwen2_5_vl (the reference's AutoModelForTokenClassification call fails for this family), so the head is
+    applied here by hand exactly as those classes do.  Pins oracle.qwen25vl.response_values."""
+    c = tiny.TINY
+    model = _hf_tiny_model()
+    z = np.load(os.path.join(HERE, "model_tiny.npz"))
+    batch = tiny.make_batch(c)
+    ids, mask, P, R, pos = batch["input_ids"], batch["attention_mask"], batch["P"], batch["R"], z["position_ids"]
+    rs = np.random.RandomState(5)
+    score = torch.nn.Linear(c["hidden_size"], 1)
+    w = torch.from_numpy((rs.standard_normal((1, c["hidden_size"])) * 0.05).astype(np.float32)).bfloat16().float()
+    with torch.no_grad():
+        score.weight.copy_(w); score.bias.fill_(0.125)
+    vals, off = [], 0
+    for b in range(ids.shape[0]):
+        sel = mask[b] == 1
+        n_patch = int(batch["patch_counts"][b])
+        px = torch.from_numpy(batch["pixel_values"][off:off + n_patch])
+        off += n_patch
+        with torch.no_grad():
+            o = model(input_ids=torch.from_numpy(ids[b][sel])[None], attention_mask=None, position_ids=torch.from_numpy(pos[b][:, sel])[:, None, :],
+                      pixel_values=px, image_grid_thw=torch.from_numpy(batch["image_grid_thw"][b:b + 1]), use_cache=False, output_hidden_states=True)
+            v = score(o.hidden_states[-1][0])[:, 0]
+        full = np.zeros(P + R, dtype=np.float32)
+        full[sel] = v.numpy()
+        vals.append(full[-R - 1:-1])
+    save("values_tiny", score_weight=w.numpy(), score_bias=np.asarray([0.125], dtype=np.float32), values=np.stack(vals))
+
+
 # ------------------------------------------------------------------ 6. trainer-side RL math outside the GRPO kernel + rollout post-processing
 def gen_rl_extra():
     """apply_kl_penalty's pieces + KL controllers, the non-GRPO estimators, the value loss, FlopsCounter and the rollout
@@ -694,7 +726,7 @@ def gen_update_loop():
     save("update_loop", **out)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset", "generate", "loop"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "model", "extra", "dataset", "generate", "loop", "values"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -713,3 +745,5 @@ if __name__ == "__main__":
         gen_generate()
     if "loop" in which:
         gen_update_loop()
+    if "values" in which:
+        gen_values()

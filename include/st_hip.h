@@ -299,6 +299,10 @@ int st_mxfp8_quantize(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, ui
  * st_gemm_mxfp8_nt_f32: out[M,N] (fp32) = or += dequant(A)[M,K] dequant(B)[N,K]^T on the 4-wave tile. */
 int st_mxfp8_quantize_t(const st_bf16* x, int64_t ldx, uint8_t* qT, int64_t ldq, uint32_t* scales, int64_t scale_rows, int R, int C,
                         st_stream_t stream);
+/* st_mxfp8_quantize + st_mxfp8_quantize_t of the same x in ONE pass over it (a gradient that feeds both an fp8 input-gradient and an fp8
+ * weight-gradient GEMM): q / scales as st_mxfp8_quantize, qT / scales_t as st_mxfp8_quantize_t, bit for bit.  R % 128 == 0, C % 128 == 0. */
+int st_mxfp8_quantize_both(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, uint8_t* qT, int64_t ldqT,
+                           uint32_t* scales_t, int64_t scale_t_rows, int R, int C, st_stream_t stream);
 int st_gemm_mxfp8_nt_f32(const uint8_t* A, int64_t lda, const uint32_t* SA, int64_t sa_rows, const uint8_t* B, int64_t ldb,
                          const uint32_t* SB, int64_t sb_rows, float* out, int64_t ldc, int accumulate, int M, int N, int K, st_stream_t stream);
 int st_gemm_mxfp8_select(int waves);

@@ -51,13 +51,19 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_kernel(const uint16_t* __r
 // through LDS, then thread (column c = t & 63, block j = t >> 6) owns one whole MX block — no cross-lane reduction — and writes its 32 bytes.
 // (A 128 x 128 tile with two columns per thread — one LDS dword per row — measured 20 % SLOWER in the bench: 33 KiB of LDS and 64 live
 // values per thread cost more occupancy than the halved LDS instruction count buys.)
+// BOTH: the same pass also writes the ordinary (row-wise) quantisation q / srow of x — a gradient that feeds an fp8 input-gradient GEMM
+// (MX blocks along its features) AND an fp8 weight-gradient GEMM (blocks along the tokens) is read once; a thread quantises the 32
+// columns it has just loaded (one whole MX block) from its registers.  Needs C % 32 == 0 for that part (C % 128 == 0 at the call sites).
+template <bool BOTH>
 __global__ __launch_bounds__(256) void mxfp8_quantize_t_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ qT, int64_t ldq,
-                                                              uint32_t* __restrict__ scales, int64_t scale_rows, int R, int C) {
+                                                              uint32_t* __restrict__ scales, int64_t scale_rows, int R, int C,
+                                                              uint8_t* __restrict__ qrow, int64_t ldqr, uint32_t* __restrict__ srow, int64_t srow_rows) {
     __shared__ uint16_t tile[128][64 + 2];                    // +2: rows 132 bytes apart; a wave's column reads (64 consecutive columns of one row) are conflict-free
     const int t = threadIdx.x;
     const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 64;
     {
         const int row = t >> 1, cb = (t & 1) * 32;
+        float fr[32];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + cb + k * 8;
@@ -65,6 +71,37 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_t_kernel(const uint16_t* _
             if (c < C) v = *reinterpret_cast<const uint4*>(x + (int64_t)(r0 + row) * ldx + c);       // C % 8 == 0: all-in or all-out
             uint32_t* d = reinterpret_cast<uint32_t*>(&tile[row][cb + k * 8]);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if constexpr (BOTH) {
+                float f8[8];
+                unpack8(v, f8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fr[k * 8 + i] = f8[i];
+            }
+        }
+        if constexpr (BOTH) {
+            if (c0 + cb < C) {                                    // C % 32 == 0: the thread's 32 columns are one whole MX block
+                float amax = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(fr[i]));
+                int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+                e = e < 0 ? 0 : (e > 254 ? 254 : e);
+                const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+                uint32_t w[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    float v4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v4[i] = fminf(fmaxf(fr[4 * h + i] * inv, -448.f), 448.f);
+                    int packed = __builtin_amdgcn_cvt_pk_fp8_f32(v4[0], v4[1], 0, false);
+                    packed = __builtin_amdgcn_cvt_pk_fp8_f32(v4[2], v4[3], packed, true);
+                    w[h] = (uint32_t)packed;
+                }
+                uint4* dst = reinterpret_cast<uint4*>(qrow + (int64_t)(r0 + row) * ldqr + c0 + cb);
+                dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                const int col = c0 + cb;
+                reinterpret_cast<uint8_t*>(srow + (int64_t)(col >> 7) * srow_rows + r0 + row)[(col >> 5) & 3] = (uint8_t)e;
+            }
         }
     }
     __syncthreads();
@@ -257,8 +294,19 @@ int st_mxfp8_quantize_t(const st_bf16* x, int64_t ldx, uint8_t* qT, int64_t ldq,
     if (!x || !qT || !scales || R <= 0 || C <= 0 || (R % 128) || (C & 7) || (ldx & 7) || (ldq & 15) || ldx < C || ldq < R || scale_rows < C ||
         (((uintptr_t)x) & 15) || (((uintptr_t)qT) & 15))
         return ST_EINVAL;
-    hipLaunchKernelGGL(mxfp8_quantize_t_kernel, dim3(st_cdiv(C, 64), R / 128), dim3(256), 0, (hipStream_t)stream, x, ldx, qT, ldq, scales,
-                       scale_rows, R, C);
+    hipLaunchKernelGGL(mxfp8_quantize_t_kernel<false>, dim3(st_cdiv(C, 64), R / 128), dim3(256), 0, (hipStream_t)stream, x, ldx, qT, ldq, scales,
+                       scale_rows, R, C, (uint8_t*)nullptr, (int64_t)0, (uint32_t*)nullptr, (int64_t)0);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+int st_mxfp8_quantize_both(const st_bf16* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows, uint8_t* qT, int64_t ldqT,
+                           uint32_t* scales_t, int64_t scale_t_rows, int R, int C, st_stream_t stream) {
+    if (!x || !q || !scales || !qT || !scales_t || R <= 0 || C <= 0 || (R % 128) || (C % 128) || (ldx & 7) || (ldq & 15) || (ldqT & 15) || ldx < C ||
+        ldq < C || ldqT < R || scale_rows < R || scale_t_rows < C || (((uintptr_t)x) & 15) || (((uintptr_t)q) & 15) || (((uintptr_t)qT) & 15))
+        return ST_EINVAL;
+    hipLaunchKernelGGL(mxfp8_quantize_t_kernel<true>, dim3(st_cdiv(C, 64), R / 128), dim3(256), 0, (hipStream_t)stream, x, ldx, qT, ldqT, scales_t,
+                       scale_t_rows, R, C, q, ldq, scales, scale_rows);
     ST_CHECK_LAUNCH();
     return 0;
 }

@@ -406,13 +406,22 @@ class Qwen25VL:
             self.p.wq = None
             self.p.wqt = None
 
-    def _dgrad(self, dy, name):
-        """dX = dY W for an LM projection: bf16 (W read as stored, contraction-major) or MX-fp8 against the transposed fp8 copy."""
+    def _dgrad(self, dy, name, dyq=None):
+        """dX = dY W for an LM projection: bf16 (W read as stored, contraction-major) or MX-fp8 against the transposed fp8 copy
+        (dyq: dY's row-wise MX-fp8 operand when _quantize_grad already made it)."""
         if self.fp8_dgrad and dy.shape[0] > 256 and dy.shape[1] % 128 == 0:
-            dq, ds = ops.mxfp8_quantize(dy)
+            dq, ds = dyq if dyq is not None else ops.mxfp8_quantize(dy)
             wq, ws = self.p.wqt[name]
             return ops.gemm_mxfp8_nt(dq, ds, wq, ws)
         return ops.gemm_nn(dy, self.p.w[name])
+
+    def _quantize_grad(self, dy):
+        """A projection's output gradient feeds its input-gradient GEMM (MX blocks along the features) and its weight-gradient GEMM (blocks
+        along the tokens): with both in fp8 the two operands come out of ONE pass over dY.  Returns (row-wise operand, token-minor operand)
+        or (None, None) when the shapes / modes do not call for it."""
+        if self.fp8_dgrad and self.fp8_wgrad and dy.shape[0] > 256 and dy.shape[0] % 128 == 0 and dy.shape[1] % 128 == 0:
+            return ops.mxfp8_quantize_both(dy)
+        return None, None
 
     def _linear(self, x, name, bias=None, residual=None, xq=None):
         """y = x W^T (+bias)(+residual) for an LM projection: bf16 MFMA GEMM, or MX-fp8 when enabled and the shape fits its tile
@@ -597,12 +606,12 @@ class Qwen25VL:
         self._dw(g["v.patch_embed"], dx, pxw, None)
 
     # ---------------------------------------------------------------- helpers
-    def _dw(self, gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gb: Optional[torch.Tensor], fp8: bool = False):
+    def _dw(self, gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, gb: Optional[torch.Tensor], fp8: bool = False, dyt=None):
         """gw (N,K) fp32 += dy(M,N)^T x(M,K); gb (N,) += column sums of dy.  M is a multiple of 64 (padded rows are zero).
         fp8 (enable_fp8(wgrad=True), LM projections): both operands quantised token-minor on the fly (st_mxfp8_quantize_t: MX blocks of 32
         consecutive packed tokens), the product on the 4-wave fp8 tile accumulating into the fp32 gradient."""
         if fp8 and dy.shape[0] > 256 and dy.shape[0] % 128 == 0:
-            dq, ds = ops.mxfp8_quantize_t(dy)
+            dq, ds = dyt if dyt is not None else ops.mxfp8_quantize_t(dy)
             xq, xs = ops.mxfp8_quantize_t(x)
             ops.gemm_mxfp8_nt_f32(dq, ds, xq, xs, gw, accumulate=True)
         elif ops.layout_gemm_ok(dy.shape[1], x.shape[1], dy.shape[0]):
@@ -686,26 +695,30 @@ class Qwen25VL:
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
         x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved
-        dm = self._dgrad(dx2, p + "down_w")
+        q2, t2 = self._quantize_grad(dx2)
+        dm = self._dgrad(dx2, p + "down_w", dyq=q2)
         if m is None:                                       # recompute the light activations (see _lm_layer_fwd): m in the pass that
             dgu, m = ops.swiglu_bwd(gu, dm, want_m=True)    # forms dgu from the same gate | up values (bit-identical to swiglu_fwd)
             h2, _ = ops.rmsnorm_fwd(x1, w[p + "post_norm"], c.rms_eps, want_rstd=False)
             h1, _ = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps, want_rstd=False)
         else:
             dgu = ops.swiglu_bwd(gu, dm)
-        self._dw(g[p + "down_w"], dx2, m, None, fp8=self.fp8_wgrad)
-        self._dw(g[p + "gu_w"], dgu, h2, None, fp8=self.fp8_wgrad)
-        dh2 = self._dgrad(dgu, p + "gu_w")
+        self._dw(g[p + "down_w"], dx2, m, None, fp8=self.fp8_wgrad, dyt=t2)
+        qg, tg = self._quantize_grad(dgu)
+        self._dw(g[p + "gu_w"], dgu, h2, None, fp8=self.fp8_wgrad, dyt=tg)
+        dh2 = self._dgrad(dgu, p + "gu_w", dyq=qg)
         dx1 = ops.rmsnorm_bwd(x1, w[p + "post_norm"], r2, dh2, dres=dx2, dw_accum=g[p + "post_norm"])
-        self._dw(g[p + "o_w"], dx1, a, None, fp8=self.fp8_wgrad)
-        da = self._dgrad(dx1, p + "o_w")
+        q1, t1 = self._quantize_grad(dx1)
+        self._dw(g[p + "o_w"], dx1, a, None, fp8=self.fp8_wgrad, dyt=t1)
+        da = self._dgrad(dx1, p + "o_w", dyq=q1)
         dqkv = torch.zeros_like(qkv)
         q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
         ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
                          self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
         ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
-        self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"], fp8=self.fp8_wgrad)
-        dh1 = self._dgrad(dqkv, p + "qkv_w")
+        qq, tq = self._quantize_grad(dqkv)
+        self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"], fp8=self.fp8_wgrad, dyt=tq)
+        dh1 = self._dgrad(dqkv, p + "qkv_w", dyq=qq)
         return ops.rmsnorm_bwd(x0, w[p + "in_norm"], r1, dh1, dres=dx1, dw_accum=g[p + "in_norm"])
 
     def _head_fwd(self, x: torch.Tensor, b: DeviceBatch, temperature: float):

@@ -429,6 +429,17 @@ def mxfp8_quantize_t(x):
     return qT, sc
 
 
+def mxfp8_quantize_both(x):
+    """((q, scales), (qT, scales_t)) = (mxfp8_quantize(x), mxfp8_quantize_t(x)) in one pass over x (R % 128 == 0, C % 128 == 0)."""
+    _chk(x, BF16, "x")
+    R, C = x.shape
+    q, sc = _mx_buffers(R, C, x.device)
+    qT = torch.empty(C, R, dtype=torch.uint8, device=x.device)
+    sct = torch.zeros(R // 128, (C + 3) // 4 * 4, dtype=torch.int32, device=x.device)
+    lib().st_mxfp8_quantize_both(_p(x), x.stride(0), _p(q), q.stride(0), _p(sc), sc.shape[1], _p(qT), qT.stride(0), _p(sct), sct.shape[1], R, C, _s())
+    return (q, sc), (qT, sct)
+
+
 def gemm_mxfp8_nt_f32(aq, sa, bq, sb, out_f32, accumulate=False):
     """out_f32[M,N] = or += dequant(aq, sa) @ dequant(bq, sb)^T (fp32 result: the weight gradients)."""
     M, K = aq.shape

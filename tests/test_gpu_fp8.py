@@ -114,6 +114,19 @@ def test_transposing_quantiser_matches_quantiser_of_the_transpose(ops, shape):
     assert torch.equal(got[1][:, :C], want[1][:, :C])
 
 
+@pytest.mark.parametrize("shape", [(128, 128), (384, 256), (1024, 3584), (256, 37888)])
+def test_one_pass_quantiser_for_both_gradient_gemms(ops, shape):
+    R, C = shape
+    rs = np.random.RandomState(R + C + 1)
+    x = _bf(rs.standard_normal((R, C)) * np.exp(rs.uniform(-6, 4, (R, 1))) * np.exp(rs.uniform(-2, 2, (1, C)))).cuda()
+    x[R // 2, :32] = 0
+    (q, s), (qt, st) = ops.mxfp8_quantize_both(x)
+    wq, ws = ops.mxfp8_quantize(x)
+    wt, wts = ops.mxfp8_quantize_t(x)
+    assert torch.equal(q, wq) and torch.equal(s[:, :R], ws[:, :R])
+    assert torch.equal(qt, wt) and torch.equal(st[:, :C], wts[:, :C])
+
+
 @pytest.mark.parametrize("shape", [(256, 256, 128), (300, 520, 384), (3584, 4608, 2048)])
 def test_fp32_accumulating_gemm_of_the_fp8_tile(ops, shape):
     """st_gemm_mxfp8_nt_f32 (the weight-gradient form: fp32 result, = or +=) against the fp32 product of the de-quantised operands."""

@@ -416,3 +416,58 @@ def test_ragged_last_batch_is_padded_cyclically_to_the_world_size(rows, world):
     flat = [x for sh in shards for x in sh]
     want = (list(range(rows)) * (len(flat) // rows + 1))[:len(flat)]
     assert flat == want
+
+
+# ------------------------------------------------------------------------------------------------ adv_estimator = gae (critic)
+class StubCriticGroup(StubWorkerGroup):
+    """values = 0.1 * (response slot index + 1) on valid slots; update_critic records the batch it was handed."""
+
+    def __init__(self):
+        super().__init__()
+        self.inits, self.value_calls, self.critic_updates = 0, 0, []
+
+    def init_model(self):
+        self.inits += 1
+
+    def compute_values(self, data):
+        self.value_calls += 1
+        m = data.batch["response_mask"].float()
+        v = 0.1 * torch.arange(1, m.shape[1] + 1, dtype=torch.float32)[None, :] * m
+        return DataProto.from_dict({"values": v})
+
+    def update_critic(self, data):
+        self.critic_updates.append(data)
+        return DataProto(non_tensor_batch={"critic/vf_loss": np.array([0.25, 0.75]), "critic/grad_norm": np.array([1.5])})
+
+
+def test_gae_runs_values_advantages_critic_update_then_actor_update(tmp_path, capsys):
+    """ray_trainer.py:230-233, 248-257, 428-434, 644-675, 483-517: with adv_estimator=gae the step is gen -> reward -> old (-> ref) -> values
+    -> GAE (core_algos.compute_gae_advantage_return on the critic's values) -> update_critic -> update_actor, the critic is initialised
+    first and checkpointed next to the actor; without a critic worker group the trainer refuses to start."""
+    from verl.trainer import core_algos
+    extra = ["algorithm.adv_estimator=gae", "algorithm.gamma=1.0", "algorithm.lam=0.9", "algorithm.disable_kl=true", "worker.critic.global_batch_size=2",
+             "worker.critic.micro_batch_size_per_device_for_update=2", "worker.critic.micro_batch_size_per_device_for_experience=2", "trainer.max_steps=2",
+             "trainer.save_freq=1"]
+    tr, wg, cfg = make_trainer(tmp_path, extra=extra)
+    assert tr.use_critic and cfg.worker.critic.optim.training_steps == tr.training_steps
+    with pytest.raises(ValueError, match="critic worker group"):
+        tr.set_worker_groups(wg, wg)
+    cg = StubCriticGroup(); cg.n = wg.n
+    tr.set_worker_groups(wg, wg, cg)
+    tr.init_workers()
+    assert cg.inits == 1
+    tr.fit()
+    out = capsys.readouterr().out
+    assert cg.value_calls == 2 and len(cg.critic_updates) == 2 and len(wg.updates) == 2
+    b = cg.critic_updates[-1]
+    assert {"values", "returns", "advantages", "token_level_rewards"} <= set(b.batch.keys())
+    adv, ret = core_algos.compute_gae_advantage_return(b.batch["token_level_rewards"], b.batch["values"], b.batch["response_mask"], 1.0, 0.9)
+    assert torch.allclose(b.batch["returns"], ret) and torch.allclose(b.batch["advantages"], adv)
+    assert torch.equal(wg.updates[-1].batch["advantages"], b.batch["advantages"])            # the actor trains on the same advantages
+    step = [l for l in out.splitlines() if l.startswith("step 2:")][0]
+    for key in ("critic/vf_loss:0.5", "critic/grad_norm:1.5", "critic/values/mean", "critic/vf_explained_var", "timing_s/values", "timing_s/update_critic"):
+        assert key in step, (key, step)
+    assert any(p.endswith(os.path.join("global_step_2", "critic")) for p in cg.saved) and any(p.endswith(os.path.join("global_step_2", "actor")) for p in wg.saved)
+    # batch-size validation of the critic's config (ray_trainer.py:248-257)
+    with pytest.raises(ValueError, match="critic global batch size"):
+        make_trainer(tmp_path, extra=extra + ["worker.critic.global_batch_size=3"])

@@ -143,6 +143,11 @@ class Generator:
         check of PolicyEngine.compute_log_prob(use_rollout_log_probs=True)."""
         m, c, w = self.m, self.m.cfg, self.m.p.w
         dev = self.m.p.device
+        dbg_t = []
+        def mark(what):                                        # ST_GEN_DEBUG: host wall-clock of the sections of a call
+            if os.environ.get("ST_GEN_DEBUG"):
+                torch.cuda.synchronize(); dbg_t.append((what, time.perf_counter()))
+        mark("entry")
         ids_np, mask_np, pos_np = (np.asarray(x.cpu() if torch.is_tensor(x) else x) for x in (input_ids, attention_mask, position_ids))
         nb, P = ids_np.shape
         if pos_np.ndim == 2:
@@ -158,6 +163,7 @@ class Generator:
         kp = torch.empty(L, Tp + 128, width, dtype=BF16, device=dev)
         vp = torch.empty(L, Tp + 128, width, dtype=BF16, device=dev)
         last_h = torch.empty(nb, c.hidden_size, dtype=BF16, device=dev)
+        mark("prompt K/V buffers")
         ev_p0, ev_p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev_p0.record()
         i0 = 0
@@ -182,6 +188,7 @@ class Generator:
             ops.rows_gather(x, rows, out=last_h[i0:i1])
             i0 = i1
         ev_p1.record()
+        mark("prefill (host staging + forward)")
         head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
         # ---------------- decode state (per SAMPLE, global over the phases below)
         rep = torch.arange(nb, device=dev, dtype=I32).repeat_interleave(n)
@@ -216,6 +223,8 @@ class Generator:
             """Decode the samples S_np (sorted ids; they may sit at different response indices) until none is live or — with
             until_half — at most half of the phase's rows are (finished rows would otherwise keep occupying the GEMM tiles; the
             caller re-batches the survivors, possibly together with those of other waves).  Returns the surviving ids."""
+            if debug:
+                torch.cuda.synchronize(); t_ph = [time.perf_counter()]
             Ba = len(S_np)
             Bp = ix.round_up(Ba, 32) if Ba <= 256 else ix.round_up(Ba, 128)
             fused = can_fuse and Bp <= ops.DECODE_MAX_ROWS
@@ -358,13 +367,19 @@ class Generator:
 
             # the decode iteration is launch-bound (~10 launches x layers): capture it once per phase into a hipGraph and replay
             graph, done = None, 0
+            if debug:
+                torch.cuda.synchronize(); t_ph.append(time.perf_counter())
             if use_graph:
                 iteration()                                        # eager warm-up iteration
                 torch.cuda.synchronize()
+                if debug:
+                    t_ph.append(time.perf_counter())
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     iteration()
                 done = 1                                           # capture itself does not execute
+            if debug:
+                torch.cuda.synchronize(); t_ph.append(time.perf_counter())
             n_live = Ba
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             len0 = gen_len.sum()
@@ -381,6 +396,10 @@ class Generator:
                     iteration()
                 done += 1
             ev1.record()
+            if debug:
+                torch.cuda.synchronize(); t_ph.append(time.perf_counter())
+                print(f"[gen]   phase of {Ba} rows: setup {1e3 * (t_ph[1] - t_ph[0]):.1f} ms, eager iteration {1e3 * (t_ph[2] - t_ph[1]):.1f} ms, "
+                      f"capture + instantiate {1e3 * (t_ph[3] - t_ph[2]):.1f} ms, replay loop {1e3 * (t_ph[4] - t_ph[3]):.1f} ms wall for {done - done0} iterations", flush=True)
             steps = done - done0
             if steps > 0:
                 kv_row = 2 * width * 2 * L                                   # K and V bytes of one cached position over all layers
@@ -418,6 +437,7 @@ class Generator:
                 torch.cuda.synchronize()
                 print(f"[gen] phase rows={len(S)} -> survivors={len(r)} in {time.perf_counter() - t0:.3f}s", flush=True)
             return r
+        mark("decode state (K/V buffers of the samples, first logits)")
         for s0 in range(0, B, wave):
             S = np.arange(s0, min(B, s0 + wave), dtype=np.int64)
             pool = np.concatenate([pool, run(S, compact)])
@@ -425,6 +445,9 @@ class Generator:
             S, pool = np.sort(pool[:wave]), pool[wave:]
             pool = np.concatenate([pool, run(S, len(S) > 32)])
         torch.cuda.synchronize()
+        mark("decode phases")
+        if dbg_t:
+            print("[gen] sections: " + ", ".join(f"{w_} {1e3 * (t_ - dbg_t[i_][1]):.0f} ms" for i_, (w_, t_) in enumerate(dbg_t[1:])), flush=True)
         self.stats["prefill_s"] += ev_p0.elapsed_time(ev_p1) * 1e-3
         self.stats["phases"] += len(self._timers)
         for ev0, ev1, steps, nbytes, rows, flops in self._timers:

@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .model import F32, I64, ParamStore, Qwen25VL, VLConfig
+from .model import F32, I64, ParamStore, Qwen25VL, VLConfig, pixels_on_device
 
 
 @dataclass
@@ -339,7 +339,7 @@ class PolicyEngine:
         if multi:                                               # several images per sample: no sharing, the per-sample path
             groups = list(range(n))
         if owners:                                              # dp_actor.py:78-83 concatenates over the samples
-            px = torch.cat([torch.as_tensor(items[r]["pixel_values"]) for r in owners], 0)
+            px = torch.cat([pixels_on_device(items[r]["pixel_values"], self.store.device) for r in owners], 0)      # one H2D copy per image and step
             gr = np.concatenate([np.asarray(items[r]["image_grid_thw"]).reshape(-1, 3) for r in owners], 0)
         return self.model.stage(ids, am, data["position_ids"][sl], R, px, gr, groups=groups)
 

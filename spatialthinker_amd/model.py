@@ -925,6 +925,35 @@ class Qwen25VL:
         return lp_full.view(b.pk.B, b.pk.R), metrics
 
 
+# ---- one host -> device copy per image and step.  The phases of a step (rollout prefill, reference pass, update passes) stage the SAME
+# per-sample pixel tensors (6.3 MB of fp32 patches per STVQA image, pageable host memory) — three copies of 400 MB per GPU and step in the
+# bench.  The device copy is kept, keyed by the identity of the host tensor (which is held, so the id stays valid), until the next rollout
+# starts (Generator.generate drops the cache: new prompts) or the cache holds more than ST_PIXEL_CACHE_MB.
+_PIXEL_CACHE: Dict[tuple, tuple] = {}
+_PIXEL_CACHE_BYTES = [0]
+
+
+def pixels_on_device(t, device) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        t = torch.from_numpy(np.ascontiguousarray(t))
+    if t.is_cuda:
+        return t
+    key = (id(t), t.data_ptr(), tuple(t.shape), str(device))
+    hit = _PIXEL_CACHE.get(key)
+    if hit is None:
+        if _PIXEL_CACHE_BYTES[0] > int(os.environ.get("ST_PIXEL_CACHE_MB", "4096")) << 20:
+            drop_pixel_cache()
+        hit = (t, t.to(device=device, dtype=F32, non_blocking=True))
+        _PIXEL_CACHE[key] = hit
+        _PIXEL_CACHE_BYTES[0] += hit[1].numel() * 4
+    return hit[1]
+
+
+def drop_pixel_cache():
+    _PIXEL_CACHE.clear()
+    _PIXEL_CACHE_BYTES[0] = 0
+
+
 def _seg_pairs(pk) -> float:
     """(query, key) pairs of the shared-prefix causal attention over the packed segments: own rows causally + the whole prefix."""
     L = (pk.seg_e - pk.seg_b).astype(np.float64)

@@ -21,7 +21,7 @@ import torch
 
 from . import indexing as ix
 from . import ops
-from .model import BF16, F32, I32, I64, Qwen25VL
+from .model import BF16, F32, I32, I64, Qwen25VL, drop_pixel_cache, pixels_on_device
 
 
 class Generator:
@@ -99,6 +99,7 @@ class Generator:
         """generate_chunk() over the whole call when its caches fit the free HBM, otherwise over consecutive chunks of prompts
         (plan_prompt_chunks).  Samples keep their GLOBAL row ids for the counter RNG, so the tokens do not depend on the chunking.  A
         chunked call returns no prompt cache (it would have to outlive the chunks): the old-policy pass then recomputes the prompts."""
+        drop_pixel_cache()                                       # a new rollout = new prompts: every image pays its one host -> device copy again
         mask_np = np.asarray(attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask)
         lens = mask_np.sum(1).astype(np.int64)
         chunks = self.plan_prompt_chunks(lens, n, max_new_tokens)
@@ -173,7 +174,7 @@ class Generator:
                 tok += int(lens[i1]); i1 += 1
             px = gr = None
             if pixel_values is not None:
-                px = torch.cat([torch.as_tensor(pixel_values[i]) for i in range(i0, i1)], 0)
+                px = torch.cat([pixels_on_device(pixel_values[i], dev) for i in range(i0, i1)], 0)
                 gr = np.concatenate([np.asarray(image_grid_thw[i]).reshape(-1, 3) for i in range(i0, i1)], 0)
             b = m.stage(ids_np[i0:i1], mask_np[i0:i1], pos_np[i0:i1], 0, px, gr)
             T, base = b.pk.T, int(p_off[i0])

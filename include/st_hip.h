@@ -256,7 +256,7 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
  * one-workgroup-per-CU kernel (attn_decode128_kernel: the tiles of all of a workgroup's items stream through one 4-slot LDS ring, 3 tiles
  * in flight per CU), 0 = one workgroup per item (attn_fwd128_kernel<false>; default — measured faster, see attention.hip — and the
  * path of wider items).  Same arithmetic: bit-identical partials (tests/test_gpu_kernels.py).  ST_DECODE_ATTN=persistent sets the initial value to 1. */
-int st_decode_attn_select(int persistent);
+int st_decode_attn_select(int persistent);   /* 2 = the persistent kernel with TWO workgroups per CU (2-slot rings, 80 KiB of LDS each) */
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
 int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows,

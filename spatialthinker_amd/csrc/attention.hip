@@ -489,9 +489,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
 // Same arithmetic as attn_fwd128_kernel<false> tile for tile (same S^T / softmax / PV sequence): bit-identical partials.
 // Needs max_q <= 64 query rows per item (two row blocks); larger groups (G = 16 rollouts x 7 heads) stay on the kernel above.
 // =============================================================================================
-#define DEC_SLOTS 4
 #define DEC_QBYTES 16384
-#define DEC_LDS_BYTES (DEC_SLOTS * F2_STAGE + 2 * DEC_QBYTES)
+// two shapes of the persistent kernel: <4 slots, 2 Q buffers, 1 workgroup per CU> (the first version: 3 tiles in flight per CU, ONE computing
+// wave per tile step) and <2 slots, 1 Q buffer, 2 workgroups per CU> (80 KiB each = the CU's whole LDS: one tile in flight per workgroup as
+// in the one-item-per-workgroup kernel, two computing waves per CU, no per-item prologue; the next item's Q may be staged once every wave has
+// read the current item's Q into registers, i.e. from the item's second tile on)
+#define DEC_LDS_BYTES_OF(SLOTS, QBUFS) ((SLOTS) * F2_STAGE + (QBUFS) * DEC_QBYTES)
 
 template <int N> __device__ __forceinline__ void dec_wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -602,7 +605,8 @@ __device__ __forceinline__ void dec_stage_q(const DecArgs& a, const DecItem& it,
     }
 }
 
-__global__ __launch_bounds__(256, 1) void attn_decode128_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+template <int DEC_SLOTS, int DEC_QBUFS, int DEC_MINB>
+__global__ __launch_bounds__(256, DEC_MINB) void attn_decode128_kernel(const uint16_t* __restrict__ q, int64_t ldq,
                                                                const uint16_t* __restrict__ k, int64_t ldk,
                                                                const uint16_t* __restrict__ v, int64_t ldv,
                                                                const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end,
@@ -645,9 +649,11 @@ __global__ __launch_bounds__(256, 1) void attn_decode128_kernel(const uint16_t* 
     // one stream unit = one K/V tile (8 copies per wave) + the item's Q rows in front of its first tile (4 more); the producer
     // stays within the item after the consumer's (the Q double buffer) and within DEC_SLOTS - 1 units of it (the K/V ring)
 #define DEC_PRODUCE_WHILE(LIMIT)                                                                                                     \
-    while (produced - consumed < (LIMIT) && p_open && p_seq <= c_seq + 1) {                                                         \
+    while (produced - consumed < (LIMIT) && p_open &&                                                                               \
+           (DEC_QBUFS == 2 ? p_seq <= c_seq + 1                                                                                      \
+                           : (p_seq == c_seq || (p_seq == c_seq + 1 && (p_tile > 0 || c_tile >= 1))))) {                            \
         int cnt_ = 8;                                                                                                               \
-        if (p_tile == 0) { dec_stage_q(a, pit, qbuf + (p_seq & 1) * DEC_QBYTES, wave, lane); cnt_ = 12; }                           \
+        if (p_tile == 0) { dec_stage_q(a, pit, qbuf + (p_seq & (DEC_QBUFS - 1)) * DEC_QBYTES, wave, lane); cnt_ = 12; }             \
         dec_stage_kv(a, pit, p_tile, dsm + (produced & (DEC_SLOTS - 1)) * F2_STAGE, wave, lane, koff, voff);                        \
         fifo |= (uint64_t)cnt_ << (8 * (produced - consumed));                                                                      \
         ++produced;                                                                                                                 \
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void attn_decode128_kernel(const uint16_t* 
         const int q_idx = wave * 32 + qc;
         const bool q_ok = q_idx < cit.Lq;
         if (c_tile == 0 && active) {
-            const char* qp = qbuf + (c_seq & 1) * DEC_QBYTES + (wave * 32 + qc) * 256;
+            const char* qp = qbuf + (c_seq & (DEC_QBUFS - 1)) * DEC_QBYTES + (wave * 32 + qc) * 256;
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) qf[s2] = *reinterpret_cast<const bf16x8*>(qp + (((2 * s2 + half) ^ k_swz) << 4));
 #pragma unroll
@@ -1608,9 +1614,9 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
 // with one workgroup per CU a single wave computes every tile of the CU (decode items have 7 or 56 query rows) and also issues its share
 // of the copies, ~2 us per tile, where two co-resident workgroups run two such waves side by side.  Kept selectable (ST_DECODE_ATTN=persistent,
 // st_decode_attn_select) and bit-identical (tests/test_gpu_kernels.py).
-static int g_decode_attn_persistent = [] { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'p') ? 1 : 0; }();
-int st_decode_attn_select(int persistent) {
-    if (persistent != 0 && persistent != 1) return ST_EINVAL;
+static int g_decode_attn_persistent = [] { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'p') ? ((e[1] == '2') ? 2 : 1) : 0; }();      // "persistent" / "p2"
+int st_decode_attn_select(int persistent) {          // 0 = one workgroup per item, 1 = persistent, one workgroup per CU, 2 = persistent, two per CU
+    if (persistent < 0 || persistent > 2) return ST_EINVAL;
     g_decode_attn_persistent = persistent;
     return 0;
 }
@@ -1625,16 +1631,19 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
         n_q > 0 && !(ldq & 7) && !(ldk & 7) && !(ldv & 7) && !(ldo & 3) && max_q > 0 && (k_pre == nullptr) == (v_pre == nullptr) &&
         (!k_pre || (pre_beg && !(ldk_pre & 7) && !(ldv_pre & 7)))) {
         hipStream_t s = (hipStream_t)stream;
-        static bool configured = false;
-        if (!configured) {
-            hipFuncSetAttribute((const void*)attn_decode128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_BYTES);
-            configured = true;
-        }
         const int64_t W = (int64_t)n_seq * n_q;
-        const int grid = (int)(W < st_num_cus() ? W : st_num_cus());
         StProfScope ps(ST_K_DECODE_ATTN, s, 0.0);
-        hipLaunchKernelGGL(attn_decode128_kernel, dim3(grid), dim3(256), DEC_LDS_BYTES, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg,
-                           q_group, T_out, n_seq, n_q, scale * LOG2E, out, ldo, lse, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre);
+#define DEC_GO(SLOTS, QBUFS, MINB)                                                                                                    \
+        do {                                                                                                                          \
+            auto kern = attn_decode128_kernel<SLOTS, QBUFS, MINB>;                                                                    \
+            static bool configured = false;                                                                                           \
+            if (!configured) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_BYTES_OF(SLOTS, QBUFS)); configured = true; } \
+            const int64_t slots_ = (int64_t)st_num_cus() * (MINB);                                                                     \
+            hipLaunchKernelGGL(kern, dim3((int)(W < slots_ ? W : slots_)), dim3(256), DEC_LDS_BYTES_OF(SLOTS, QBUFS), s, q, ldq, k, ldk, v, ldv, q_beg, q_end, \
+                               k_beg, k_end, o_beg, q_group, T_out, n_seq, n_q, scale * LOG2E, out, ldo, lse, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre); \
+        } while (0)
+        if (g_decode_attn_persistent == 2) DEC_GO(2, 1, 2); else DEC_GO(4, 2, 1);
+#undef DEC_GO
         ST_CHECK_LAUNCH();
         return 0;
     }

@@ -742,10 +742,11 @@ def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, sc
     return out, lse
 
 
-def decode_attn_select(persistent: bool):
-    """Kernel behind attn_fwd_ranges for decode-shaped launches: True = persistent one-workgroup-per-CU kernel, False = one workgroup
-    per item (default: measured faster; st_decode_attn_select; A/B runs and the bit-identity test)."""
-    lib().st_decode_attn_select(1 if persistent else 0)
+def decode_attn_select(persistent):
+    """Kernel behind attn_fwd_ranges for decode-shaped launches: 0 / False = one workgroup per item (default), 1 / True = the persistent
+    kernel with one workgroup per CU (4-slot ring), 2 = persistent with two workgroups per CU (2-slot rings); all bit-identical
+    (st_decode_attn_select; A/B runs and the bit-identity test)."""
+    lib().st_decode_attn_select(int(persistent))
 
 
 def attn_merge(parts, lse, n_parts, heads, D, out=None, q_group=0):

@@ -788,7 +788,7 @@ def test_decode_attention_persistent_kernel_is_bit_identical_to_one_item_per_wor
     scale = 1.0 / math.sqrt(D)
     res = {}
     try:
-        for mode in (False, True):
+        for mode in (0, 1, 2):                                   # one workgroup per item / persistent, one per CU / persistent, two per CU
             ops.decode_attn_select(mode)
             parts = torch.full((NP * rows_all, width), float("nan"), dtype=torch.bfloat16, device="cuda")
             lse = torch.full((nkv, NP * rows_all), float("nan"), dtype=torch.float32, device="cuda")
@@ -799,14 +799,16 @@ def test_decode_attention_persistent_kernel_is_bit_identical_to_one_item_per_wor
             torch.cuda.synchronize()
             res[mode] = (parts.clone(), lse.clone(), merged.clone())
     finally:
-        ops.decode_attn_select(False)                             # the default
-    (p0, l0, m0), (p1, l1, m1) = res[False], res[True]
-    assert torch.equal(l0, l1) or torch.equal(torch.nan_to_num(l0, nan=7.0), torch.nan_to_num(l1, nan=7.0))
+        ops.decode_attn_select(0)                                 # the default
+    (p0, l0, m0) = res[0]
     live = torch.isfinite(l0)                                     # (heads, slabs*rows): rows of items that had keys
     assert int(live.sum()) > 0 and int((l0 == float("-inf")).sum()) > 0
     rows_live = live.any(0)
-    assert torch.equal(p0[rows_live].view(torch.int16), p1[rows_live].view(torch.int16))
-    assert torch.equal(m0.view(torch.int16), m1.view(torch.int16))
+    for mode in (1, 2):
+        p1, l1, m1 = res[mode]
+        assert torch.equal(l0, l1) or torch.equal(torch.nan_to_num(l0, nan=7.0), torch.nan_to_num(l1, nan=7.0)), mode
+        assert torch.equal(p0[rows_live].view(torch.int16), p1[rows_live].view(torch.int16)), mode
+        assert torch.equal(m0.view(torch.int16), m1.view(torch.int16)), mode
     # dense fp32 reference of the merged attention for a sample of rows
     worst = 0.0
     for b in rs.choice(B, size=min(B, 6), replace=False):

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_kernel(const uint16_t* __r
 // token-minor with MX blocks of 32 consecutive tokens): x (R, C) bf16 row-major -> qT (C, R) e4m3 bytes + scales S[R/128][Cs] dwords (byte j of
 // S[kt][c] = scale of rows 128 kt + 32 j .. + 31 of column c) = st_mxfp8_quantize of the transposed matrix, without materialising it.
 // R % 128 == 0 (packed token counts are padded to 128; the padding rows are zero).  One workgroup per 128 rows x 64 columns: the tile passes
-// through LDS, then thread (column c = t & 63, block j = t >> 6) owns one whole MX block — no cross-lane reduction — and writes its 32 bytes.
+// through LDS, then thread (column c = t >> 2, block j = t & 3) owns one whole MX block — no cross-lane reduction — and writes its 32 bytes.
 // (A 128 x 128 tile with two columns per thread — one LDS dword per row — measured 20 % SLOWER in the bench: 33 KiB of LDS and 64 live
 // values per thread cost more occupancy than the halved LDS instruction count buys.)
 // BOTH: the same pass also writes the ordinary (row-wise) quantisation q / srow of x — a gradient that feeds an fp8 input-gradient GEMM
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_t_kernel(const uint16_t* _
             const int c = c0 + cb + k * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (c < C) v = *reinterpret_cast<const uint4*>(x + (int64_t)(r0 + row) * ldx + c);       // C % 8 == 0: all-in or all-out
-            uint32_t* d = reinterpret_cast<uint32_t*>(&tile[row][cb + k * 8]);
+            uint32_t* d = reinterpret_cast<uint32_t*>(&tile[row][(cb + k * 8 + 32 * (row >> 6)) & 63]);     // rows 64.. rotated by 32 columns (see the reads)
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             if constexpr (BOTH) {
                 float f8[8];
@@ -105,12 +105,16 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_t_kernel(const uint16_t* _
         }
     }
     __syncthreads();
-    const int c = t & 63, j = t >> 6;
+    // thread (column c = t >> 2, block j = t & 3): the four blocks of a column sit in four consecutive lanes, so a column's 128 output bytes
+    // leave as one contiguous 128-byte segment (with c = t & 63 a wave wrote 64 scattered 32-byte pieces: 2.8 TB/s).  LDS: rows 32 apart
+    // are 32 banks apart (33-dword pitch), rows 64 apart would collide — they are stored rotated by 32 columns (16 dwords)
+    const int c = t >> 2, j = t & 3;
+    const int cr = (c + 32 * (j >> 1)) & 63;
     float f[32];
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-        f[i] = bf2f(tile[j * 32 + i][c]);
+        f[i] = bf2f(tile[j * 32 + i][cr]);
         amax = fmaxf(amax, fabsf(f[i]));
     }
     int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;

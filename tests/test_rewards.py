@@ -37,3 +37,45 @@ def test_missing_image_size_raises_like_the_reference(gold):
     with pytest.raises(ValueError) as e:
         spatial_sgg_compute_score("x", "y", "no size here")
     assert str(e.value) == gold["missing_size_error"]
+
+
+# ---------------------------------------------------------------- fractional label similarity
+@pytest.fixture(scope="module")
+def graded(golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    from label_sim import trigram_jaccard
+    return trigram_jaccard, json.load(open(os.path.join(golden_dir, "rewards_graded.json")))
+
+
+def _scene(text):
+    import re
+    return json.loads(re.search(r"<scene>(.*?)</scene>", text, re.S).group(1))
+
+
+def test_graded_similarity_scores_and_assignments_are_float64_exact(graded):
+    """The reference scorer was run under a GRADED deterministic similarity (character-trigram Jaccard, tests/golden/label_sim.py) and
+    under the binary stub; the Hungarian cost 2 (1 - sim) + (1 - ciou) (reference spatial_sgg.py:150-160) depends on the fraction.
+    Both regimes must reproduce float64-exactly, and in >= 20 strings the graded assignment differs from the binary one."""
+    sim, gold = graded
+    differ = scored = 0
+    try:
+        for kind, fn in (("binary", S._exact_similarity), ("graded", sim)):
+            S.set_similarity(fn)
+            for case in gold["cases"]:
+                got = spatial_sgg_compute_score(case["predict"], case["ground_truth"], case["problem"])
+                assert got == case[f"spatial_sgg_{kind}"], (kind, case["name"], got, case[f"spatial_sgg_{kind}"])
+                mapping = list(S.bi_match(_scene(case["ground_truth"])["objects"], _scene(case["predict"])["objects"]))
+                assert mapping == case[f"mapping_{kind}"], (kind, case["name"], mapping)
+                g_rel, p_rel = _scene(case["ground_truth"]).get("relationships", []), _scene(case["predict"]).get("relationships", [])
+                if g_rel and p_rel:
+                    assert S._triplet_matches(g_rel, p_rel) == len(case[f"triplets_{kind}"]), (kind, case["name"])
+        for a, b, want in gold["sims"]:
+            assert sim(a, b) == want
+        for case in gold["cases"]:
+            differ += case["mapping_binary"] != case["mapping_graded"]
+            scored += case["spatial_sgg_binary"] != case["spatial_sgg_graded"]
+    finally:
+        S.set_similarity(S._exact_similarity)
+    assert differ >= 20 and scored >= 8 and len(gold["cases"]) >= 50, (differ, scored)
+    assert any(0.0 < c["spatial_sgg_graded"]["spatial_score"] < 1.0 for c in gold["cases"])

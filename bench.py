@@ -115,7 +115,7 @@ def through_api(a):
     tiny = a.model == "tiny"
     G, npr = a.rollouts, a.prompts_per_gpu
     R = 64 if tiny else a.response_cap
-    spec = "synthetic:stvqa" + (f":{a.image}" if a.image else "") + "@train"
+    spec = "synthetic:stvqa" + (f":{a.image}" if a.image else "") + (":len=16,4" if tiny else ":len=512,128") + "@train"
     n_opt = 4 if (G * npr) % 16 == 0 else 1
     cmd = [sys.executable, "-m", "verl.trainer.main", f"data.train_files={spec}", "data.val_files=", f"data.rollout_batch_size={npr * max(1, a.gpus)}",
            f"data.max_prompt_length={128 if tiny else 1152}", f"data.max_response_length={R}", f"worker.actor.model.model_path={size}",
@@ -125,7 +125,7 @@ def through_api(a):
            "algorithm.use_kl_loss=true", "algorithm.kl_penalty=low_var_kl", "algorithm.kl_coef=1.0e-2", f"trainer.max_steps={a.steps + a.warmup}",
            "trainer.total_episodes=100", f"trainer.n_gpus_per_node={max(1, a.gpus)}", "trainer.val_before_train=false", "trainer.logger=['console']",
            "trainer.save_freq=-1", "trainer.save_checkpoint_path=/tmp/st_bench_api_ckpt"]
-    env = dict(os.environ, PYTHONPATH=ROOT, ST_SKIP_FINAL_SAVE="1", ST_SYNTH_RESPONSE_LENGTHS="16,4" if tiny else "512,128")
+    env = dict(os.environ, PYTHONPATH=ROOT, ST_SKIP_FINAL_SAVE="1")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
     if p.returncode != 0:
         sys.stderr.write(p.stdout[-3000:] + p.stderr[-3000:])

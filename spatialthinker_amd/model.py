@@ -927,18 +927,22 @@ class Qwen25VL:
 
 # ---- one host -> device copy per image and step.  The phases of a step (rollout prefill, reference pass, update passes) stage the SAME
 # per-sample pixel tensors (6.3 MB of fp32 patches per STVQA image, pageable host memory) — three copies of 400 MB per GPU and step in the
-# bench.  The device copy is kept, keyed by the identity of the host tensor (which is held, so the id stays valid), until the next rollout
-# starts (Generator.generate drops the cache: new prompts) or the cache holds more than ST_PIXEL_CACHE_MB.
+# bench.  The device copy is kept, keyed by the host tensor's storage address + shape + dtype + version (the host tensor is held, so the
+# address stays valid), until the next rollout starts (Generator.generate drops the cache: new prompts) or the cache holds more than
+# ST_PIXEL_CACHE_MB.  The cache is module-global: actor and critic workers of one process share it (same images, same step).
 _PIXEL_CACHE: Dict[tuple, tuple] = {}
 _PIXEL_CACHE_BYTES = [0]
 
 
 def pixels_on_device(t, device) -> torch.Tensor:
+    """Device copy of one image's patch tensor.  Cached only for host TORCH tensors (the trainer path passes them: dataset rows keep
+    the tensors alive for the step), keyed by storage address, shape, dtype AND the tensor's in-place version counter — an in-place edit of
+    the host tensor is a miss, not stale pixels.  Anything else (numpy arrays: a fresh wrapper per call could never hit) is copied uncached."""
     if not torch.is_tensor(t):
-        t = torch.from_numpy(np.ascontiguousarray(t))
+        return torch.from_numpy(np.ascontiguousarray(t)).to(device=device, dtype=F32, non_blocking=True)
     if t.is_cuda:
         return t
-    key = (id(t), t.data_ptr(), tuple(t.shape), str(device))
+    key = (t.data_ptr(), tuple(t.shape), str(t.dtype), int(t._version), str(device))
     hit = _PIXEL_CACHE.get(key)
     if hit is None:
         if _PIXEL_CACHE_BYTES[0] > int(os.environ.get("ST_PIXEL_CACHE_MB", "4096")) << 20:

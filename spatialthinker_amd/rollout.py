@@ -119,12 +119,11 @@ class Generator:
                 outs[-1], d = outs[-1]
                 lps.append(d["log_probs"])
         out = torch.cat(outs, 0)
-        if not return_prompt_cache:
-            return out
-        if emit:                            # no prompt K/V outlives the chunks, but the rollout's own log-probs do
+        if emit:                            # same contract as generate_chunk: (responses, dict) whenever emit is set, with or without
+            # return_prompt_cache — no prompt K/V outlives the chunks, but the rollout's own log-probs do
             return out, dict(log_probs=torch.cat(lps, 0), responses=out, temperature=float(kw.get("temperature", 1.0)),
                              weights_version=getattr(self.m.p, "version", 0))
-        return out, None
+        return (out, None) if return_prompt_cache else out
 
     @torch.no_grad()
     def generate_chunk(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
@@ -229,6 +228,11 @@ class Generator:
             Ba = len(S_np)
             Bp = ix.round_up(Ba, 32) if Ba <= 256 else ix.round_up(Ba, 128)
             fused = can_fuse and Bp <= ops.DECODE_MAX_ROWS
+            if emit_log_probs and not fused:
+                # the log-probability of a sampled token is written by st_decode_step (fused path only): an unfused wave (ST_MAX_DECODE above
+                # DECODE_MAX_ROWS) would hand back zeros that PolicyEngine.rollout_log_probs cannot tell from real values
+                raise RuntimeError(f"emit_log_probs needs the fused decode step, but a wave of {Bp} rows exceeds DECODE_MAX_ROWS = {ops.DECODE_MAX_ROWS} "
+                                   f"(ST_MAX_DECODE = {self.max_decode_batch}): lower ST_MAX_DECODE or turn old_log_probs_from_rollout off")
             S_t = ti(S_np)
             S_l = S_t.long()
             S_rng = S_t + int(rng_row_offset) if rng_row_offset else S_t       # the counter RNG is keyed by the sample's row in the WHOLE call

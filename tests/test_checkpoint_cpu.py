@@ -199,3 +199,85 @@ def test_fp32_master_enabled_before_the_load_keeps_the_checkpoints_own_precision
     assert torch.equal(back[k], off_grid[k])                                   # the fp32 values themselves, not their bf16 rounding
     assert not torch.equal(back[k], off_grid[k].bfloat16().float())
     assert torch.equal(st2.flat, st2.master.bfloat16())                        # the working copy is the rounding of the master
+
+
+def _real_fsdp_worker(rank, world, hf_dir, out, steps):
+    """What a reference run leaves on disk, produced by REAL torch FSDP (use_orig_params=True, frozen vision tower — fsdp_workers.py:227-229,
+    268-280) + AdamW on `world` gloo ranks and saved exactly as FSDPCheckpointManager.save_checkpoint does (:83-131)."""
+    import functools
+    import warnings
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("ST_TEST_PORT", "29581"), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.distributed.device_mesh import init_device_mesh
+    from torch.distributed.fsdp import FullyShardedDataParallel as FSDP, ShardedOptimStateDictConfig, ShardedStateDictConfig, ShardingStrategy, StateDictType
+    from torch.distributed.fsdp.wrap import transformer_auto_wrap_policy
+    from transformers import Qwen2_5_VLForConditionalGeneration
+    model = Qwen2_5_VLForConditionalGeneration.from_pretrained(hf_dir, torch_dtype=torch.float32).train()
+    model.model.visual.requires_grad_(False)
+    layer_cls = {type(model.model.language_model.layers[0]), type(model.model.visual.blocks[0])}
+    fs = FSDP(model, sharding_strategy=ShardingStrategy.FULL_SHARD, device_id=torch.device("cpu"), use_orig_params=True,
+              auto_wrap_policy=functools.partial(transformer_auto_wrap_policy, transformer_layer_cls=layer_cls),
+              device_mesh=init_device_mesh("cpu", (world,), mesh_dim_names=("fsdp",)))
+    opt = torch.optim.AdamW(fs.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2)
+    for step in range(steps):
+        ids = torch.randint(0, 900, (2, 12), generator=torch.Generator().manual_seed(1000 * step + rank))
+        loss = fs(input_ids=ids, attention_mask=torch.ones_like(ids)).logits.float().pow(2).mean()
+        opt.zero_grad(); loss.backward(); opt.step()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with FSDP.state_dict_type(fs, StateDictType.SHARDED_STATE_DICT, ShardedStateDictConfig(offload_to_cpu=True), ShardedOptimStateDictConfig(offload_to_cpu=True)):
+            msd, osd = fs.state_dict(), opt.state_dict()
+    os.makedirs(out, exist_ok=True)
+    torch.save(msd, os.path.join(out, f"model_world_size_{world}_rank_{rank}.pt"))
+    torch.save(osd, os.path.join(out, f"optim_world_size_{world}_rank_{rank}.pt"))
+    torch.save({"lr_scheduler": {"last_epoch": steps, "_step_count": steps + 1, "base_lrs": [1e-3], "_last_lr": [1e-3], "lr_lambdas": [None]},
+                "rng": {"cpu": torch.get_rng_state()}}, os.path.join(out, f"extra_state_world_size_{world}_rank_{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_adamw_moments_of_a_real_fsdp_run_are_restored_per_parameter(tmp_path, capsys):
+    """the reference's optim_world_size_W_rank_r.pt with use_orig_params=True (what freeze_vision_tower — every shipped
+    script — switches on) holds per-PARAMETER 1-D pieces keyed by the parameter's index: the loader concatenates them in rank order and
+    names them through the model file's key order.  Ground truth: the same two AdamW steps on ONE process with the two ranks' losses
+    averaged (FSDP averages the gradients)."""
+    import torch.multiprocessing as tmp
+    from transformers import Qwen2_5_VLForConditionalGeneration
+    from verl.utils.checkpoint import load_reference_checkpoint
+    world, steps = 2, 2
+    cfg, store, params = _store()
+    hf_dir, out = str(tmp_path / "hf"), str(tmp_path / "global_step_2" / "actor")
+    save_hf(store, hf_dir)
+    tmp.spawn(_real_fsdp_worker, args=(world, hf_dir, out, steps), nprocs=world)
+    # single-process ground truth
+    model = Qwen2_5_VLForConditionalGeneration.from_pretrained(hf_dir, torch_dtype=torch.float32).train()
+    model.model.visual.requires_grad_(False)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2)
+    for step in range(steps):
+        loss = 0.0
+        for rank in range(world):
+            ids = torch.randint(0, 900, (2, 12), generator=torch.Generator().manual_seed(1000 * step + rank))
+            loss = loss + model(input_ids=ids, attention_mask=torch.ones_like(ids)).logits.float().pow(2).mean() / world
+        opt.zero_grad(); loss.backward(); opt.step()
+    tgt = mdl.ParamStore(cfg, device="cpu", trainable=False)
+    tgt.trainable = True
+    tgt.m, tgt.v, tgt.c = torch.zeros(tgt.numel, dtype=torch.float32), torch.zeros(tgt.numel, dtype=torch.float32), None
+    tgt.refresh_transposes = lambda: None
+    info = load_reference_checkpoint(tgt, out)
+    assert info == {"world_size": world, "opt_steps": steps, "sched_steps": steps, "optimizer": "loaded-per-parameter"}
+    assert "restored AdamW state" in capsys.readouterr().out
+    got_m = tgt.export_hf({n: tgt._view(tgt.m, n) for n in tgt.layout})
+    got_v = tgt.export_hf({n: tgt._view(tgt.v, n) for n in tgt.layout})
+    got_w = tgt.export_hf()
+    n_state = 0
+    for name, p in model.named_parameters():
+        st = opt.state.get(p)
+        if not st:
+            assert float(got_m[name].abs().max()) == 0.0, name             # frozen tower: no state, zeros
+            continue
+        n_state += 1
+        scale = float(st["exp_avg"].abs().max()) + 1e-30
+        assert float((got_m[name].float() - st["exp_avg"]).abs().max()) <= 2e-4 * scale + 1e-12, name
+        assert float((got_v[name].float() - st["exp_avg_sq"]).abs().max()) <= 4e-4 * float(st["exp_avg_sq"].abs().max()) + 1e-20, name
+        assert float((got_w[name].float() - p.detach().bfloat16().float()).abs().max()) <= 2.0 ** -7 * float(p.detach().abs().max()), name   # bf16 store
+    assert n_state >= 20

@@ -267,6 +267,20 @@ def test_save_limit_and_resume_replays_nothing(tmp_path, capsys):
     assert "step 3:" in out and "step 5:" in out
     with pytest.raises(ValueError):
         make_trainer(tmp_path / "d", ["trainer.load_checkpoint_path=/tmp/not_a_step_dir"])[0].fit()
+    # a state of THIS loader saved for another dataset size must STOP the resume (it used to restart the data order with a
+    # print, after kl_coef had already been overwritten); only another implementation's dataloader.pt restarts the order
+    tr3, _, _ = make_trainer(tmp_path / "e", ["trainer.max_steps=5", f"trainer.load_checkpoint_path={ck}"], n_rows=32)
+    kl_before = tr3.kl_ctrl.kl_coef
+    with pytest.raises(ValueError, match="different dataset size"):
+        tr3.fit()
+    assert tr3.kl_ctrl.kl_coef == kl_before
+    import shutil
+    ck_f = tmp_path / "f" / "global_step_2"
+    shutil.copytree(ck, ck_f)
+    torch.save({"_snapshot": {"_main_snapshot": {}}, "_steps_since_snapshot": 0}, ck_f / "dataloader.pt")      # StatefulDataLoader-shaped
+    tr4, wg4, _ = make_trainer(tmp_path / "g", ["trainer.max_steps=3", f"trainer.load_checkpoint_path={ck_f}"], n_rows=16)
+    tr4.fit()
+    assert "the data order starts from scratch" in capsys.readouterr().out and len(wg4.updates) == 1
 
 
 # ------------------------------------------------------------------------------------------------ validation

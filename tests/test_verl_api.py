@@ -123,3 +123,43 @@ def test_reward_manager_places_score_on_last_valid_token():
     assert metrics["overall"] == [1.0, 0.0] and metrics["format"] == [1.0, 0.0]
     with pytest.raises(NotImplementedError):
         CustomRewardManager(_Tok(), RewardConfig(score_function="nope"))
+
+
+def test_reference_import_paths_of_the_single_controller_resolve():
+    """Third-party worker code written against the reference imports `verl.single_controller.base.Worker` and
+    `verl.single_controller.base.decorator.{Dispatch, register}` (reference verl/workers/fsdp_workers.py:41-42)."""
+    from verl.single_controller.base import ClassWithInitArgs, ResourcePool, Worker, WorkerGroup
+    from verl.single_controller.base.decorator import Dispatch, Execute, register
+    from verl.single_controller import decorator as D
+    from verl.workers.fsdp_workers import FSDPWorker
+    assert Dispatch is D.Dispatch and register is D.register and Execute is D.Execute
+    assert issubclass(FSDPWorker, Worker)
+
+    class Mine(Worker):
+        @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
+        def twice(self, x):
+            return 2 * x
+
+    wg = WorkerGroup(ResourcePool([1]), ClassWithInitArgs(Mine))
+    assert wg.twice(21) == 42 and wg.world_size == 1 and wg.worker.rank == 0
+    assert wg.execute_func_rank_zero(lambda a, b: a + b, 1, 2) == 3
+    assert wg.worker.get_master_addr_port() == (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))
+
+
+def test_synthetic_lengths_travel_as_dataset_rows_not_as_a_worker_hook():
+    """bench.py --through-api: `synthetic:stvqa:len=mu,sd@train` rows carry the forced response lengths; FSDPWorker has no benchmark hook."""
+    import inspect
+    from spatialthinker_amd.pretrained import synthetic_config
+    from verl.utils.dataset import SyntheticSTVQADataset
+    from verl.utils.tokenizer import get_tokenizer
+    from verl.workers import fsdp_workers
+    assert "ST_SYNTH" not in inspect.getsource(fsdp_workers)
+    mcfg, _ = synthetic_config("random:tiny")
+    ds = SyntheticSTVQADataset(mcfg, get_tokenizer("random:tiny"), size=8, max_prompt_length=128, grid=(1, 8, 8), text_tokens=(8, 12),
+                               response_lengths=(16.0, 4.0, 4, 24))
+    row = ds[3]
+    lens = row["synthetic_response_lengths"]
+    assert lens.shape == (4,) and lens.dtype == np.int64 and (lens >= 1).all() and (lens <= 24).all()
+    assert np.array_equal(lens, ds[3]["synthetic_response_lengths"])                  # deterministic per row
+    assert "synthetic_response_lengths" not in SyntheticSTVQADataset(mcfg, get_tokenizer("random:tiny"), size=8, max_prompt_length=128,
+                                                                      grid=(1, 8, 8), text_tokens=(8, 12))[3]

@@ -1,6 +1,7 @@
 """Convert this engine's checkpoint (actor/huggingface/*.safetensors + actor/optim_world_size_1_rank_0.pt) into the reference's
-layout — model_/optim_/extra_state_world_size_W_rank_r.pt with DTensor Shard(0) shards on an ("fsdp",) mesh — so that the reference's
-FSDPCheckpointManager.load_checkpoint (verl/utils/checkpoint/fsdp_checkpoint_manager.py:52-81) or scripts/model_merger.py can read it.
+layout — model_/extra_state_world_size_W_rank_r.pt with DTensor Shard(0) shards on an ("fsdp",) mesh — so that the reference's
+scripts/model_merger.py can read it.  MERGER-ONLY: a reference run cannot RESUME from the export (FSDPCheckpointManager.load_checkpoint,
+verl/utils/checkpoint/fsdp_checkpoint_manager.py:52-81, loads optimizer files in its own per-rank layout unconditionally).
     python tools/export_reference_checkpoint.py <global_step_N/actor> <out_dir> <world_size>
 Runs stand-alone (no process group may exist: the device mesh is built on torch's in-process fake backend)."""
 import glob

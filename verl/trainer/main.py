@@ -56,12 +56,19 @@ def main():
             grid, text = ((1, 8, 8), (8, 12)) if tiny else ((1, 32, 42), (200, 564))
             # "synthetic:stvqa:224x224@train": square/rect images of that pixel size (SURVEY 8d': 224/448/896 -> 256/1024/4096
             # patches) with 700 text tokens, instead of the STVQA-shaped 588x448 default
+            # "synthetic:stvqa:len=512,128@train": the rows also carry forced response lengths ~ clip(N(512, 128), 64, cap) for their
+            # rollouts (benchmark mode: random-init weights never emit EOS on their own)
             name = spec.split("@")[0].split(":")
-            if len(name) >= 3 and "x" in name[2]:
-                w_px, h_px = (int(v) for v in name[2].lower().split("x"))
-                grid, text = (1, h_px // mcfg.v_patch, w_px // mcfg.v_patch), ((8, 12) if tiny else (200, 500))
+            lengths = None
+            for field in name[2:]:
+                if field.startswith("len="):
+                    mu, sd = (float(v) for v in field[4:].split(","))
+                    lengths = (mu, sd, int(cfg.worker.rollout.n), int(cfg.data.max_response_length))
+                elif "x" in field:
+                    w_px, h_px = (int(v) for v in field.lower().split("x"))
+                    grid, text = (1, h_px // mcfg.v_patch, w_px // mcfg.v_patch), ((8, 12) if tiny else (200, 500))
             return SyntheticSTVQADataset(mcfg, tokenizer, size=max(4 * cfg.data.rollout_batch_size, 64), max_prompt_length=cfg.data.max_prompt_length,
-                                         seed=cfg.data.seed + (0 if train else 1), grid=grid, text_tokens=text)
+                                         seed=cfg.data.seed + (0 if train else 1), grid=grid, text_tokens=text, response_lengths=lengths if train else None)
         # ray_trainer.py:267-313: the train set takes mixed_data / text_only, the validation set does not; both keep the dataset's own
         # shuffle (seed 42) — data.shuffle / data.seed drive the SAMPLER
         extra = dict(mixed_data=cfg.data.mixed_data, text_only=cfg.data.text_only) if train else {}

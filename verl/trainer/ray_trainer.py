@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from ..protocol import DataProto
-from ..utils.dataloader import ResumableDataLoader
+from ..utils.dataloader import ForeignDataloaderState, ResumableDataLoader
 from ..utils.seqlen_balancing import get_seqlen_balanced_partitions, log_seqlen_unbalance
 from . import core_algos
 from .metrics import compute_data_metrics, compute_throughout_metrics, compute_timing_metrics, reduce_metrics
@@ -356,11 +356,16 @@ class RayPPOTrainer:
         dl = os.path.join(p, "dataloader.pt")
         if os.path.exists(dl):
             try:
-                st = torch.load(dl, weights_only=False)
-                self.kl_ctrl.kl_coef = st.get("kl_coef", self.kl_ctrl.kl_coef)
-                self.train_dataloader.load_state_dict(st["dataloader"] if "dataloader" in st else st)      # round-2 files nested it
-            except Exception as e:           # a reference run's dataloader.pt (StatefulDataLoader snapshot) or an unreadable file: go on
+                try:
+                    st = torch.load(dl, weights_only=False)  # an unreadable file of THIS loader is an error, not a fresh start
+                except ModuleNotFoundError as e:             # pickled objects of a package this image lacks (torchdata): another implementation's file
+                    raise ForeignDataloaderState(str(e)) from e
+                self.train_dataloader.load_state_dict(st["dataloader"] if isinstance(st, dict) and "dataloader" in st else st)   # round-2 files nested it
+            except ForeignDataloaderState as e:   # ONLY a reference run's dataloader.pt (StatefulDataLoader snapshot): the data order restarts;
+                # a state of this loader saved for another dataset size / rollout_batch_size stays a ValueError and stops the resume
                 print(f"Dataloader state at {dl} is not usable here ({type(e).__name__}: {e}); the data order starts from scratch.")
+            else:
+                self.kl_ctrl.kl_coef = st.get("kl_coef", self.kl_ctrl.kl_coef)        # only after the loader state has loaded
         else:
             print(f"No dataloader state found at {dl}, will start from scratch.")
 
@@ -387,7 +392,10 @@ class RayPPOTrainer:
                 batch = DataProto.from_single_dict(batch_dict)                 # this rank's rows of the global rollout batch
                 nt_keys = [k for k in ("raw_prompt_ids", "multi_modal_data", "multi_modal_inputs") if k in batch.non_tensor_batch]
                 gen_batch = batch.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=nt_keys)
-                if "synthetic_response_lengths" in batch.meta_info:
+                if "synthetic_response_lengths" in batch.non_tensor_batch:       # benchmark datasets only (SyntheticSTVQADataset(response_lengths=...))
+                    per_row = batch.non_tensor_batch.pop("synthetic_response_lengths")
+                    gen_batch.meta_info["synthetic_response_lengths"] = np.concatenate([np.asarray(v, dtype=np.int64) for v in per_row])
+                elif "synthetic_response_lengths" in batch.meta_info:
                     gen_batch.meta_info["synthetic_response_lengths"] = batch.meta_info["synthetic_response_lengths"]
                 with _timer("step", timing_raw):
                     with _timer("gen", timing_raw):

@@ -12,17 +12,23 @@ This engine keeps full replicas, so its native checkpoint is ONE HF-loadable dir
 (verl/workers/fsdp_workers.py save_checkpoint).  To let a run checkpointed by the reference continue here (and vice versa):
   * load_reference_checkpoint  — reads all W model shard files (unpickling DTensors needs no process group), concatenates the local
     shards along their placement dimension, maps transformers-4.49 names to the 5.x names, fills the ParamStore's weights and the
-    scheduler position.  OPTIMIZER STATE: the reference's files hold flat-parameter shards keyed by integer (see above); mapping them
-    back to parameters needs the FSDP wrap policy and flattening order of the run that wrote them, which this loader does not
-    reconstruct — such files are recognised, reported, and the AdamW moments / Kahan buffers / step counter start from zero (a
-    resumed run re-warms its moments over the next ~1/(1-beta2) steps; it never crashes and never mixes up tensors).  Name-keyed
-    optimizer files (what export_reference_layout(write_optim=True) writes: this build's own round-trip format) load bit for bit;
+    scheduler position.  OPTIMIZER STATE: integer-keyed raw `optimizer.state_dict()` files.  With FSDP use_orig_params=True (set by
+    `freeze_vision_tower`, i.e. by every shipped script) an entry is one ORIGINAL parameter's rank-local 1-D piece: those are
+    concatenated in rank order, mapped to names through the model file's key order and restored (_restore_per_parameter_state; pinned
+    against real FSDP + AdamW on two gloo ranks in tests/test_checkpoint_cpu.py).  With use_orig_params=False an entry is the shard of a
+    FlatParameter of a whole wrapped unit; mapping it back needs the wrap policy and flattening order of the run that wrote it, which
+    this loader does not reconstruct — such files are recognised, reported, and the AdamW moments / Kahan buffers / step counter start
+    from zero (it never crashes and never mixes up tensors).  Name-keyed optimizer files (what
+    export_reference_layout(write_optim=True) writes: this build's own round-trip format) load bit for bit;
   * export_reference_layout    — writes this engine's weights as W rank files of DTensor shards under the transformers-4.49 names
     (`visual.*`, `model.*`: what FSDPCheckpointManager.load_checkpoint :52-81 and scripts/model_merger.py :37-164 expect), plus the
-    scheduler position.  No "rng" entry is written (the reference restores it only `if "rng" in extra_state`; an empty one would
-    raise KeyError('cpu')) and, by default, no optimizer files: the reference's Optimizer.load_state_dict accepts only its own
-    integer-keyed flat-shard layout.  DTensor construction needs a process group of W ranks: a stand-alone process builds them on
-    torch's in-process "fake" backend, one rank at a time (tools/export_reference_checkpoint.py).
+    scheduler position.  MERGER-ONLY: the export is an input for scripts/model_merger.py (which reads the model shards alone), NOT a
+    resume point for a reference run — FSDPCheckpointManager.load_checkpoint (:57-62) `torch.load`s optim_world_size_W_rank_r.pt
+    unconditionally, so without optimizer files it stops with FileNotFoundError, and the name-keyed files of write_optim=True are
+    rejected by its Optimizer.load_state_dict (it accepts only its own integer-keyed per-rank layout, whose piece boundaries follow
+    the FSDP wrap policy of the run that loads them).  No "rng" entry is written.  DTensor construction needs a process group of W
+    ranks: a stand-alone process builds them on torch's in-process "fake" backend, one rank at a time
+    (tools/export_reference_checkpoint.py).
 The CUDA RNG state of the reference ("rng") has no counterpart: this engine's sampler is counter-based (seed, row, step)."""
 from __future__ import annotations
 
@@ -111,6 +117,60 @@ def denormalise_hf_names(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]
     return out
 
 
+def _restore_per_parameter_state(store, path: str, W: int) -> Optional[int]:
+    """The reference's optimizer files when FSDP ran with use_orig_params=True (what `freeze_vision_tower` switches on,
+    verl/workers/fsdp_workers.py:227-229, and what every shipped script sets): the optimizer then holds the ORIGINAL parameters, so the
+    raw `optimizer.state_dict()` a rank saves (fsdp_checkpoint_manager.py:95-96) is {"state": {i: {step, exp_avg, exp_avg_sq
+    [, compensation]}}} with i = the parameter's position in `module.parameters()` and every tensor the rank's 1-D piece of that
+    parameter's flattened values (possibly empty, then the entry may be missing).  Pieces concatenated in rank order are the flattened
+    parameter; the parameter order is the key order of the model shard file (a state dict lists parameters in `parameters()` order;
+    Qwen2.5-VL has no persistent buffers; a tied lm_head appears once in `parameters()`).  Returns the step count, or None when the
+    files are not of this form (flat-parameter shards of use_orig_params=False: sizes do not add up to parameter sizes)."""
+    model0 = torch.load(os.path.join(path, f"model_world_size_{W}_rank_0.pt"), map_location="cpu", weights_only=False)
+    names = [k.replace("_fsdp_wrapped_module.", "").replace("_checkpoint_wrapped_module.", "") for k in model0.keys()]
+    numel = []
+    for t in model0.values():
+        loc, dim = _local(t)
+        numel.append(int(torch.Size(t.shape).numel()) if hasattr(t, "shape") else int(loc.numel()))
+    shapes = [tuple(t.shape) for t in model0.values()]
+    per_rank = [torch.load(os.path.join(path, f"optim_world_size_{W}_rank_{r}.pt"), map_location="cpu", weights_only=False) for r in range(W)]
+    n_params = sum(len(g["params"]) for g in per_rank[0]["param_groups"])
+    if n_params == len(names) - 1 and "lm_head.weight" in names:      # tied head: one parameter, two state-dict names
+        k = names.index("lm_head.weight")
+        names.pop(k); numel.pop(k); shapes.pop(k)
+    if n_params != len(names):
+        return None
+    ids = sorted({i for d in per_rank for i in d["state"].keys()})
+    full: Dict[str, Dict[str, torch.Tensor]] = {}
+    steps = []
+    for i in ids:
+        if not isinstance(i, int) or not 0 <= i < len(names):
+            return None
+        entries = [d["state"].get(i) for d in per_rank]
+        keys = sorted({k for e in entries if e for k in e.keys()})
+        st = {}
+        for k in keys:
+            vals = [e[k] for e in entries if e is not None and k in e]
+            if k == "step" or not torch.is_tensor(vals[0]) or vals[0].dim() == 0:
+                steps.append(int(float(vals[0])))
+                continue
+            flat = torch.cat([v.reshape(-1) for v in vals])
+            if flat.numel() != numel[i]:
+                return None                                               # flat-parameter shards (padding, several parameters per entry)
+            st[k] = flat.reshape(shapes[i])
+        full[names[i]] = st
+    state = normalise_hf_names(full)
+    views = store.export_hf()
+    for buf, key in ((store.m, "exp_avg"), (store.v, "exp_avg_sq"), (store.c, "compensation")):
+        if buf is None:
+            continue
+        have = {n: st[key] for n, st in state.items() if key in st}
+        store.load_hf_state_dict({n: have[n] if n in have else torch.zeros(tuple(t.shape)) for n, t in views.items()}, target=buf)
+    print(f"[checkpoint] restored AdamW state of {len(full)} parameters from the reference's per-parameter optimizer shards ({W} ranks, "
+          f"step {max(steps) if steps else 0})")
+    return max(steps) if steps else 0
+
+
 def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
     """Fill `store` (ParamStore) — and, when given, the PolicyEngine's optimizer / scheduler counters — from a checkpoint directory in
     the reference's layout.  Returns {"world_size", "opt_steps", "sched_steps", "optimizer"}; "optimizer" is "loaded", "reset" (files
@@ -129,14 +189,23 @@ def load_reference_checkpoint(store, path: str, engine=None) -> Dict[str, Any]:
             keys, probe = None, None
             print(f"[checkpoint] cannot read {opt_file} ({type(e).__name__}: {e}); the optimizer state starts from zero")
         if keys is None or any(not isinstance(k, str) for k in keys):
+            restored = None
             if keys is not None:
-                print(f"[checkpoint] {opt_file} holds the reference's raw per-rank optimizer.state_dict() ({len(keys)} flat-parameter shards keyed "
-                      f"by integer); they are not unflattened here — weights and scheduler position are restored, AdamW moments / Kahan buffers / "
-                      f"step counter start from zero")
-            info["optimizer"] = "reset"
-            for buf in (store.m, store.v, store.c):
-                if buf is not None:
-                    buf.zero_()
+                try:
+                    restored = _restore_per_parameter_state(store, path, W)
+                except Exception as e:                                    # a layout this reader does not know must not end the run
+                    print(f"[checkpoint] {opt_file}: per-parameter restore failed ({type(e).__name__}: {e})")
+            if restored is not None:
+                info["optimizer"], info["opt_steps"] = "loaded-per-parameter", restored
+            else:
+                if keys is not None:
+                    print(f"[checkpoint] {opt_file} holds the reference's raw per-rank optimizer.state_dict() ({len(keys)} flat-parameter shards keyed "
+                          f"by integer, FSDP use_orig_params=False); they are not unflattened here — weights and scheduler position are restored, "
+                          f"AdamW moments / Kahan buffers / step counter start from zero")
+                info["optimizer"] = "reset"
+                for buf in (store.m, store.v, store.c):
+                    if buf is not None:
+                        buf.zero_()
         else:
             info["optimizer"] = "loaded"
     if info["optimizer"] == "loaded":
@@ -168,8 +237,8 @@ def export_reference_layout(hf_state: Dict[str, torch.Tensor], optim_state: Opti
     (it brings up torch's "fake" backend once per rank to build the device mesh).
     names: "hf4" (default) renames to the transformers-4.49 parameter names a reference run expects; "asis" keeps the given names.
     write_optim: also write NAME-keyed optimizer files — this build's own round-trip format (load_reference_checkpoint reads them back
-    bit for bit); the reference cannot load them, so they are off by default (a reference run resumed from the export starts its
-    optimizer fresh, exactly as it would from a HF checkpoint)."""
+    bit for bit).  The reference can load NEITHER form as a resume point (module docstring: merger-only) — to continue in the
+    reference, merge the shards with scripts/model_merger.py and start it from the resulting HF directory."""
     if names == "hf4":
         hf_state = denormalise_hf_names(hf_state)
         if optim_state is not None:

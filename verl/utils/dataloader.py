@@ -15,6 +15,11 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 
+class ForeignDataloaderState(ValueError):
+    """A dataloader.pt that another implementation wrote (the reference's torchdata StatefulDataLoader snapshot): the ONE resume error the
+    trainer tolerates (data order restarts); a state of THIS loader saved for other sizes stays a plain ValueError and stops the run."""
+
+
 class ResumableDataLoader:
     def __init__(self, dataset: Dataset, batch_size: int, shuffle: bool = True, seed: int = 1, collate_fn: Optional[Callable] = None,
                  drop_last: bool = True, num_workers: int = 0, rank: int = 0, world_size: int = 1):
@@ -70,7 +75,7 @@ class ResumableDataLoader:
     def load_state_dict(self, state: Dict[str, Any]) -> None:
         if not isinstance(state, dict) or "generator_state" not in state:
             # e.g. the reference's dataloader.pt: a torchdata StatefulDataLoader snapshot (worker / sampler-iterator internals)
-            raise ValueError("not a state of this loader (no `generator_state`): written by another dataloader implementation")
+            raise ForeignDataloaderState("not a state of this loader (no `generator_state`): written by another dataloader implementation")
         if state.get("batch_size", self.batch_size) != self.batch_size or state.get("num_rows", len(self.dataset)) != len(self.dataset):
             raise ValueError("dataloader state was saved for a different dataset size or rollout_batch_size")
         self.gen.set_state(state["generator_state"])

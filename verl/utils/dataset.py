@@ -39,9 +39,14 @@ class SyntheticSTVQADataset(Dataset):
     a `problem` column ending in "Image size: (W x H)" and an `answer_option_text` scene-graph ground truth."""
 
     def __init__(self, model_cfg, tokenizer, size: int = 4096, max_prompt_length: int = 1152, seed: int = 1, grid=(1, 32, 42),
-                 text_tokens=(200, 564), answer_key: str = "answer"):
+                 text_tokens=(200, 564), answer_key: str = "answer", response_lengths=None):
+        """response_lengths = (mean, std, n, cap): synthetic-benchmark mode (`synthetic:stvqa:len=512,128@train`, bench.py --through-api) —
+        every row carries `synthetic_response_lengths`, the n response lengths ~ clip(N(mean, std), min(64, cap), cap) its rollouts are cut
+        to; the trainer hands them to the rollout as meta_info (random-init weights would otherwise never emit EOS)."""
         self.cfg, self.tok, self.size, self.P, self.seed, self.grid, self.text_tokens = model_cfg, tokenizer, size, max_prompt_length, seed, grid, text_tokens
         self.answer_key = answer_key
+        self.response_lengths = response_lengths
+        self.epoch_salt = 0
 
     def __len__(self):
         return self.size
@@ -65,10 +70,14 @@ class SyntheticSTVQADataset(Dataset):
         objs = [{"id": o["id"], "bbox": [o["bbox"][0], o["bbox"][2], o["bbox"][1] + 5, o["bbox"][3] + 5]} for o in objs]
         gt = f"<scene>{json.dumps({'objects': objs, 'relationships': []})}</scene>\n<answer>(A) yes</answer>"
         pix = torch.from_numpy(rs.standard_normal((t * h * w, c.patch_k)).astype(np.float32))
-        return {"input_ids": input_ids, "attention_mask": attention_mask, "position_ids": position_ids,
-                "raw_prompt_ids": ids.tolist(), "multi_modal_data": {"image": [None]},
-                "multi_modal_inputs": {"pixel_values": pix, "image_grid_thw": torch.from_numpy(grid)},
-                "ground_truth": gt, "problem": "Synthetic scene. Image size: (588 x 448)\nQ. is it?\nOptions: (A) yes (B) no"}
+        row = {"input_ids": input_ids, "attention_mask": attention_mask, "position_ids": position_ids,
+               "raw_prompt_ids": ids.tolist(), "multi_modal_data": {"image": [None]},
+               "multi_modal_inputs": {"pixel_values": pix, "image_grid_thw": torch.from_numpy(grid)},
+               "ground_truth": gt, "problem": "Synthetic scene. Image size: (588 x 448)\nQ. is it?\nOptions: (A) yes (B) no"}
+        if self.response_lengths is not None:
+            mu, sd, n, cap = self.response_lengths
+            row["synthetic_response_lengths"] = np.clip(rs.normal(mu, sd, int(n)), min(64, cap), cap).astype(np.int64)
+        return row
 
 
 class RLHFDataset(Dataset):

@@ -23,16 +23,18 @@ from spatialthinker_amd.pretrained import load_model, save_hf
 from spatialthinker_amd.rollout import Generator
 
 from ..protocol import DataProto
-from ..single_controller.decorator import Dispatch, register
+from ..single_controller.base import Worker
+from ..single_controller.base.decorator import Dispatch, register
 from ..utils.flops_counter import FlopsCounter
 from ..utils.tokenizer import get_processor, get_tokenizer
 from .rollout import assemble_rollout_batch
 
 
-class FSDPWorker:
+class FSDPWorker(Worker):
     _warned_padding = False
 
     def __init__(self, config, role: Literal["actor", "critic", "rollout", "ref", "actor_rollout", "actor_rollout_ref"]):
+        super().__init__()
         self.config, self.role = config, role
         self.world_size = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
@@ -181,12 +183,7 @@ class FSDPWorker:
             gr = [m["image_grid_thw"] for m in mm]
         eos = self.special["eos"]
         self._gen_calls = getattr(self, "_gen_calls", 0) + 1
-        forced = prompts.meta_info.get("synthetic_response_lengths")
-        synth = os.environ.get("ST_SYNTH_RESPONSE_LENGTHS")          # "mean,std": synthetic benchmark through the kept API (bench.py --through-api)
-        if forced is None and synth and str(self.config.actor.model.model_path).startswith("random:"):
-            mu, sd = (float(v) for v in synth.split(","))
-            rs = np.random.RandomState(1234 + self.rank + 1000 * self._gen_calls)
-            forced = np.clip(rs.normal(mu, sd, len(ids) * n), min(64, r.response_length), r.response_length).astype(np.int64)
+        forced = prompts.meta_info.get("synthetic_response_lengths")       # set by a benchmark dataset only (verl/utils/dataset.py); None in training
         # the prefill's prompt K/V serves the old-policy log-prob pass that follows on the same weights (PolicyEngine checks that
         # the cache matches the rows it is handed, else it simply recomputes)
         resp, self._prompt_cache = self.generator.generate(

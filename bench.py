@@ -89,6 +89,18 @@ def parse():
                     help="TEST MODE for a 1-GPU box: the N ranks of --gpus N all use cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on "
                          "one device).  Runs the real multi-rank step — rank-sharded batches, overlapped gradient exchange on device tensors, "
                          "barrier / max-over-ranks timing, the exchange statistics of the JSON line — with a small model; not a scaling measurement")
+    ap.add_argument("--overlap-old", default="on", choices=["on", "off"],
+                    help="on (default): the old-policy log-prob pass of the samples that have finished runs on a CU-range stream WHILE the decode "
+                         "tail of the rollout (phases of <= --tail-rows rows) runs on the complementary compute units (actor.EarlyLogProb); off: the "
+                         "reference's serial order, rollout then compute_log_prob")
+    ap.add_argument("--tail-cus", type=int, default=64, help="compute units of the decode tail's stream under --overlap-old on (multiple of 8)")
+    ap.add_argument("--tail-rows", type=int, default=128, help="decode phases of at most this many rows run on the tail stream")
+    ap.add_argument("--no-fp8-leg", action="store_true",
+                    help="skip the short BASELINE-config-#5 leg (G = 16, 896x896, 32 prompts/GPU, MX-fp8 projections forward + dX + dW; 2 steps + 1 "
+                         "warm-up in a child process before this process touches the GPU) that the default command reports as `cfg5_fp8`")
+    ap.add_argument("--gemm-table", default=None, metavar="PATH",
+                    help="write the per-(form, M, N, K) table of the event-timed GEMM launches of the timed region as JSON (the five costliest "
+                         "shapes are in the line's roofline.by_shape either way)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/contract check without a GPU: ranks rendezvous over gloo, time K trivial steps, rank 0 prints the JSON line")
     return ap.parse_args()
@@ -104,6 +116,54 @@ def maybe_spawn(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
+
+def gemm_shape_table(ev_ms, ev_units, ev_tags):
+    """Event-timed GEMM launches of the timed region grouped by (form, epilogue flags, M, N, K): launches, total ms, TF/s.  Rows sorted by
+    the time a shape would save at the class's best rate (where the in-situ loss sits)."""
+    from spatialthinker_amd import ops
+    rows = {}
+    for ms, u, t in zip(ev_ms.tolist(), ev_units.tolist(), ev_tags.tolist()):
+        r = rows.setdefault(int(t), [0, 0.0, 0.0])
+        r[0] += 1; r[1] += ms; r[2] += u
+    out = []
+    for t, (n, ms, u) in rows.items():
+        d = ops.gemm_tag_decode(t)
+        d.update(launches=n, ms=round(ms, 3), tflops=round(u / (ms * 1e-3) / 1e12, 1) if ms > 0 else None)
+        out.append(d)
+    out.sort(key=lambda d: -d["ms"])
+    return out
+
+
+def fp8_leg(a):
+    """BASELINE config #5's per-GPU shape in its own arithmetic (fp8 MFMA), as a short leg of the DEFAULT command so that the driver's bench
+    witnesses it: a CHILD process — started before this process initialises the GPU, so it finds the whole HBM and is
+    never an exec from a GPU process — runs `bench.py --dtype fp8 --fp8-dgrad --fp8-wgrad --rollouts 16 --prompts-per-gpu 32 --image
+    896x896 --steps 2 --warmup 1`; its line is condensed into {value, dtype, roofline {frac, peak}, timing_s}.  A throughput mode, not
+    a parity mode; the headline `value` stays the bf16 config #3 step.  Returns None when the leg does not apply."""
+    default_workload = (a.model == "7b" and a.dtype == "bf16" and a.gpus <= 1 and not a.image and a.rollouts == 8 and a.prompts_per_gpu == 64
+                        and not a.worst_case and not a.responses_at_cap and not a.prompt_tokens and not a.old_from_rollout and not a.master_fp32)
+    if a.no_fp8_leg or not default_workload or "RANK" in os.environ:
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp8", "--fp8-dgrad", "--fp8-wgrad", "--rollouts", "16", "--prompts-per-gpu", "32",
+           "--image", "896x896", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp8-leg"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if p.returncode != 0 or not line:
+            return {"error": f"child exited with {p.returncode}", "stderr_tail": p.stderr[-400:]}
+        d = json.loads(line[-1])
+    except Exception as e:                                    # the leg must never cost the headline measurement
+        return {"error": f"{type(e).__name__}: {e}"}
+    cls = [c for c in d.get("roofline_classes", []) if c and c.get("peak") == 5000.0]
+    r8 = cls[0] if cls else (d.get("roofline") if (d.get("roofline") or {}).get("peak") == 5000.0 else None)
+    return {"value": d.get("value"), "unit": d.get("unit"), "dtype": d.get("dtype"), "steps": d.get("steps"), "warmup": d.get("warmup"),
+            "ms_per_step": d.get("ms_per_step"), "config": d.get("config"), "timing_s": d.get("timing_s"),
+            "roofline": None if r8 is None else {k: r8.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_timed", "avg_launch_ms")},
+            "roofline_bf16_gemm_frac": (d.get("roofline") or {}).get("frac"), "peak_mem_gb": d.get("peak_mem_gb"),
+            "command": " ".join(cmd[1:]), "wall_s": time.perf_counter() - t0,
+            "note": "throughput mode (MX-fp8 LM projections forward + input / weight gradients; decode, attention, lm_head, ViT stay bf16), not a parity mode"}
 
 
 def through_api(a):
@@ -573,6 +633,7 @@ def main():
     maybe_spawn(a)
     if a.dry_run:
         return dry_run(a)
+    cfg5 = fp8_leg(a)                         # child process, BEFORE this process touches the GPU
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == max(1, a.gpus), f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
@@ -655,13 +716,21 @@ def main():
             lens_in = np.full(B, R, dtype=np.int64)
         staged.append((batch_in, lens_in))
 
+    overlap_old = a.overlap_old == "on" and not a.old_from_rollout and not a.ranks_share_gpu
+    overlap_stats = {"early_rows": 0, "feed_host_s": 0.0}
+
     def one_step(step_idx, timed):
         (ids, mask, pos, pix, grids), lens = staged[step_idx]
         tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
         t0 = tick()
+        early, extra = None, {}
+        if overlap_old:
+            n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+            early = actor.early_log_prob(ids, mask, pos, G, R, temperature, eos_id, side_stream=ops.cu_range_stream(a.tail_cus, n_cu - a.tail_cus))
+            extra = dict(on_finished=early.feed, tail_stream=ops.cu_range_stream(0, a.tail_cus), tail_rows=a.tail_rows)
         resp, prompt_cache = gen.generate(ids, mask, pos, n=G, max_new_tokens=R, temperature=temperature, eos_token_id=eos_id,
                                           pad_token_id=pad_id, seed=a.seed * 1000 + step_idx, pixel_values=pix, image_grid_thw=grids,
-                                          forced_lengths=lens, return_prompt_cache=True, emit_log_probs=a.old_from_rollout)
+                                          forced_lengths=lens, return_prompt_cache=True, emit_log_probs=a.old_from_rollout, **extra)
         t1 = tick()
         # ---- the (B, P+R) batch of vllm_rollout_spmd.py:144-188, assembled by the worker's own post-processing
         out = assemble_rollout_batch(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), resp.cpu(), G, eos_id)
@@ -675,9 +744,14 @@ def main():
         rewards = torch.zeros(B, R)
         rewards[torch.arange(B), rmask.sum(1) - 1] = scores
         t2 = tick()
-        data["old_log_probs"] = actor.compute_log_prob(data, temperature, prompt_cache=prompt_cache,
-                                                       use_rollout_log_probs=a.old_from_rollout)   # as FSDPWorker.compute_log_probs
-        del prompt_cache
+        if early is not None:
+            data["old_log_probs"] = early.finish(data, prompt_cache)       # most of it ran beside the decode tail; the rest runs here
+            overlap_stats["early_rows"] += sum(len(s_) for s_ in early.sets[:-1]) if len(early.sets) > 1 else 0
+            overlap_stats["feed_host_s"] += early.fed_s
+        else:
+            data["old_log_probs"] = actor.compute_log_prob(data, temperature, prompt_cache=prompt_cache,
+                                                           use_rollout_log_probs=a.old_from_rollout)   # as FSDPWorker.compute_log_probs
+        del prompt_cache, early
         t3 = tick()
         data["ref_log_probs"] = ref.compute_log_prob(data, temperature)
         t4 = tick()
@@ -710,7 +784,10 @@ def main():
                                                  prefix_cached=cached)
             f_exp = executed(ref.last_plan["experience"])
             f_upd = executed(actor.last_plan["update"])
-            f_old = executed(actor.last_plan["experience"], cached=actor.last_prompt_cache_hit) if actor.last_plan["experience"] else 0.0   # prompt K/V re-used from the rollout; 0 when the rollout's own log-probs were used
+            if overlap_old:                                                  # sets of finished samples, prompts cached: the responses' tokens + context once
+                f_old = cfg.flops_forward_grouped([(int(plen[r // G]), [rlen[r]]) for r in range(B)], [], logit_rows=int(rmask.sum()), prefix_cached=True)
+            else:
+                f_old = executed(actor.last_plan["experience"], cached=actor.last_prompt_cache_hit) if actor.last_plan["experience"] else 0.0   # prompt K/V re-used from the rollout; 0 when the rollout's own log-probs were used
             flops["old"] += f_old; flops["ref"] += f_exp; flops["update"] += 3 * f_upd
             flops["reference_formulation"] = flops.get("reference_formulation", 0.0) + 5 * f_ref
             tokens_total[0] += int(mask_f.sum())
@@ -766,9 +843,15 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     prof = {}
+    gemm_shapes = None
     for k in classes:
         seen = ops.prof_seen(k)
-        n_launch, ms, units = ops.prof_read(k)
+        if k == ops.K_GEMM:                       # per-launch view: the per-(form, M, N, K) table behind `roofline`
+            ev_ms, ev_units, ev_tags = ops.prof_read_events(k)
+            n_launch, ms, units = len(ev_ms), float(ev_ms.sum(dtype=np.float64)), float(ev_units.sum())
+            gemm_shapes = gemm_shape_table(ev_ms, ev_units, ev_tags)
+        else:
+            n_launch, ms, units = ops.prof_read(k)
         ops.prof_disable(k)
         prof[k] = (seen, n_launch, ms, units)
     phase_max = dict(phase)
@@ -797,6 +880,12 @@ def main():
                     "avg_launch_ms": ms / max(n_launch, 1)}
         dec_traffic = None
         main_roof = roof(ops.K_GEMM)
+        if gemm_shapes:
+            main_roof["by_shape"] = gemm_shapes[:6]          # the costliest (form, M, N, K) groups of the sampled launches; --gemm-table writes all
+            if a.gemm_table:
+                os.makedirs(os.path.dirname(os.path.abspath(a.gemm_table)), exist_ok=True)
+                with open(a.gemm_table, "w") as f:
+                    json.dump({"command": " ".join(sys.argv), "stride": PROF_STRIDE, "class_tflops": main_roof["achieved"], "shapes": gemm_shapes}, f, indent=1)
         main_roof["algorithmic_bytes_per_launch"] = ops.gemm_bytes["bytes"] / max(1, ops.gemm_bytes["launches"])
         main_roof["algorithmic_bytes"] = "operands once + result once (+ residual / fp32 read-modify-write), averaged over the class's launches"
         # HBM traffic per launch of the GEMM class: a PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
@@ -861,6 +950,9 @@ def main():
             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             "peak_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
             "reserved_gb_after_each_step": reserved_trace,
+            "overlap_old": ({"mode": f"old-policy log-probs of finished samples on CUs [{a.tail_cus}, all) beside decode phases of <= {a.tail_rows} rows on CUs [0, {a.tail_cus})",
+                             "rows_computed_during_the_rollout_per_step": overlap_stats["early_rows"] / max(1, a.steps + a.warmup),
+                             "feed_host_s_per_step": overlap_stats["feed_host_s"] / max(1, a.steps + a.warmup)} if overlap_old else None),
             "passes_per_step": {"update": update_passes, "old": len(actor.last_plan.get("experience", [])),
                                 "ref": len(ref.last_plan.get("experience", []))},
             "rollout_prompt_chunks": len(getattr(gen, "last_chunks", [(0, npr)])), "prompt_cache_hit": bool(actor.last_prompt_cache_hit),
@@ -873,6 +965,8 @@ def main():
             "roofline_classes": [roof(k) for k in classes if k != ops.K_GEMM and prof[k][1] > 0],
             "roofline_decode": dec,
         }
+        if cfg5 is not None:
+            out["cfg5_fp8"] = cfg5
         if world == 1 and not a.no_cpu_baseline and not tiny:
             out["cpu_baseline"] = cpu_baseline()
         elif tiny and not a.no_cpu_baseline:

@@ -35,6 +35,11 @@ enum { ST_K_GEMM = 0, ST_K_ATTN_FWD = 1, ST_K_ATTN_BWD = 2, ST_K_LOGPROB = 3, ST
 int st_prof_enable(int klass, int max_events);
 int st_prof_read(int klass, int* launches, double* total_ms, double* total_units);
 int st_prof_disable(int klass);
+/* per-launch view of the sampled launches (round 5: the per-shape table behind `roofline`, profiles/r05_gemm_shapes.json): duration in
+ * ms, algorithmic units and the launcher's shape tag — GEMM class: form (0 NT, 1 NN, 2 TN, 3 SwiGLU) << 60 | epilogue flags (1 bias,
+ * 2 residual, 4 fp32 out, 8 accumulate) << 56 | K << 36 | N << 18 | M; 0 for the other classes.  Fills up to `max` entries, returns the
+ * sampled count in *n_out, resets the class like st_prof_read. */
+int st_prof_read_events(int klass, int max, float* ms_out, double* units_out, unsigned long long* tags_out, int* n_out);
 /* sample every stride-th launch of the class (default 1): max_events then spans stride * max_events launches of a long run */
 int st_prof_set_stride(int klass, int stride);
 /* algorithmic units (flops / bytes) of the NEXT launch of the class, for launchers whose work depends on device-side ranges
@@ -392,8 +397,11 @@ int st_sample(const st_bf16* logits, int64_t ldl, int B, int V, float temperatur
  * st_sample_partials: st_sample without its last stage — the 16 partial (value, index) pairs per row stay in scratch (B*33 floats).
  * st_decode_step, per row b (one workgroup): token = argmax of the partials (forced_token where forced_len[b] == gen_len[b] + 1);
  *   if active[b]: out_tokens[b, min(gen_len[b], R-1)] = token;  active[b] &= !(gen_len[b] + 1 >= R || token in eos_ids (unless ignore_eos));
- *   tok_out[b] = token;  slot_out[b] = min(gen_len[b], R-1) (cache slot of this token's K/V);  gen_len[b] += 1;
- *   ke_gen[c*B + b] = clamp(k_base[b] + slot + 1, kb_gen[c*B + b], kb_gen[c*B + b] + chunk_keys) for the n_chunks generated-key chunks;
+ *   tok_out[b] = token;  slot_out[b] = min(gen_len[b], R-1) (cache slot of this token's K/V);  gen_len[b] += 1 while the row was active
+ *   on entry (round 5: a finished row keeps its response length);
+ *   ke_gen[c*B + b] = clamp(k_base[b] + slot + 1, kb_gen[c*B + b], kb_gen[c*B + b] + chunk_keys) for the n_chunks generated-key chunks
+ *   of a row that was active on entry, kb_gen[c*B + b] (EMPTY range) otherwise — a finished row stays in the GEMM tiles until the phase
+ *   is re-batched, but the attention launch streams no generated K/V for it any more (round 5);
  *   cos_out/sin_out[b, :] = M-RoPE table row of pos[:, b] (as st_mrope_table), then pos[:, b] += 1;  x_out[b, :H] = embed[token, :H].
  * Round 4, optional (lse_partials / logp_out non-NULL): the rollout's OWN log-probabilities.  st_sample_partials additionally leaves, per row
  *   and split, (max, sum exp(z - max)) of the unfiltered z = logit / T in lse_partials (B*32 floats); st_decode_step then writes
@@ -408,6 +416,16 @@ int st_decode_step(const float* sample_scratch, const int32_t* forced_len, int32
                    const float* inv_freq, int D, int s0, int s1, int s2, float* cos_out, float* sin_out, const st_bf16* embed,
                    int64_t ld_embed, st_bf16* x_out, int64_t ldx, int H, int B, const float* lse_partials, const st_bf16* logits, int64_t ldl,
                    float temperature, float* logp_out, st_stream_t stream);
+
+/* ---- CU-partitioned streams (round 5: the decode tail of the rollout runs beside the old-policy log-prob pass of the finished samples;
+ *      reference phases verl/trainer/ray_trainer.py:585-640 run one after the other) -----------------------------------------------
+ * st_stream_create_cu_range: a HIP stream whose kernels run only on compute units [first_cu, first_cu + n_cus) of the chip's CU-mask
+ * bit order (hipExtStreamCreateWithCUMask).  On MI355X bit i is slot i / 8 of XCD i % 8 (tools/probes/cu_mask_probe.hip), so a range
+ * whose bounds are multiples of 8 takes the same number of CUs from every XCD; two streams on disjoint ranges run side by side without
+ * slowing each other (probe: 64 CUs stream 3.4 TB/s next to 192 CUs at 1.64 PF/s, alone and together).  The handle is a hipStream_t for
+ * every st_* entry's `stream` argument.  st_stream_destroy releases it (the stream must be idle). */
+int st_stream_create_cu_range(int first_cu, int n_cus, st_stream_t* stream_out);
+int st_stream_destroy(st_stream_t stream);
 
 #ifdef __cplusplus
 }

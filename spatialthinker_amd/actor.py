@@ -15,6 +15,7 @@ from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -269,6 +270,138 @@ def _rows(x, sl):
     return x[sl] if x is not None else None
 
 
+def _rollout_rows(prompt_ids, prompt_mask, prompt_pos, responses, eos_token_id) -> Dict[str, torch.Tensor]:
+    """The rows `assemble_rollout_batch` (verl/workers/rollout/hip_rollout.py; reference vllm_rollout_spmd.py:144-188) builds for these
+    samples: response mask = 1 through the first EOS (torch_functional.py:23-33), response position ids last + 1 .. last + R on every
+    M-RoPE row.  Restated here so that the engine does not import the API layer above it; tests compare the two."""
+    R = responses.shape[1]
+    eos = torch.as_tensor([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id), dtype=responses.dtype)
+    hit = torch.isin(responses, eos).long()
+    rmask = (hit.cumsum(1) - hit).eq(0).to(prompt_mask.dtype)
+    delta = torch.arange(1, R + 1).view(1, 1, -1)
+    return {"input_ids": torch.cat([prompt_ids, responses], -1), "attention_mask": torch.cat([prompt_mask, rmask], -1), "response_mask": rmask,
+            "position_ids": torch.cat([prompt_pos, prompt_pos[..., -1:] + delta], -1)}
+
+
+class EarlyLogProb:
+    """The old-policy log-prob pass of a GRPO step, started before the rollout has ended (round 5).
+
+    The reference runs rollout and `compute_log_probs` one after the other (verl/trainer/ray_trainer.py:585-640).  Here the last ~400 of a
+    rollout's ~900 decode iterations run <= 128 live rows — weight streaming with the matrix pipes idle — while the log-prob pass of the
+    samples that have already finished is MFMA-bound and needs nothing but their tokens and the prompt K/V of the prefill.  The generator
+    reports the finishers of every decode phase (Generator.generate(on_finished=self.feed)); `feed` stages their rows exactly as
+    `assemble_rollout_batch` will (same response mask, same position ids) and issues Qwen25VL.log_probs_cached for them on `side_stream`, a
+    CU-range stream complementary to the decode tail's (ops.cu_range_stream): both streams keep to their compute units and neither slows
+    the other (tools/probes/cu_mask_probe.hip).  `finish` computes the samples of the last phase, waits for the side stream and returns the
+    (N, R) tensor compute_log_prob would have returned.
+
+    Same arithmetic, different grouping: a pass holds the finishers of ONE phase (cut by the token budget), not consecutive rows.  The
+    log-prob of a row does not depend on the rows it is packed with up to the summation order of the GEMM tail split, so
+    `PolicyEngine.compute_log_prob_in_sets` — the same sets, processed serially after the rollout — is the bit-identical serial form
+    (tests/test_gpu_rollout.py::test_early_old_log_probs_are_bit_identical_to_the_serial_order)."""
+
+    def __init__(self, engine: "PolicyEngine", input_ids, attention_mask, position_ids, n: int, response_length: int, temperature: float,
+                 eos_token_id, side_stream=None):
+        self.e, self.n, self.R, self.t, self.eos, self.side = engine, int(n), int(response_length), float(temperature), eos_token_id, side_stream
+        self.ids = torch.as_tensor(_to_np(input_ids))
+        self.mask = torch.as_tensor(_to_np(attention_mask))
+        pos = torch.as_tensor(_to_np(position_ids))
+        self.pos = pos if pos.dim() == 3 else pos[:, None, :].repeat(1, 3, 1)
+        self.done: List[tuple] = []          # (sample ids, responses used (cpu), log-probs (device), stream it was issued on)
+        self.sets: List[np.ndarray] = []     # the sets in processing order (the serial re-run of the bit-identity test)
+        self.tokens_per_pass = int(os.environ.get("ST_TOKENS_EARLY", "32768"))
+        self.rows_per_pass = 256
+        self.fed_s = 0.0                     # host seconds spent inside feed (staging + launches)
+        self._keep: list = []
+
+    # -- one set of samples: rows as assemble_rollout_batch builds them, passes by the token budget, log_probs_cached per pass
+    def _process(self, sample_ids: np.ndarray, resp_cpu: torch.Tensor, cache: dict, compute_stream=None, copy_stream=None):
+        """compute_stream / copy_stream (the hook's case): every host -> device copy of the staging runs on `copy_stream`, where it waits
+        for nothing but the copies before it — on the compute stream a copy from pageable memory would hold the HOST until the passes
+        queued there have finished (first version: 2.3 s of host time per rollout inside the hook, the decode loop starved meanwhile);
+        the passes themselves are then queued on `compute_stream` in one go."""
+        pr = torch.as_tensor(sample_ids // self.n)
+        rows = _rollout_rows(self.ids[pr], self.mask[pr], self.pos[pr], resp_cpu, self.eos)
+        r_len = rows["response_mask"].sum(1).numpy().astype(np.int64)
+        cuts, a = [], 0
+        while a < len(sample_ids):
+            b, tok = a + 1, int(r_len[a])
+            while b < len(sample_ids) and b - a < self.rows_per_pass and tok + int(r_len[b]) <= self.tokens_per_pass:
+                tok += int(r_len[b]); b += 1
+            cuts.append(slice(a, b))
+            a = b
+        cur = torch.cuda.current_stream()
+        cs, ks = copy_stream or cur, compute_stream or cur
+        with torch.cuda.stream(cs):
+            dbs = [self.e.model.stage_responses(rows["input_ids"][sl], rows["attention_mask"][sl], rows["position_ids"][sl], self.R,
+                                                (sample_ids[sl] // self.n), cache["p_off"]) for sl in cuts]
+        if ks is not cs:
+            ks.wait_stream(cs)
+        with torch.cuda.stream(ks):
+            lp = torch.cat([self.e.model.log_probs_cached(db, cache, self.t) for db in dbs], 0)
+        self._keep.append(dbs)               # staged on another stream than the one that reads them: alive until finish()
+        return lp
+
+    def feed(self, sample_ids: np.ndarray, out: torch.Tensor, event, cache: dict):
+        """Generator hook: rows `sample_ids` of `out` are final once `event` has passed."""
+        t0 = time.perf_counter()
+        sample_ids = np.asarray(sample_ids, dtype=np.int64)
+        st = self.side if self.side is not None else torch.cuda.current_stream()
+        cs = self._copy_stream() if self.side is not None else st
+        cs.wait_event(event)
+        with torch.cuda.stream(cs):
+            resp = out[torch.as_tensor(sample_ids, device=out.device)].cpu()       # holds the host until `event` only (passed long ago)
+        with ops.scratch_slot(1 if self.side is not None else 0):
+            lp = self._process(sample_ids, resp, cache, compute_stream=st, copy_stream=cs)
+        self.done.append((sample_ids, resp, lp, st))
+        self.sets.append(sample_ids)
+        self.fed_s += time.perf_counter() - t0
+
+    _copy = {}
+
+    def _copy_stream(self):
+        dev = torch.cuda.current_device()
+        if dev not in EarlyLogProb._copy:
+            EarlyLogProb._copy[dev] = torch.cuda.Stream()
+        return EarlyLogProb._copy[dev]
+
+    @torch.no_grad()
+    def finish(self, data: Dict[str, Any], cache: Optional[dict]) -> torch.Tensor:
+        """(N, R) old-policy log-probs for `data` (the assembled rollout batch).  Rows the hook never saw (the last phase's finishers;
+        everything when the generator ran without hooks) are computed here; fed rows are checked against data["responses"] and
+        recomputed through the ordinary pass on any mismatch (then nothing of the early work is used)."""
+        e = self.e
+        N = data["input_ids"].shape[0]
+        resp_all = torch.as_tensor(data["responses"]).cpu()
+        ok = cache is not None and "kp" in cache and e._cache_matches(data, cache, self.R)
+        for ids_, resp, _, _ in self.done:
+            ok = ok and bool(torch.equal(resp_all[torch.as_tensor(ids_)], resp))
+        if not ok:
+            self.done, self.sets = [], []
+            return e.compute_log_prob(data, self.t, prompt_cache=cache)
+        seen = np.zeros(N, dtype=bool)
+        for ids_, *_ in self.done:
+            seen[ids_] = True
+        rest = np.nonzero(~seen)[0].astype(np.int64)
+        cur = torch.cuda.current_stream()
+        if len(rest):
+            lp = self._process(rest, resp_all[torch.as_tensor(rest)], cache)
+            self.done.append((rest, None, lp, cur))
+            self.sets.append(rest)
+        out = torch.zeros(N, self.R, dtype=F32, device=e.store.device)
+        for ids_, _, lp, st in self.done:
+            if st is not cur:
+                cur.wait_stream(st)
+            out.index_copy_(0, torch.as_tensor(ids_, device=out.device), lp)
+        e.last_prompt_cache_hit, e.last_log_prob_source = True, "forward (finished samples during the decode tail)"
+        e.last_plan["experience"] = [(int(len(s_)),) for s_ in self.sets]
+        for st in {id(d[3]): d[3] for d in self.done}.values():
+            st.synchronize()                 # the staged batches were allocated on the copy stream and read on the side stream: nothing of
+        self.done, self._keep = [], []       # them may return to the allocator while a pass still runs
+        release_cached_blocks()
+        return out
+
+
 def _to_np(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
@@ -435,6 +568,28 @@ class PolicyEngine:
         out = torch.cat(outs, 0)
         del outs, b
         release_cached_blocks()
+        return out
+
+    def early_log_prob(self, input_ids, attention_mask, position_ids, n: int, response_length: int, temperature: float, eos_token_id,
+                       side_stream=None) -> "EarlyLogProb":
+        """Old-policy log-probs of the rollouts that have FINISHED, computed while the decode tail of the same rollout still runs
+        (EarlyLogProb): hand its .feed to Generator.generate(on_finished=...), call .finish(data, prompt_cache) where compute_log_prob
+        would be called."""
+        return EarlyLogProb(self, input_ids, attention_mask, position_ids, n, response_length, temperature, eos_token_id, side_stream)
+
+    @torch.no_grad()
+    def compute_log_prob_in_sets(self, data: Dict[str, Any], temperature: float, prompt_cache: dict, sets, eos_token_id, n: int) -> torch.Tensor:
+        """The serial form of EarlyLogProb: the same sets of rows, one after the other on the current stream, after the rollout."""
+        R = data["responses"].shape[1]
+        P = data["input_ids"].shape[1] - R
+        early = EarlyLogProb(self, data["input_ids"][::n, :P], data["attention_mask"][::n, :P], data["position_ids"][::n, ..., :P], n, R,
+                             temperature, eos_token_id, None)
+        resp_all = torch.as_tensor(data["responses"]).cpu()
+        out = torch.zeros(data["input_ids"].shape[0], R, dtype=F32, device=self.store.device)
+        for s_ in sets:
+            s_ = np.asarray(s_, dtype=np.int64)
+            if len(s_):
+                out.index_copy_(0, torch.as_tensor(s_, device=out.device), early._process(s_, resp_all[torch.as_tensor(s_)], prompt_cache))
         return out
 
     def _cache_matches(self, data: Dict[str, Any], cache: dict, R: int) -> bool:

@@ -10,8 +10,10 @@ const char* st_arch(void) { return "gfx950"; }
 int st_prof_enable(int klass, int max_events) {
     if (klass < 0 || klass >= ST_K_COUNT || max_events <= 0) return ST_EINVAL;
     StProf& p = g_prof[klass];
-    if (p.ev) { for (int i = 0; i < 2 * p.cap; ++i) hipEventDestroy(p.ev[i]); delete[] p.ev; }
+    if (p.ev) { for (int i = 0; i < 2 * p.cap; ++i) hipEventDestroy(p.ev[i]); delete[] p.ev; delete[] p.unit_each; delete[] p.tags; }
     p.ev = new hipEvent_t[2 * max_events];
+    p.unit_each = new double[max_events];
+    p.tags = new unsigned long long[max_events];
     for (int i = 0; i < 2 * max_events; ++i) hipEventCreate(&p.ev[i]);
     p.cap = max_events; p.n = 0; p.units = 0.0; p.pending = 0.0; p.seen = 0; p.stride = 1; p.on = true;
     return 0;
@@ -44,6 +46,43 @@ int st_prof_read(int klass, int* launches, double* total_ms, double* total_units
     if (total_units) *total_units = p.units;
     p.n = 0; p.units = 0.0; p.seen = 0;
     return 0;
+}
+/* per-launch view of the sampled launches since st_prof_enable / the last read: duration (ms), algorithmic units and the launcher's
+ * shape tag (GEMM class: st_prof_tag = form | epilogue flags | M, N, K; 0 for classes that give none).  Synchronises the events, fills
+ * up to `max` entries, returns the number of sampled launches in *n_out and resets the class like st_prof_read. */
+int st_prof_read_events(int klass, int max, float* ms_out, double* units_out, unsigned long long* tags_out, int* n_out) {
+    if (klass < 0 || klass >= ST_K_COUNT || max < 0 || !n_out) return ST_EINVAL;
+    StProf& p = g_prof[klass];
+    for (int i = 0; i < p.n; ++i) {
+        float t = 0.f;
+        hipEventSynchronize(p.ev[2 * i + 1]);
+        if (hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) t = 0.f;
+        if (i < max) {
+            if (ms_out) ms_out[i] = t;
+            if (units_out) units_out[i] = p.unit_each[i];
+            if (tags_out) tags_out[i] = p.tags[i];
+        }
+    }
+    *n_out = p.n;
+    p.n = 0; p.units = 0.0; p.seen = 0;
+    return 0;
+}
+int st_stream_create_cu_range(int first_cu, int n_cus, st_stream_t* stream_out) {
+    const int total = st_num_cus();
+    if (!stream_out || first_cu < 0 || n_cus <= 0 || first_cu + n_cus > total) return ST_EINVAL;
+    uint32_t mask[16] = {0};
+    if (total > 512) return ST_EINVAL;
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+    if (e != hipSuccess) return (int)e;
+    *stream_out = (st_stream_t)s;
+    return 0;
+}
+int st_stream_destroy(st_stream_t stream) {
+    if (!stream) return ST_EINVAL;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
 }
 int st_prof_disable(int klass) {
     if (klass < 0 || klass >= ST_K_COUNT) return ST_EINVAL;

@@ -125,12 +125,19 @@ struct StProf {
     hipEvent_t* ev = nullptr;      // 2*cap events
     double units = 0.0;            // algorithmic flops / bytes of the SAMPLED launches
     double pending = 0.0;          // st_prof_hint_units: units of the next launch when the launcher cannot know them (attention)
+    double* unit_each = nullptr;   // cap entries: units of sampled launch i (st_prof_read_events)
+    unsigned long long* tags = nullptr;   // cap entries: the launcher's shape tag of sampled launch i (st_prof_tag), 0 when it gives none
 };
+// shape tag of a GEMM launch: form (0 = NT, 1 = NN, 2 = TN, 3 = SwiGLU) | epilogue flags (1 bias, 2 residual, 4 fp32 out, 8 accumulate) | M, N, K
+static inline unsigned long long st_prof_tag(int form, int flags, int M, int N, int K) {
+    return ((unsigned long long)(form & 15) << 60) | ((unsigned long long)(flags & 15) << 56) | ((unsigned long long)(K & 0x3ffff) << 36) |
+           ((unsigned long long)(N & 0x3ffff) << 18) | (unsigned long long)(M & 0x3ffff);
+}
 extern StProf g_prof[ST_K_COUNT];
 
 struct StProfScope {
     int k; hipStream_t s; bool live;
-    StProfScope(int klass, hipStream_t st, double units) : k(klass), s(st), live(false) {
+    StProfScope(int klass, hipStream_t st, double units, unsigned long long tag = 0) : k(klass), s(st), live(false) {
         StProf& p = g_prof[k];
         if (p.on) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -138,7 +145,11 @@ struct StProfScope {
             if (cs == hipStreamCaptureStatusNone) {
                 const bool pick = (p.seen % p.stride) == 0 && p.n < p.cap;      // every stride-th launch: the cap spans the whole run
                 p.seen++;
-                if (pick) { live = true; hipEventRecord(p.ev[2 * p.n], s); p.units += units > 0.0 ? units : p.pending; }
+                if (pick) {
+                    live = true; hipEventRecord(p.ev[2 * p.n], s);
+                    const double u = units > 0.0 ? units : p.pending;
+                    p.units += u; p.unit_each[p.n] = u; p.tags[p.n] = tag;
+                }
             }
             p.pending = 0.0;
         }

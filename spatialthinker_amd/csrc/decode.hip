@@ -467,15 +467,19 @@ __global__ __launch_bounds__(256) void decode_step_kernel(const float* __restric
         bool stop = j + 1 >= R;                              // the length cap ends a sample like an EOS
         if (!ignore_eos)
             for (int e = 0; e < n_eos; ++e) stop = stop || ((int64_t)besti == eos_ids[e]);
-        active[row] = (live && !stop) ? 1 : 0;
+        const bool live_next = live && !stop;
+        active[row] = live_next ? 1 : 0;
         tok_out[row] = besti;
         slot_out[row] = col;
-        gen_len[row] = j + 1;
+        gen_len[row] = live ? j + 1 : j;                     // a finished row keeps its response length (round 5: it used to keep counting)
+        // A finished row stays in the phase's GEMM tiles until the phase is re-batched, but its output is never read again: its generated-key
+        // ranges are EMPTY from here on, so the attention launch streams no K/V for it (round 5; in the bench's 512-row phase the finished
+        // rows were 15-17 % of the generated-K/V traffic, 27-69 % in the later phases).  Its prompt partial keeps the merged row finite.
         const int kend = k_base[row] + col + 1;              // one past the cache row this token's K/V will occupy
         for (int c = 0; c < n_chunks; ++c) {
             const int kb = kb_gen[c * B + row];
             int ke = kb + chunk_keys < kend ? kb + chunk_keys : kend;
-            ke_gen[c * B + row] = ke > kb ? ke : kb;
+            ke_gen[c * B + row] = (live && ke > kb) ? ke : kb;   // (the forward of a row's LAST token still attends: tests tap its logits)
         }
         s_tok = besti;
     }

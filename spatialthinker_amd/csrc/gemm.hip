@@ -359,7 +359,8 @@ extern "C" int st_gemm_nt(const st_bf16* A, int64_t lda, const st_bf16* B, int64
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bool hb = bias != nullptr, hr = residual != nullptr;
-    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);   // MFMA-bound class only (roofline.achieved)
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K,     // MFMA-bound class only (roofline.achieved)
+                   st_prof_tag(0, (hb ? 1 : 0) | (hr ? 2 : 0) | (out_f32 ? 4 : 0) | (accumulate ? 8 : 0), M, N, K));
     // tile choice (tools/gemm_shapes.py on MI355X, all 12 fwd/dX/dW shapes of a 7B layer): the 256x256 tile (8 waves, 128 KiB LDS,
     // 128 flop/B of L2 traffic) wins or ties from ~0.5 workgroups per CU upwards (dW of the 3584x3584 projection, 196 tiles:
     // 1098 vs 926 TF); only smaller problems fill the chip better with 128x128 tiles at 2 workgroups/CU.

@@ -12,7 +12,7 @@ extern "C" int st_gemm_nn(const st_bf16* A, int64_t lda, const st_bf16* B, int64
         (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K, st_prof_tag(1, 0, M, N, K));
     if (g_train_variant == 40 && M > 256 && lda < (1 << 22) && ldb < (1 << 22)) return st_gemm_asm4_nn(A, lda, B, ldb, out, ldc, M, N, K, s);   // 32-bit buffer offsets: larger pitches take the 8-wave tile
     return launch_tile_layout<false, true, true, false>(A, lda, B, ldb, out, nullptr, ldc, M, N, K, s);
 }
@@ -24,7 +24,7 @@ extern "C" int st_gemm_tn(const st_bf16* A, int64_t lda, const st_bf16* B, int64
         ldc < N || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)N * (double)K, st_prof_tag(2, 4 | (accumulate ? 8 : 0), M, N, K));
     if (g_train_variant == 40 && lda < (1 << 22) && ldb < (1 << 22)) return st_gemm_asm4_tn(A, lda, B, ldb, out_f32, ldc, accumulate, M, N, K, s);
     if (accumulate) return launch_tile_layout<true, true, false, true>(A, lda, B, ldb, nullptr, out_f32, ldc, M, N, K, s);
     return launch_tile_layout<true, true, false, false>(A, lda, B, ldb, nullptr, out_f32, ldc, M, N, K, s);

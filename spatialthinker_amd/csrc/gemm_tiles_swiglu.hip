@@ -14,7 +14,7 @@ extern "C" int st_gemm_swiglu(const st_bf16* A, int64_t lda, const st_bf16* gate
         (gu_out && ldgu < 2 * (int64_t)I) || (((uintptr_t)A) & 15) || (((uintptr_t)gate_up_w) & 15))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)(2 * I) * (double)K);
+    StProfScope ps(ST_K_GEMM, s, 2.0 * (double)M * (double)(2 * I) * (double)K, st_prof_tag(3, gu_out ? 1 : 0, M, 2 * I, K));
     if (g_train_variant == 40 && (int64_t)st_cdiv(M, 256) * st_cdiv(I, 128) >= 128 && lda < (1 << 22) && ldb < (1 << 22))
         return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, gu_out, ldgu, m_out, ldm, M, I, K, s);
     return launch_tile_swiglu<256, 256, 4, 2, 2, true>(A, lda, gate_up_w, ldb, m_out, ldm, M, I, K, s, gu_out, ldgu);

@@ -6,6 +6,8 @@ kernels of libst_hip.so on torch's current stream and raises if a tensor is not 
 from __future__ import annotations
 
 import math
+
+import numpy as np
 import os
 from typing import Optional
 
@@ -181,12 +183,46 @@ _SCRATCH_ELEMS = 16 * DECODE_MAX_ROWS * 4608
 _scratch = {}
 
 
+_scratch_slot = [0]
+
+
+class scratch_slot:
+    """`with ops.scratch_slot(1):` — the decode-shaped GEMMs issued inside use their OWN fp32 slab buffer.  The decode tail of a rollout
+    (a replayed hipGraph whose slab buffer is slot 0, fixed at capture) and the log-prob pass of its finished samples run side by side on
+    two CU-partitioned streams (round 5); the pass reaches the same entry with its M <= 256 GEMMs and must not share the slabs."""
+
+    def __init__(self, slot: int):
+        self.slot = int(slot)
+
+    def __enter__(self):
+        self.prev, _scratch_slot[0] = _scratch_slot[0], self.slot
+
+    def __exit__(self, *exc):
+        _scratch_slot[0] = self.prev
+
+
 def _skinny_scratch(device):
-    """fp32 split-K slab buffer [split][M][N] of the decode-shaped GEMM (contents irrelevant between calls)."""
-    key = (device.type, device.index)
+    """fp32 split-K slab buffer [split][M][N] of the decode-shaped GEMM (contents irrelevant between calls); one per scratch_slot."""
+    key = (device.type, device.index, _scratch_slot[0])
     if key not in _scratch:
+        assert not torch.cuda.is_current_stream_capturing(), "the slab buffer must exist before a hipGraph capture (run one eager iteration first)"
         _scratch[key] = torch.empty(_SCRATCH_ELEMS, dtype=F32, device=device)
     return _scratch[key]
+
+
+_cu_streams = {}
+
+
+def cu_range_stream(first_cu: int, n_cus: int) -> "torch.cuda.Stream":
+    """A stream whose kernels run on compute units [first_cu, first_cu + n_cus) only (st_stream_create_cu_range; on MI355X multiples of 8
+    take the same share of every XCD).  Cached per range: the handle lives as long as the process."""
+    import ctypes
+    key = (torch.cuda.current_device(), int(first_cu), int(n_cus))
+    if key not in _cu_streams:
+        h = ctypes.c_void_p(0)
+        lib().st_stream_create_cu_range(int(first_cu), int(n_cus), ctypes.byref(h))
+        _cu_streams[key] = torch.cuda.ExternalStream(h.value)
+    return _cu_streams[key]
 
 
 # (M, N, K) -> (tile variant, split-K count) chosen by autotune_decode_gemm; empty = library defaults everywhere
@@ -719,6 +755,27 @@ def prof_read(klass: int):
     n, ms, units = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
     lib().st_prof_read(klass, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(units))
     return n.value, ms.value, units.value
+
+
+def prof_read_events(klass: int, max_events: int = 400000):
+    """Per-launch view of the sampled launches (st_prof_read_events): (ms float32[n], units float64[n], tags uint64[n]); resets the class.
+    GEMM-class tags decode with gemm_tag_decode()."""
+    import ctypes
+    ms = np.zeros(max_events, dtype=np.float32); units = np.zeros(max_events, dtype=np.float64); tags = np.zeros(max_events, dtype=np.uint64)
+    n = ctypes.c_int(0)
+    lib().st_prof_read_events(klass, max_events, ms.ctypes.data_as(ctypes.c_void_p), units.ctypes.data_as(ctypes.c_void_p),
+                              tags.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n))
+    k = min(n.value, max_events)
+    return ms[:k], units[:k], tags[:k]
+
+
+def gemm_tag_decode(tag: int) -> dict:
+    """st_prof_tag of a GEMM launch -> {form, flags, M, N, K}"""
+    tag = int(tag)
+    form = ("nt", "nn", "tn", "swiglu")[(tag >> 60) & 15] if ((tag >> 60) & 15) < 4 else "?"
+    fl = (tag >> 56) & 15
+    flags = "+".join(n for b, n in ((1, "gu_kept" if form == "swiglu" else "bias"), (2, "residual"), (4, "f32out"), (8, "accumulate")) if fl & b)
+    return {"form": form, "flags": flags, "M": tag & 0x3ffff, "N": (tag >> 18) & 0x3ffff, "K": (tag >> 36) & 0x3ffff}
 
 
 def prof_seen(klass: int) -> int:

@@ -110,6 +110,9 @@ class Generator:
                                        forced_lengths=forced_lengths, **kw)
         outs, lps = [], []
         emit = bool(kw.get("emit_log_probs"))
+        for k_ in ("on_finished", "tail_stream", "tail_rows"):   # the hook's sample ids and prompt cache are per call: a chunked call runs without
+            kw.pop(k_, None)
+        self.last_finish_sets = []
         for (a, b) in chunks:
             outs.append(self.generate_chunk(input_ids[a:b], attention_mask[a:b], position_ids[a:b], n=n, max_new_tokens=max_new_tokens,
                                             return_prompt_cache=False, pixel_values=None if pixel_values is None else pixel_values[a:b],
@@ -119,6 +122,7 @@ class Generator:
                 outs[-1], d = outs[-1]
                 lps.append(d["log_probs"])
         out = torch.cat(outs, 0)
+        self.last_finish_sets = []          # (the chunks' sets hold chunk-local ids)
         if emit:                            # same contract as generate_chunk: (responses, dict) whenever emit is set, with or without
             # return_prompt_cache — no prompt K/V outlives the chunks, but the rollout's own log-probs do
             return out, dict(log_probs=torch.cat(lps, 0), responses=out, temperature=float(kw.get("temperature", 1.0)),
@@ -130,7 +134,8 @@ class Generator:
                        eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
                        image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
                        sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
-                       return_prompt_cache: bool = False, rng_row_offset: int = 0, emit_log_probs: bool = False):
+                       return_prompt_cache: bool = False, rng_row_offset: int = 0, emit_log_probs: bool = False,
+                       on_finished=None, tail_stream=None, tail_rows: int = 128):
         """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
         pixel_values[i] (N_i, 1176) / image_grid_thw[i] (1, 3).  Returns responses (b*n, max_new_tokens) int64 on the
         device, prompt-major, padded with pad_token_id after the first EOS (vllm_rollout_spmd.py:144-147).
@@ -140,7 +145,14 @@ class Generator:
         emit_log_probs (round 4, opt-in): the decode loop also records log softmax(logits / T)[token] of every token it samples —
         log pi_old(a_t | s_t) of the policy that drew it, from the logits the sampler reads anyway (vLLM's `logprobs`).  Returned as
         cache["log_probs"] (b*n, R) fp32 (0 behind the end of a response) with cache["responses"] / ["temperature"] for the identity
-        check of PolicyEngine.compute_log_prob(use_rollout_log_probs=True)."""
+        check of PolicyEngine.compute_log_prob(use_rollout_log_probs=True).
+        on_finished / tail_stream / tail_rows (round 5): the decode tail runs beside other work.  Every time a decode phase ends,
+        on_finished(sample_ids, out, event, prompt_cache) is called for the samples that finished in it — `out` the (b*n, R) response
+        tensor whose rows `sample_ids` are final once `event` (recorded on the phase's stream) has passed, `prompt_cache` the prefill's
+        K/V — after the NEXT phase's first iterations are queued, so the hook's host work (staging a log-prob pass for another stream)
+        hides behind them.  Phases of <= tail_rows rows run on `tail_stream` (a CU-range stream, ops.cu_range_stream): their kernels
+        keep to its compute units and a pass on the complementary range runs at its own speed (tools/probes/cu_mask_probe.hip).
+        self.last_finish_sets records the sets in hook order (the last phase's finishers included, for which no hook runs)."""
         m, c, w = self.m, self.m.cfg, self.m.p.w
         dev = self.m.p.device
         dbg_t = []
@@ -190,6 +202,8 @@ class Generator:
         ev_p1.record()
         mark("prefill (host staging + forward)")
         head = w["embed"] if c.tie_word_embeddings else w["lm_head"]
+        hook_cache = dict(kp=kp, vp=vp, last_h=last_h, p_off=p_off.astype(np.int64), prompt_ids=ids_np, prompt_mask=mask_np, n=n,
+                          weights_version=getattr(self.m.p, "version", 0)) if on_finished is not None else None
         # ---------------- decode state (per SAMPLE, global over the phases below)
         rep = torch.arange(nb, device=dev, dtype=I32).repeat_interleave(n)
         hn, _ = ops.rmsnorm_fwd(ops.rows_gather(last_h, rep), w["final_norm"], c.rms_eps, want_rstd=False)
@@ -218,6 +232,18 @@ class Generator:
         wave = max(1, self.max_decode_batch)
         if self.autotune and wave <= ops.DECODE_MAX_ROWS:
             self._tune_decode(ix.round_up(min(B, wave), 32))
+
+        pending_hooks: list = []                               # (sample ids, event) of finished phases whose on_finished call is still due
+        self.last_finish_sets = []
+
+        hooks_live = [tail_stream is None]                     # with a tail stream the hooks only fire while a phase runs ON it: a pass
+        # on the complementary CU range next to a full-chip phase would push that phase onto the few CUs the pass leaves free
+
+        def run_hooks():
+            while hooks_live[0] and pending_hooks:
+                fin, ev = pending_hooks.pop(0)
+                if on_finished is not None and len(fin):
+                    on_finished(fin, out, ev, hook_cache)
 
         def decode_phase(S_np: np.ndarray, until_half: bool):
             """Decode the samples S_np (sorted ids; they may sit at different response indices) until none is live or — with
@@ -388,10 +414,13 @@ class Generator:
             n_live = Ba
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             len0 = gen_len.sum()
+            len0_rows = gen_len.clone() if fused else None       # fused path: a finished row's length freezes (st_decode_step), see below
             ev0.record()
             done0 = done
             while True:
                 if done % sync_every == 0 or done >= R:
+                    if done > done0:
+                        run_hooks()                                # the iterations queued above cover the hook's host work
                     n_live = int(active.sum().item())
                     if n_live == 0 or (until_half and Bp > 32 and n_live <= Bp // 2):
                         break
@@ -409,7 +438,13 @@ class Generator:
             if steps > 0:
                 kv_row = 2 * width * 2 * L                                   # K and V bytes of one cached position over all layers
                 prompt_ctx = float(sum(int(pe[p_] - pb[p_]) for p_ in pids))
-                gen_ctx = float(len0.item() + gen_len.sum().item()) / 2.0    # mean generated context per iteration, summed over the rows
+                if fused:
+                    # generated K/V the iterations HAD to read: a row attends to its own context only while it is live (finished rows have
+                    # empty key ranges): sum over rows of (mean context while live) x (iterations it was live), per iteration of the phase
+                    l0, l1 = len0_rows.double(), gen_len.double()
+                    gen_ctx = float(((l0 + l1) * 0.5 * (l1 - l0)).sum().item()) / steps
+                else:
+                    gen_ctx = float(len0.item() + gen_len.sum().item()) / 2.0    # mean generated context per iteration, summed over the rows
                 # algorithmic flops of the iterations: every live-or-not row of the phase runs the projections + lm_head (2 flop per weight)
                 # and attends to its prompt + generated context (4 * D flop per (query head, key))
                 row_ctx = float(sum(int(pe[p_] - pb[p_]) * int(c_) for p_, c_ in zip(pids, cnt))) + gen_ctx
@@ -434,13 +469,27 @@ class Generator:
         debug = bool(os.environ.get("ST_GEN_DEBUG"))
         pool = np.zeros(0, dtype=np.int64)
 
+        main_stream = torch.cuda.current_stream()
+        last_stream = [main_stream]
+
         def run(S, until_half):
             if debug:
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-            r = decode_phase(S, until_half)
+            st = tail_stream if (tail_stream is not None and len(S) <= tail_rows) else main_stream
+            if st is not last_stream[0]:
+                st.wait_stream(last_stream[0])                  # the sample-indexed state (out, K/V, pending logits) of the earlier phases
+            hooks_live[0] = tail_stream is None or st is tail_stream
+            with torch.cuda.stream(st):
+                r = decode_phase(S, until_half)
+                ev = torch.cuda.Event()
+                ev.record(st)                                   # `out` holds the final tokens of this phase's finishers from here on
+            last_stream[0] = st
+            fin = np.setdiff1d(S, r)
+            self.last_finish_sets.append(fin)
+            pending_hooks.append((fin, ev))
             if debug:
                 torch.cuda.synchronize()
-                print(f"[gen] phase rows={len(S)} -> survivors={len(r)} in {time.perf_counter() - t0:.3f}s", flush=True)
+                print(f"[gen] phase rows={len(S)} -> survivors={len(r)} in {time.perf_counter() - t0:.3f}s" + (" (tail stream)" if st is not main_stream else ""), flush=True)
             return r
         mark("decode state (K/V buffers of the samples, first logits)")
         for s0 in range(0, B, wave):
@@ -449,6 +498,13 @@ class Generator:
         while len(pool):
             S, pool = np.sort(pool[:wave]), pool[wave:]
             pool = np.concatenate([pool, run(S, len(S) > 32)])
+        if len(pending_hooks) > 1:                              # all but the LAST phase's finishers (those are the caller's, after the rollout)
+            last = pending_hooks.pop()
+            hooks_live[0] = True
+            run_hooks()
+        pending_hooks.clear()
+        if last_stream[0] is not main_stream:
+            main_stream.wait_stream(last_stream[0])
         torch.cuda.synchronize()
         mark("decode phases")
         if dbg_t:

@@ -366,3 +366,57 @@ def test_rollout_recorded_log_probs_match_the_recomputed_old_policy_log_probs(en
     # measured on MI355X: 0.0233 at T = 1, 0.0312 at T = 0.7 — ONE bf16 step of a logit of magnitude 4..8 (2^-5) divided by T: the decode
     # GEMM and the packed-forward GEMM round a logit to neighbouring bf16 values; the bound is 1.3x that
     assert worst < 0.041
+
+
+def test_early_old_log_probs_are_bit_identical_to_the_serial_order(env):
+    """the old-policy log-prob pass of the samples that have FINISHED runs on a CU-range stream while the decode tail of
+    the same rollout runs on the complementary compute units (actor.EarlyLogProb <- Generator.generate(on_finished=...)).
+    (a) the tokens of the rollout do not depend on the hooks / the tail stream;  (b) the hook really computed rows DURING the rollout,
+    in several sets;  (c) the result is BIT-IDENTICAL to the same sets processed serially after the rollout (compute_log_prob_in_sets)
+    and (d) equal to the ordinary consecutive-rows pass up to the GEMM summation order (one bf16 step of a logit)."""
+    from spatialthinker_amd import ops
+    from spatialthinker_amd.actor import PolicyEngine
+    from spatialthinker_amd.rollout import Generator
+    from verl.workers.rollout.hip_rollout import assemble_rollout_batch
+    cfg, params, eng, _ = env
+    ids, mask, pos, pix, grids = _prompts()
+    n, R, T = 96, 24, 1.0
+    rs = np.random.RandomState(7)
+    lens = np.clip(rs.normal(12, 5, 2 * n), 2, R).astype(np.int64)
+    actor = PolicyEngine(cfg, eng.p, None)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    tail, side = ops.cu_range_stream(0, 64), ops.cu_range_stream(64, n_cu - 64)
+    kw = dict(n=n, max_new_tokens=R, temperature=T, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID, seed=11, pixel_values=pix,
+              image_grid_thw=grids, forced_lengths=lens, sync_every=2, return_prompt_cache=True)
+    plain, cache0 = Generator(eng).generate(ids, mask, pos, **kw)
+    early = actor.early_log_prob(ids, mask, pos, n, R, T, [tiny.EOS_ID], side_stream=side)
+    gen = Generator(eng)
+    resp, cache = gen.generate(ids, mask, pos, on_finished=early.feed, tail_stream=tail, tail_rows=128, **kw)
+    assert torch.equal(resp, plain)                                                     # (a)
+    fed = [len(s_) for s_ in early.sets]
+    assert len(fed) >= 2 and sum(fed) >= n, fed                                         # (b) several sets, most rows during the rollout
+    out = assemble_rollout_batch(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pos), resp.cpu(), n, [tiny.EOS_ID])
+    data = dict(input_ids=out["input_ids"], attention_mask=out["attention_mask"], position_ids=out["position_ids"], responses=out["responses"])
+    got = early.finish(data, cache)
+    sets = [s_.copy() for s_ in early.sets]
+    assert sorted(np.concatenate(sets).tolist()) == list(range(2 * n))
+    hooked = [s_.tolist() for s_ in gen.last_finish_sets[:-1] if len(s_)]
+    assert [s_.tolist() for s_ in sets[:len(hooked)]] == hooked                         # the hook saw every phase's finishers but the last's
+    serial = actor.compute_log_prob_in_sets(data, T, cache, sets, [tiny.EOS_ID], n)
+    assert torch.equal(got, serial)                                                     # (c)
+    ordinary = actor.compute_log_prob(data, T, prompt_cache=cache)
+    assert actor.last_prompt_cache_hit
+    rm = out["response_mask"].cuda().bool()
+    assert float((got - ordinary)[rm].abs().max()) < 0.04                               # (d)
+    assert float(got[~rm].abs().max()) == 0.0
+    # a response that does not match what the hook saw -> everything is recomputed by the ordinary pass (nothing stale is returned)
+    early2 = actor.early_log_prob(ids, mask, pos, n, R, T, [tiny.EOS_ID], side_stream=side)
+    resp2, cache2 = Generator(eng).generate(ids, mask, pos, on_finished=early2.feed, tail_stream=tail, tail_rows=128, **kw)
+    tampered = dict(data)
+    tampered["responses"] = data["responses"].clone()
+    victim = int(early2.sets[0][0])
+    tampered["responses"][victim, 0] = (tampered["responses"][victim, 0] + 1) % 900
+    tampered["input_ids"] = torch.cat([data["input_ids"][:, :-R], tampered["responses"]], 1)
+    got2 = early2.finish(tampered, cache2)
+    want2 = actor.compute_log_prob(tampered, T, prompt_cache=cache2)
+    assert torch.equal(got2, want2) and early2.sets == []

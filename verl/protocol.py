@@ -294,3 +294,22 @@ def pad_dataproto_to_divisor(data: DataProto, size_divisor: int) -> Tuple[DataPr
 
 def unpad_dataproto(data: DataProto, pad_size: int) -> DataProto:
     return data[:-pad_size] if pad_size else data
+
+
+def all_gather_data_proto(data: DataProto, size: int, group) -> None:
+    """In place: every rank of `group` ends up with the rows of ALL its ranks, rank-major (reference verl/protocol.py:651-689) — the
+    pre-processing step of Ulysses sequence parallelism: the sp ranks of a group must run the SAME rows (each computes a slice of every
+    sequence).  Tensors travel through all_gather on their own device (gloo: host tensors; RCCL: device tensors), objects by
+    all_gather_object."""
+    import torch.distributed as dist
+    if data.batch is not None:
+        out = {}
+        for key in sorted(data.batch.keys()):
+            t = data.batch[key].contiguous()
+            parts = [torch.empty_like(t) for _ in range(size)]
+            dist.all_gather(parts, t, group=group)
+            out[key] = torch.cat(parts, dim=0)
+        data.batch = TensorBatch(out, batch_size=len(data.batch) * size)
+    gathered = [None] * size
+    dist.all_gather_object(gathered, data.non_tensor_batch, group=group)
+    data.non_tensor_batch = {k: np.concatenate([g[k] for g in gathered], axis=0) for k in data.non_tensor_batch}

@@ -89,10 +89,11 @@ def parse():
                     help="TEST MODE for a 1-GPU box: the N ranks of --gpus N all use cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on "
                          "one device).  Runs the real multi-rank step — rank-sharded batches, overlapped gradient exchange on device tensors, "
                          "barrier / max-over-ranks timing, the exchange statistics of the JSON line — with a small model; not a scaling measurement")
-    ap.add_argument("--overlap-old", default="on", choices=["on", "off"],
-                    help="on (default): the old-policy log-prob pass of the samples that have finished runs on a CU-range stream WHILE the decode "
-                         "tail of the rollout (phases of <= --tail-rows rows) runs on the complementary compute units (actor.EarlyLogProb); off: the "
-                         "reference's serial order, rollout then compute_log_prob")
+    ap.add_argument("--overlap-old", default="off", choices=["on", "off"],
+                    help="on: the old-policy log-prob pass of the samples that have finished runs on a CU-range stream WHILE the decode tail of the "
+                         "rollout (phases of <= --tail-rows rows) runs on the complementary compute units (actor.EarlyLogProb) — bit-identical "
+                         "results, measured SLOWER on MI355X (profiles/r05_notes.md: the two streams share every XCD's L2 and the fabric; gen + old "
+                         "12.35-12.40 s vs 11.99 s serial), hence off (default): the reference's serial order, rollout then compute_log_prob")
     ap.add_argument("--tail-cus", type=int, default=64, help="compute units of the decode tail's stream under --overlap-old on (multiple of 8)")
     ap.add_argument("--tail-rows", type=int, default=128, help="decode phases of at most this many rows run on the tail stream")
     ap.add_argument("--no-fp8-leg", action="store_true",

@@ -105,9 +105,14 @@ class GradReducer:
     first slice sent .. gradients final — and (b) the part of it the compute stream spends inside finish() (what the overlap did NOT
     hide); stats() reads the events of the steps finished so far."""
 
-    def __init__(self, grad: torch.Tensor, world: int, group=None, bucket_elems: int = 1 << 27, mode: str = "allreduce", payload: str = "fp32"):
+    def __init__(self, grad: torch.Tensor, world: int, group=None, bucket_elems: int = 1 << 27, mode: str = "allreduce", payload: str = "fp32",
+                 mean_over: Optional[int] = None):
         assert mode in ("allreduce", "reduce_scatter") and payload in ("fp32", "bf16"), (mode, payload)
         self.grad, self.world, self.pg, self.bucket = grad, world, group, max(1, int(bucket_elems))
+        # the exchange SUMS over all `world` ranks and divides by `mean_over`: the data-parallel replicas (= world, FSDP's averaged
+        # reduce-scatter) — or world / sp under Ulysses sequence parallelism, where the sp ranks of a group hold partial sums over their
+        # token slices of the SAME rows (what the reference reaches with Gather's grad_scaler, verl/utils/ulysses.py:227-235)
+        self.mean_over = int(mean_over) if mean_over else world
         self.mode, self.payload = mode, payload
         self.sent: List[tuple] = []
         self.works: list = []
@@ -242,7 +247,7 @@ class GradReducer:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         self.sent, self.works, self.early_elems = [], [], 0
-        self.grad.mul_(1.0 / self.world)                          # FSDP reduce-scatter averages over ranks
+        self.grad.mul_(1.0 / self.mean_over)                      # FSDP reduce-scatter averages over the data-parallel ranks
         self._timers.append((self._t_first, t_begin, self._mark(), early))
         self._t_first = None
 
@@ -409,11 +414,16 @@ def _to_np(x):
 class PolicyEngine:
     """Holds one model replica (actor with optimizer, or frozen reference when hyper is None)."""
 
-    def __init__(self, cfg: VLConfig, store: ParamStore, hyper: Optional[ActorHyper] = None, process_group=None):
+    def __init__(self, cfg: VLConfig, store: ParamStore, hyper: Optional[ActorHyper] = None, process_group=None, sp_group=None):
         self.cfg, self.store, self.h = cfg, store, hyper
         self.model = Qwen25VL(cfg, store)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # Ulysses sequence parallelism (worker.actor.ulysses_sequence_parallel_size): the ranks of sp_group run the SAME rows, each on
+        # its slice of every packed pass (Qwen25VL.set_sequence_parallel); gradients add up over sp_group and average over world / sp
+        self.sp_group = sp_group
+        self.sp = dist.get_world_size(sp_group) if sp_group is not None else 1
+        self.model.set_sequence_parallel(sp_group if self.sp > 1 else None)
         self.sync_grads = self.world > 1                                       # tests force it on a 1-rank group
         self.overlap_allreduce = os.environ.get("ST_OVERLAP_ALLREDUCE", "1") != "0"
         self._reducer: Optional[GradReducer] = None
@@ -547,7 +557,8 @@ class PolicyEngine:
         N = data["input_ids"].shape[0]
         mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
         R = data["responses"].shape[1]
-        self.last_prompt_cache_hit = bool(prompt_cache is not None and "kp" in prompt_cache and self._cache_matches(data, prompt_cache, R))
+        self.last_prompt_cache_hit = bool(prompt_cache is not None and "kp" in prompt_cache and getattr(self, "sp", 1) == 1
+                                          and self._cache_matches(data, prompt_cache, R))   # (sequence-parallel passes take whole rows)
         p_len, r_len, keys = self._row_stats(data, R)
         passes = self._plan_passes(0, N, mb, max(1, int(self.fuse_experience)), self.tokens_per_pass_nograd, p_len, r_len, keys,
                                    prompts_cached=self.last_prompt_cache_hit)
@@ -613,7 +624,8 @@ class PolicyEngine:
         if getattr(self, "_reducer", None) is None or self._reducer.grad is not self.store.grad:
             self._reducer = GradReducer(self.store.grad, self.world, self.pg, self.h.allreduce_bucket_mb * (1 << 20) // 4,
                                         mode=os.environ.get("ST_GRAD_EXCHANGE", getattr(self.h, "grad_exchange", "allreduce")),
-                                        payload=os.environ.get("ST_GRAD_EXCHANGE_DTYPE", getattr(self.h, "grad_exchange_dtype", "fp32")))
+                                        payload=os.environ.get("ST_GRAD_EXCHANGE_DTYPE", getattr(self.h, "grad_exchange_dtype", "fp32")),
+                                        mean_over=max(1, self.world // max(1, getattr(self, "sp", 1))))
         return self._reducer
 
     def all_reduce_grads(self):

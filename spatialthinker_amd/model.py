@@ -377,6 +377,7 @@ class DeviceBatch:
 class Qwen25VL:
     def __init__(self, cfg: VLConfig, params: ParamStore):
         self.cfg, self.p = cfg, params
+        self.sp_group, self.sp, self.sp_rank = None, 1, 0          # Ulysses sequence parallelism: set_sequence_parallel
         D = cfg.head_dim
         self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=F32) / D))).to(params.device)   # HF :523
         self.scale = D ** -0.5
@@ -386,6 +387,66 @@ class Qwen25VL:
         self.fp8 = False                 # config #5: the LM's four projection GEMMs run forward in MX-fp8 (enable_fp8)
         self.fp8_dgrad = False           # ... and their input-gradient GEMMs too
         self.fp8_wgrad = False           # ... and their weight-gradient GEMMs
+
+    # ---------------------------------------------------------------- Ulysses sequence parallelism
+    def set_sequence_parallel(self, group) -> None:
+        """Cut every packed pass into `sp` equal row slices over the ranks of `group` (reference verl/utils/ulysses.py + the attention
+        patch flash_attention_utils.py:98-106,146-148): all row-wise work of the LM layers — norms, projections, MLP — runs on this rank's
+        slice; around the attention kernel one all-to-all hands every rank ALL rows of n_heads / sp heads (the kernels see whole
+        sequences and the unchanged segment tables) and a second one trades the result back.  None switches it off.
+        First version: the embedding / ViT in front of the layers and the lm_head + log-prob behind them run on the full stream on
+        every rank (replicated); only the rank's own logit rows enter its backward, so every weight gradient is a partial sum over the
+        rank's tokens and the sp ranks' gradients ADD UP (actor.GradReducer: sum over the world, mean over world / sp)."""
+        import torch.distributed as dist
+        self.sp_group = group
+        self.sp = dist.get_world_size(group) if group is not None else 1
+        self.sp_rank = dist.get_rank(group) if group is not None else 0
+        c = self.cfg
+        if self.sp > 1 and (c.num_heads % self.sp or c.num_kv_heads % self.sp):
+            raise ValueError(f"ulysses_sequence_parallel_size = {self.sp} must divide the {c.num_heads} query heads and the {c.num_kv_heads} key/value heads")
+
+    def _sp_a2a(self, x3: torch.Tensor, scatter_dim: int, gather_dim: int) -> torch.Tensor:
+        """One all-to-all over the sequence-parallel group: `sp` equal pieces of x3 along scatter_dim, piece j to rank j, the received
+        pieces concatenated in rank order along gather_dim."""
+        import torch.distributed as dist
+        send = torch.stack([p_.contiguous() for p_ in torch.tensor_split(x3, self.sp, dim=scatter_dim)], 0)
+        recv = torch.empty_like(send)
+        if dist.get_backend(self.sp_group) == "gloo":          # test mode (ranks sharing one GPU): gloo's all-to-all takes host tensors
+            host = torch.empty(send.shape, dtype=send.dtype)
+            dist.all_to_all_single(host, send.cpu(), group=self.sp_group)
+            recv.copy_(host)
+        else:
+            dist.all_to_all_single(recv, send, group=self.sp_group)
+        return torch.cat(list(recv.unbind(0)), dim=gather_dim).contiguous()
+
+    def _sp_gather_seq(self, x: torch.Tensor, heads: int) -> torch.Tensor:
+        """(T / sp, heads * D) rows of this rank -> (T, heads / sp * D): all rows, this rank's heads."""
+        D = self.cfg.head_dim
+        y = self._sp_a2a(x.reshape(x.shape[0], heads, D), 1, 0)
+        return y.reshape(y.shape[0], (heads // self.sp) * D)
+
+    def _sp_scatter_seq(self, x: torch.Tensor, heads: int) -> torch.Tensor:
+        """(T, heads / sp * D) -> (T / sp, heads * D): the inverse trade."""
+        D = self.cfg.head_dim
+        y = self._sp_a2a(x.reshape(x.shape[0], heads // self.sp, D), 0, 1)
+        return y.reshape(y.shape[0], heads * D)
+
+    def _sp_rows(self, T_pad: int):
+        if T_pad % self.sp:
+            raise ValueError(f"packed length {T_pad} is not divisible by the sequence-parallel size {self.sp}")
+        Tl = T_pad // self.sp
+        return self.sp_rank * Tl, Tl
+
+    def _sp_all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        out = x.new_empty((x.shape[0] * self.sp,) + tuple(x.shape[1:]))
+        if dist.get_backend(self.sp_group) == "gloo":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, x.cpu().contiguous(), group=self.sp_group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, x.contiguous(), group=self.sp_group)
+        return out
 
     def enable_fp8(self, on: bool = True, dgrad: bool = False, wgrad: bool = False):
         """Forward GEMMs of the LM layers (qkv, o, gate/up, down — 93 % of the forward FLOPs) on the block-scaled fp8 MFMA path:
@@ -649,14 +710,29 @@ class Qwen25VL:
         else:
             h1, r1 = ops.rmsnorm_fwd(x0, w[p + "in_norm"], c.rms_eps)
             qkv = self._linear(h1, p + "qkv_w", bias=w[p + "qkv_b"])
-        ops.rope_apply_(qkv, b.cos, b.sin, nq + nkv, D)
-        q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
-        if kv_out is not None:
-            kv_out(i, k, v)
-        a = torch.zeros(x0.shape[0], nq * D, dtype=BF16, device=x0.device)
-        kpre, vpre = prefix_kv if prefix_kv is not None else (None, None)     # prompt K/V cached by the rollout prefill
-        _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a,
-                                  k_pre=kpre, v_pre=vpre, pairs=b.pairs)
+        spx = None
+        if self.sp > 1:
+            # this rank's row slice through the projections; ALL rows of n_heads / sp heads through the attention kernel
+            assert kv_out is None and prefix_kv is None and not fp8, "sequence parallelism covers the plain log-prob / update passes"
+            lo, Tl = self._sp_rows(b.pk.T_pad)
+            ops.rope_apply_(qkv, b.cos[lo:lo + Tl], b.sin[lo:lo + Tl], nq + nkv, D)
+            qs = self._sp_gather_seq(qkv[:, :nq * D], nq)
+            ks = self._sp_gather_seq(qkv[:, nq * D:(nq + nkv) * D], nkv)
+            vs = self._sp_gather_seq(qkv[:, (nq + nkv) * D:], nkv)
+            a_s = torch.zeros(b.pk.T_pad, (nq // self.sp) * D, dtype=BF16, device=x0.device)
+            _, lse = ops.attn_fwd_seg(qs, ks, vs, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq // self.sp, nkv // self.sp, D,
+                                      self.scale, out=a_s, pairs=b.pairs / self.sp)
+            a = self._sp_scatter_seq(a_s, nq)
+            spx = (qs, ks, vs, a_s)
+        else:
+            ops.rope_apply_(qkv, b.cos, b.sin, nq + nkv, D)
+            q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
+            if kv_out is not None:
+                kv_out(i, k, v)
+            a = torch.zeros(x0.shape[0], nq * D, dtype=BF16, device=x0.device)
+            kpre, vpre = prefix_kv if prefix_kv is not None else (None, None)     # prompt K/V cached by the rollout prefill
+            _, lse = ops.attn_fwd_seg(q, k, v, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.pk.max_seg, nq, nkv, D, self.scale, out=a,
+                                      k_pre=kpre, v_pre=vpre, pairs=b.pairs)
         x1 = self._linear(a, p + "o_w", residual=x0)
         if fp8:
             h2, r2, h2q = ops.rmsnorm_mxfp8(x1, w[p + "post_norm"], c.rms_eps, want_y=keep, want_rstd=save is not None)
@@ -685,16 +761,16 @@ class Qwen25VL:
             # recompute_light the backward recomputes them (bit-identical kernels) instead of holding 1/3 of the activation
             # memory (-33 %, +1 % time) — off by default, the 4-micro-batch pass fits with room to spare
             if self.recompute_light:
-                save.append((x0, r1, None, qkv, a, lse, x1, r2, None, gu, None))
+                save.append((x0, r1, None, qkv, a, lse, x1, r2, None, gu, None, spx))
             else:
-                save.append((x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m))
+                save.append((x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m, spx))
         return x2
 
     def _lm_layer_bwd(self, i: int, dx2: torch.Tensor, b: DeviceBatch, saved):
         c, w, g = self.cfg, self.p.w, self.p.g
         p = f"l.{i}."
         D, nq, nkv = c.head_dim, c.num_heads, c.num_kv_heads
-        x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m = saved
+        x0, r1, h1, qkv, a, lse, x1, r2, h2, gu, m, spx = saved
         q2, t2 = self._quantize_grad(dx2)
         dm = self._dgrad(dx2, p + "down_w", dyq=q2)
         if m is None:                                       # recompute the light activations (see _lm_layer_fwd): m in the pass that
@@ -712,10 +788,22 @@ class Qwen25VL:
         self._dw(g[p + "o_w"], dx1, a, None, fp8=self.fp8_wgrad, dyt=t1)
         da = self._dgrad(dx1, p + "o_w", dyq=q1)
         dqkv = torch.zeros_like(qkv)
-        q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
-        ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
-                         self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
-        ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
+        if spx is not None:                                 # the forward's two all-to-alls, transposed: dO out, dQ / dK / dV back
+            qs, ks, vs, a_s = spx
+            lo, Tl = self._sp_rows(b.pk.T_pad)
+            da_s = self._sp_gather_seq(da, nq)
+            dqs, dks, dvs = torch.zeros_like(qs), torch.zeros_like(ks), torch.zeros_like(vs)
+            ops.attn_bwd_seg(qs, ks, vs, a_s, da_s, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq // self.sp,
+                             nkv // self.sp, D, self.scale, dqs, dks, dvs, pairs=b.pairs / self.sp)
+            dqkv[:, :nq * D] = self._sp_scatter_seq(dqs, nq)
+            dqkv[:, nq * D:(nq + nkv) * D] = self._sp_scatter_seq(dks, nkv)
+            dqkv[:, (nq + nkv) * D:] = self._sp_scatter_seq(dvs, nkv)
+            ops.rope_apply_(dqkv, b.cos[lo:lo + Tl], b.sin[lo:lo + Tl], nq + nkv, D, inverse=True)
+        else:
+            q, k, v = qkv[:, :nq * D], qkv[:, nq * D:(nq + nkv) * D], qkv[:, (nq + nkv) * D:]
+            ops.attn_bwd_seg(q, k, v, a, da, lse, b.seg[0], b.seg[1], b.seg[2], b.seg[3], b.seg[4], b.pk.T, b.pk.max_seg, nq, nkv, D,
+                             self.scale, dqkv[:, :nq * D], dqkv[:, nq * D:(nq + nkv) * D], dqkv[:, (nq + nkv) * D:], pairs=b.pairs)
+            ops.rope_apply_(dqkv, b.cos, b.sin, nq + nkv, D, inverse=True)
         qq, tq = self._quantize_grad(dqkv)
         self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"], fp8=self.fp8_wgrad, dyt=tq)
         dh1 = self._dgrad(dqkv, p + "qkv_w", dyq=qq)
@@ -777,8 +865,13 @@ class Qwen25VL:
         """(B, R) fp32 log-probs of the response tokens — DataParallelPPOActor._forward_micro_batch
         (verl/workers/actor/dp_actor.py:64-153), no-grad use."""
         x = self._embed(b, None)
+        if self.sp > 1:
+            lo, Tl = self._sp_rows(b.pk.T_pad)
+            x = x[lo:lo + Tl].contiguous()
         for i in range(self.cfg.num_layers):
             x = self._lm_layer_fwd(i, x, b, None)
+        if self.sp > 1:
+            x = self._sp_all_gather_rows(x)                 # head + log-prob on the full stream (replicated, see set_sequence_parallel)
         *_, logp, _ = self._head_fwd(x, b, temperature)
         out = torch.zeros(b.pk.B * b.pk.R, dtype=F32, device=x.device)
         out.index_copy_(0, b.out_index, logp[:len(b.out_index)])
@@ -796,7 +889,7 @@ class Qwen25VL:
     @torch.no_grad()
     def values(self, b: DeviceBatch) -> torch.Tensor:
         """(B, R) fp32 value predictions — DataParallelPPOCritic._forward_micro_batch (dp_critic.py:52-125), no-grad use."""
-        assert self.cfg.value_head
+        assert self.cfg.value_head and self.sp == 1, "the critic passes are not sequence-parallel (worker.critic.ulysses_sequence_parallel_size = 1)"
         x = self._embed(b, None)
         for i in range(self.cfg.num_layers):
             x = self._lm_layer_fwd(i, x, b, None)
@@ -874,9 +967,14 @@ class Qwen25VL:
         layer_lo = lambda i: off[f"l.{i}.in_norm"] if i < c.num_layers else off["final_norm"]
         vit_saved: Optional[list] = [] if train_vision else None
         x = self._embed(b, vit_saved)
+        if self.sp > 1:
+            sp_lo, sp_Tl = self._sp_rows(b.pk.T_pad)
+            x = x[sp_lo:sp_lo + sp_Tl].contiguous()
         saved = []
         for i in range(c.num_layers):
             x = self._lm_layer_fwd(i, x, b, saved)
+        if self.sp > 1:
+            x = self._sp_all_gather_rows(x)
         xr, hn, rn, logits, logp, lse = self._head_fwd(x, b, temperature)
         Tr, n = len(b.out_index), b.pk.B * b.pk.R
         lp_full = torch.zeros(n, dtype=F32, device=x.device)
@@ -900,6 +998,11 @@ class Qwen25VL:
             gfull, metrics = torch.cat(gs), torch.stack(ms)
         grow = torch.zeros(b.Tr_pad, dtype=F32, device=x.device)
         grow[:Tr] = gfull.index_select(0, b.out_index)
+        if self.sp > 1:
+            # the head ran on the full stream on every sp rank; only the logit rows that sit on THIS rank's token rows enter its backward,
+            # so every weight gradient below is a partial sum over the rank's tokens (the sp ranks' gradients add up to the full one)
+            mine = (b.logit_rows[:Tr] >= sp_lo) & (b.logit_rows[:Tr] < sp_lo + sp_Tl)
+            grow[:Tr] *= mine.to(grow.dtype)
         ops.logprob_bwd_(logits, b.labels, lse, grow, temperature)                       # logits buffer now holds dlogits
         head_name = "embed" if c.tie_word_embeddings else "lm_head"
         self._dw(g[head_name], logits, hn, None)
@@ -912,10 +1015,16 @@ class Qwen25VL:
             ops.rows_scatter_(dx, b.logit_distinct, ops.rows_gather_sum(dxr, b.logit_dup))
         else:
             ops.rows_scatter_(dx, b.logit_rows[:Tr], dxr[:Tr])
+        if self.sp > 1:
+            dx = dx[sp_lo:sp_lo + sp_Tl].contiguous()
         for i in reversed(range(c.num_layers)):
             dx = self._lm_layer_bwd(i, dx, b, saved.pop())
             if on_final is not None:
                 on_final(layer_lo(i), layer_lo(i + 1))
+        if self.sp > 1:                                     # back on the full stream, zero outside this rank's rows: embedding and ViT
+            dx_full = torch.zeros(b.pk.T_pad, dx.shape[1], dtype=dx.dtype, device=dx.device)      # gradients are partial sums as well
+            dx_full[sp_lo:sp_lo + sp_Tl] = dx
+            dx = dx_full
         ops.embed_grad_(g["embed"], b.embed_ids, dx)
         if b.vis is not None and train_vision:
             d_img = ops.rows_gather(dx, b.image_rows)

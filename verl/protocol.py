@@ -304,11 +304,13 @@ def all_gather_data_proto(data: DataProto, size: int, group) -> None:
     import torch.distributed as dist
     if data.batch is not None:
         out = {}
+        on_device = dist.get_backend(group) == "nccl"            # RCCL moves device tensors: host batches make the round trip the reference makes (:682-685)
         for key in sorted(data.batch.keys()):
-            t = data.batch[key].contiguous()
+            src = data.batch[key]
+            t = (src.cuda() if (on_device and not src.is_cuda) else src).contiguous()
             parts = [torch.empty_like(t) for _ in range(size)]
             dist.all_gather(parts, t, group=group)
-            out[key] = torch.cat(parts, dim=0)
+            out[key] = torch.cat(parts, dim=0).to(src.device)
         data.batch = TensorBatch(out, batch_size=len(data.batch) * size)
     gathered = [None] * size
     dist.all_gather_object(gathered, data.non_tensor_batch, group=group)

@@ -28,6 +28,23 @@ from ..single_controller.base.decorator import Dispatch, register
 from ..utils.flops_counter import FlopsCounter
 from ..utils.tokenizer import get_processor, get_tokenizer
 from .rollout import assemble_rollout_batch
+from .sharding_manager import FSDPUlyssesShardingManager
+
+
+class _SpDim:
+    """The "sp" dimension of the reference's device mesh, as FSDPUlyssesShardingManager reads it."""
+
+    def __init__(self, group, size: int, local_rank: int):
+        self._g, self._n, self._r = group, size, local_rank
+
+    def get_group(self):
+        return self._g
+
+    def size(self):
+        return self._n
+
+    def get_local_rank(self):
+        return self._r
 
 
 class FSDPWorker(Worker):
@@ -45,11 +62,20 @@ class FSDPWorker(Worker):
         self._is_rollout = role in ("rollout", "actor_rollout", "actor_rollout_ref")
         self._is_ref = role in ("ref", "actor_rollout_ref")
         self._is_critic = role == "critic"
-        # options of the reference this engine does not implement are rejected, never silently ignored
-        if int(getattr(self.config.actor, "ulysses_sequence_parallel_size", 1)) > 1:
-            raise NotImplementedError(
-                "worker.actor.ulysses_sequence_parallel_size > 1: Ulysses sequence parallelism (verl/utils/ulysses.py) is not built; a 288 GB "
-                "MI355X holds the 8192-token sequences of the shipped scripts without it — set it to 1")
+        # Ulysses sequence parallelism (fsdp_workers.py:107-125): the ranks form a ("dp", "sp") mesh, rank = dp_index * sp + sp_index; the sp
+        # ranks of a group run the SAME rows, each on its slice of every packed pass (round 5: Qwen25VL.set_sequence_parallel, all-to-all
+        # around the attention kernels, verl/utils/ulysses.py).  A 288 GB MI355X holds the shipped scripts' 8192-token sequences without
+        # it (every script sets 1); it exists for longer sequences and for parity of the option.
+        self.sp_size = int(getattr(self.config.actor, "ulysses_sequence_parallel_size", 1) or 1)
+        self.sp_group, self.ulysses_sharding_manager = None, FSDPUlyssesShardingManager(None)
+        if self.sp_size > 1 and not role == "critic":
+            if self.world_size % self.sp_size:
+                raise ValueError(f"ulysses_sequence_parallel_size = {self.sp_size} does not divide the {self.world_size} ranks")
+            for k in range(self.world_size // self.sp_size):                 # every rank creates every group (torch.distributed's contract)
+                grp = dist.new_group(list(range(k * self.sp_size, (k + 1) * self.sp_size)))
+                if k == self.rank // self.sp_size:
+                    self.sp_group = grp
+            self.ulysses_sharding_manager = FSDPUlyssesShardingManager({"sp": _SpDim(self.sp_group, self.sp_size, self.rank % self.sp_size)})
         if not bool(getattr(self.config.actor, "padding_free", True)) and self.rank == 0 and not FSDPWorker._warned_padding:
             FSDPWorker._warned_padding = True
             print("[FSDPWorker] worker.actor.padding_free=false: this engine always runs the padding-free (packed) formulation of "
@@ -65,7 +91,7 @@ class FSDPWorker(Worker):
         """fsdp_workers.py:130-147: global batch is counted in rollouts, then split over the ranks."""
         if self.config.rollout.n > 1:
             cfg.global_batch_size *= self.config.rollout.n
-        cfg.global_batch_size_per_device = cfg.global_batch_size // self.world_size
+        cfg.global_batch_size_per_device = cfg.global_batch_size // self.world_size * getattr(self, "sp_size", 1)     # :133-135
         if cfg.global_batch_size_per_device == 0:
             raise ValueError("actor global batch size * ulysses size must be larger than num gpus.")
         if cfg.global_batch_size_per_device % cfg.micro_batch_size_per_device_for_update != 0:
@@ -142,7 +168,7 @@ class FSDPWorker(Worker):
                                # gradient exchange here; ST_GRAD_EXCHANGE=reduce_scatter selects SURVEY §5.8's direct schedule
                                grad_exchange_dtype="bf16" if str(a.fsdp.mp_reduce_dtype).lower() in ("bf16", "bfloat16") else "fp32")
             self.model_config, self.special = cfg, special
-            self.actor = PolicyEngine(cfg, store, hyper)
+            self.actor = PolicyEngine(cfg, store, hyper, sp_group=self.sp_group)
             self.flops_counter = FlopsCounter(cfg)
             if self.world_size > 1:                          # sync_module_states: rank 0's weights everywhere (fsdp_workers.py:261-263)
                 dist.broadcast(store.flat, src=0)
@@ -158,7 +184,7 @@ class FSDPWorker(Worker):
             elif self.world_size > 1:
                 dist.broadcast(store.flat, src=0)
             self.model_config, self.special = cfg, special
-            self.ref_policy = PolicyEngine(cfg, store, None)
+            self.ref_policy = PolicyEngine(cfg, store, None, sp_group=self.sp_group)
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -203,10 +229,14 @@ class FSDPWorker(Worker):
         t = self.config.rollout.temperature
         data.meta_info["temperature"] = t
         cache, self._prompt_cache = getattr(self, "_prompt_cache", None), None            # one use, then the K/V memory is released
-        lp = self.actor.compute_log_prob(self._as_dict(data), t, prompt_cache=cache, use_rollout_log_probs=self._old_from_rollout()).cpu()
-        return DataProto.from_dict(tensors={"old_log_probs": lp},
-                                   meta_info={"temperature": t, "prompt_cache_hit": bool(self.actor.last_prompt_cache_hit),
-                                              "old_log_probs_source": getattr(self.actor, "last_log_prob_source", "forward")})
+        with self.ulysses_sharding_manager:                                               # sp > 1: the group's rows in, this rank's rows out (:514-520)
+            data = self.ulysses_sharding_manager.preprocess_data(data)
+            lp = self.actor.compute_log_prob(self._as_dict(data), t, prompt_cache=cache if self.sp_size == 1 else None,
+                                             use_rollout_log_probs=self._old_from_rollout()).cpu()
+            out = self.ulysses_sharding_manager.postprocess_data(DataProto.from_dict(tensors={"old_log_probs": lp}))
+        out.meta_info = {"temperature": t, "prompt_cache_hit": bool(self.actor.last_prompt_cache_hit),
+                         "old_log_probs_source": getattr(self.actor, "last_log_prob_source", "forward")}
+        return out
 
     def _old_from_rollout(self) -> bool:
         """worker.rollout.old_log_probs_from_rollout (or ST_OLD_FROM_ROLLOUT=1): opt-in, see PolicyEngine.compute_log_prob."""
@@ -216,15 +246,19 @@ class FSDPWorker(Worker):
     def compute_ref_log_probs(self, data: DataProto) -> DataProto:
         assert self._is_ref
         t = self.config.rollout.temperature
-        lp = self.ref_policy.compute_log_prob(self._as_dict(data), t, self.config.ref.micro_batch_size_per_device_for_experience).cpu()
-        return DataProto.from_dict(tensors={"ref_log_probs": lp})
+        with self.ulysses_sharding_manager:                                               # :541-545
+            data = self.ulysses_sharding_manager.preprocess_data(data)
+            lp = self.ref_policy.compute_log_prob(self._as_dict(data), t, self.config.ref.micro_batch_size_per_device_for_experience).cpu()
+            return self.ulysses_sharding_manager.postprocess_data(DataProto.from_dict(tensors={"ref_log_probs": lp}))
 
     @register(dispatch_mode=Dispatch.DP_COMPUTE_PROTO)
     def update_actor(self, data: DataProto) -> DataProto:
         assert self._is_actor
         torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
-        metrics = self.actor.update_policy(self._as_dict(data), data.meta_info["temperature"])
+        with self.ulysses_sharding_manager:                                               # :434-436 (metrics are not re-sharded)
+            data = self.ulysses_sharding_manager.preprocess_data(data)
+            metrics = self.actor.update_policy(self._as_dict(data), data.meta_info["temperature"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         est, promised = self.flops_counter.estimate_flops(data.meta_info["global_token_num"], dt)

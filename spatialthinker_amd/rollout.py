@@ -133,7 +133,7 @@ class Generator:
     def generate_chunk(self, input_ids, attention_mask, position_ids, *, n: int, max_new_tokens: int, temperature: float = 1.0,
                        eos_token_id=(151645,), pad_token_id: int = 151643, seed: int = 0, pixel_values: Optional[Sequence] = None,
                        image_grid_thw: Optional[Sequence] = None, forced_lengths: Optional[np.ndarray] = None, ignore_eos: bool = False,
-                       sync_every: int = 32, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
+                       sync_every: int = 4, use_graph: bool = True, top_k: int = -1, top_p: float = 1.0,
                        return_prompt_cache: bool = False, rng_row_offset: int = 0, emit_log_probs: bool = False,
                        on_finished=None, tail_stream=None, tail_rows: int = 128):
         """input_ids / attention_mask (b, P) left-padded, position_ids (b, 3, P) (or (b, P) text-only); per-prompt lists
@@ -417,6 +417,10 @@ class Generator:
             len0_rows = gen_len.clone() if fused else None       # fused path: a finished row's length freezes (st_decode_step), see below
             ev0.record()
             done0 = done
+            # The live count is read every `sync_every` iterations (a blocking read: the queue drains, ~0.1 ms of idle GPU per read).  A phase
+            # overshoots its re-batch point by sync_every / 2 iterations on average, at the price of the phase's WIDEST row count: with 32
+            # (rounds 1-4) the five phases of the bench's rollout wasted ~16 x (11.9 + 7.7 + 6.3 + 5.2 + 4.3) ms = 0.57 s per step, with 4
+            # ~0.07 s + ~0.03 s of reads (round 5, profiles/r05_notes.md)
             while True:
                 if done % sync_every == 0 or done >= R:
                     if done > done0:

@@ -20,7 +20,8 @@ int st_gemm_tile_decode(int variant, int splits, const uint16_t* A, int64_t lda,
     } while (0)
     // weights read by ONE row tile stream with the non-temporal policy (nothing re-reads them before the next decode iteration);
     // with two row tiles (257..512 rows) the second tile's read is an L2 / MALL hit that nt would throw away
-    const bool nt = g_decode_nt && M <= BM_OF(variant);
+    // (ST_DECODE_NT=2: nt with two row tiles as well — an A/B switch, profiles/r05_notes.md)
+    const bool nt = g_decode_nt >= 2 || (g_decode_nt && M <= BM_OF(variant));
 #define DEC_GO(BM, BN, WM, WN, ST) do { if (nt) DEC_GO_NT(BM, BN, WM, WN, ST, true); else DEC_GO_NT(BM, BN, WM, WN, ST, false); } while (0)
     switch (variant) {
         case 10: DEC_GO(64, 64, 1, 4, 3);

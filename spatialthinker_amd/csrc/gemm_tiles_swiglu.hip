@@ -81,7 +81,7 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
     if (swiglu_decode_on_asm4(M, I) && lda < (1 << 22) && ldb < (1 << 22))
         return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
     const int plan = swiglu_decode_plan(M, I);
-    if (g_decode_nt && M <= 256) {                           // one row tile: the weights are read once — non-temporal stream
+    if (g_decode_nt >= 2 || (g_decode_nt && M <= 256)) {     // one row tile: the weights are read once — non-temporal stream (2: always, A/B)
         if (plan == 7) return launch_tile_swiglu<64, 128, 1, 4, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         if (plan == 6 && M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         if (plan == 1) return launch_tile_swiglu<256, 160, 4, 2, 3, false, true, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);

@@ -723,6 +723,7 @@ def main():
 
     overlap_old = a.overlap_old == "on" and not a.old_from_rollout and not a.ranks_share_gpu
     overlap_stats = {"early_rows": 0, "feed_host_s": 0.0}
+    reward_cpu_s = [0.0]                                       # the scorer thread's own wall time over all steps (overlapped with old / ref)
 
     def one_step(step_idx, timed):
         (ids, mask, pos, pix, grids), lens = staged[step_idx]
@@ -745,9 +746,19 @@ def main():
                     multi_modal_inputs=mm)
         # ---- reward: dense spatial scorer on templated strings (no tokenizer offline), score at the last valid token
         preds, gts, problems = synth_reward_strings(B, rs)
-        scores = torch.tensor([spatial_sgg_compute_score(p, g, q)["overall"] for p, g, q in zip(preds, gts, problems)], dtype=torch.float32)
-        rewards = torch.zeros(B, R)
-        rewards[torch.arange(B), rmask.sum(1) - 1] = scores
+        reward_out = {}
+
+        def score_rewards():                                 # host work that needs only the rollout: runs beside the old / ref passes
+            t_ = time.perf_counter()                         # on a thread (as RayPPOTrainer.fit does, _RewardJob), joined before `adv`
+            scores = torch.tensor([spatial_sgg_compute_score(p, g, q)["overall"] for p, g, q in zip(preds, gts, problems)], dtype=torch.float32)
+            rw = torch.zeros(B, R)
+            rw[torch.arange(B), rmask.sum(1) - 1] = scores
+            reward_out.update(rewards=rw, seconds=time.perf_counter() - t_)
+        import threading
+        reward_thread = threading.Thread(target=score_rewards, name="reward", daemon=True)
+        reward_thread.start()
+        if os.environ.get("ST_REWARD_THREAD", "1") == "0":    # the reference's serial order
+            reward_thread.join()
         t2 = tick()
         if early is not None:
             data["old_log_probs"] = early.finish(data, prompt_cache)       # most of it ran beside the decode tail; the rest runs here
@@ -760,6 +771,9 @@ def main():
         t3 = tick()
         data["ref_log_probs"] = ref.compute_log_prob(data, temperature)
         t4 = tick()
+        reward_thread.join()
+        rewards = reward_out["rewards"]
+        reward_cpu_s[0] += reward_out["seconds"]
         group = torch.arange(npr, dtype=torch.int32).repeat_interleave(G).cuda()
         adv, status = ops.grpo_advantage(rewards.cuda(), rmask.cuda(), group, npr)
         data["advantages"] = adv
@@ -943,6 +957,8 @@ def main():
                                    f"{npr} prompts/GPU, micro-batch {micro}, {n_opt} optimizer steps/step, max_response_length {R}",
                        "global_batch": B * world, "seq_len": P + R, "parallelism": f"dp{world}" + (" (ranks share ONE GPU, gloo exchange: test mode)" if a.ranks_share_gpu else "")},
             "timing_s": {k: v / a.steps for k, v in phase.items()},
+            "reward_scorer": {"host_s_per_step": reward_cpu_s[0] / max(1, a.steps + a.warmup), "placement": "thread beside the old / ref log-prob passes, joined before adv "
+                              "(timing_s.reward = what is left of it in front of `old`; ST_REWARD_THREAD=0: the reference's serial order)"},
             "timing_s_max_over_ranks": {k: v / a.steps for k, v in phase_max.items()},
             # gradient exchange per step (max over ranks; device events on the compute stream, actor.GradReducer): the whole exchange from the
             # first layer slice sent during the last backward pass to the averaged gradients, and the part of it NOT hidden behind the

@@ -139,6 +139,52 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const uint16_t* __rest
     }
 }
 
+// Register-resident form of rmsnorm_fwd_kernel for H <= 512 * NCH (round 5): a lane issues ALL its 16-byte loads of the row first
+// (NCH independent loads in flight per lane instead of one dependent load per loop trip) and keeps them for the second pass — the row
+// is read once.  Same per-lane summation order as the loop form: bit-identical rstd and y.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                             const uint16_t* __restrict__ w, float eps,
+                                                             uint16_t* __restrict__ y, int64_t ldy,
+                                                             float* __restrict__ rstd_out, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    uint16_t* yr = y + (int64_t)row * ldy;
+    uint4 r[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int i = lane * 8 + j * 512;
+        r[j] = i < H ? *reinterpret_cast<const uint4*>(xr + i) : make_uint4(0, 0, 0, 0);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (lane * 8 + j * 512 < H) {
+            float f[8];
+            unpack8(r[j], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int i = lane * 8 + j * 512;
+        if (i < H) {
+            float f[8], wf[8];
+            unpack8(r[j], f);
+            unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = wf[e] * bfround(f[e] * rstd);
+            *reinterpret_cast<uint4*>(yr + i) = pack8(f);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Critic value head (dp_critic.py:52-125 reads `output.logits` of a token-classification model: score = nn.Linear(H, 1) on the final hidden
 // state, in the model's bf16): v[t] = bf16(sum_h hn[t][h] * w[h] + b).  One wave per row.
@@ -363,6 +409,10 @@ int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, s
     StProfScope ps(ST_K_RMSNORM, s, 4.0 * (double)T * (double)H);
     if (T <= 1024 && H <= 4096)
         hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, H);
+    else if (H <= 2048)
+        hipLaunchKernelGGL(rmsnorm_fwd_reg_kernel<4>, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
+    else if (H <= 4096)
+        hipLaunchKernelGGL(rmsnorm_fwd_reg_kernel<8>, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
     else
         hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(st_cdiv(T, 4)), dim3(256), 0, s, x, ldx, w, eps, y, ldy, rstd, T, H);
     ST_CHECK_LAUNCH();

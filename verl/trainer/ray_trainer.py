@@ -134,6 +134,33 @@ def remove_obsolete_ckpt(path: str, global_step: int, save_limit: int = -1, dire
         shutil.rmtree(os.path.join(path, directory_format.format(s)), ignore_errors=True)
 
 
+class _RewardJob:
+    """reward_fn(batch) on a thread, on a SNAPSHOT of the batch (own dicts, shared tensors): the main thread keeps adding keys to the
+    live batch (old / ref log-probs) while the scorer reads the rollout's."""
+
+    def __init__(self, fn, batch: DataProto):
+        import threading
+        snap = DataProto(batch=None if batch.batch is None else type(batch.batch)(dict(batch.batch.items()), batch_size=batch.batch.batch_size),
+                         non_tensor_batch=dict(batch.non_tensor_batch), meta_info=dict(batch.meta_info))
+        self._out, self._err, self.seconds = None, None, 0.0
+
+        def run():
+            t0 = time.perf_counter()
+            try:
+                self._out = fn(snap)
+            except BaseException as e:                      # re-raised on the main thread
+                self._err = e
+            self.seconds = time.perf_counter() - t0
+        self._t = threading.Thread(target=run, name="reward", daemon=True)
+        self._t.start()
+
+    def result(self):
+        self._t.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
 class RayPPOTrainer:
     """Name kept for drop-in use by verl.trainer.main; there is no Ray underneath."""
 
@@ -412,12 +439,20 @@ class RayPPOTrainer:
                     batch.non_tensor_batch["uid"] = np.array([str(uuid.uuid4()) for _ in range(len(batch))], dtype=object)
                     batch = batch.repeat(repeat_times=n, interleave=True)
                     batch = batch.union(gen_out)
-                    with _timer("reward", timing_raw):
-                        reward_tensor, reward_metrics = self.reward_fn(batch)
-                        batch.batch["token_level_scores"] = reward_tensor
-                        metrics.update({f"reward/{k}": v for k, v in reduce_metrics(self._gather_metric_lists(reward_metrics)).items()})
-                    pending_order = None
                     migrated = getattr(cfg.trainer, "balance_mode", "local") == "migrate"
+                    # The reward is host work (detokenise + score, reward/custom.py:48-73) that needs nothing but the rollout, and the
+                    # log-prob passes that follow are device work that needs nothing of the reward: the scorer runs on a thread beside
+                    # them (round 5) and is joined in front of the advantages.  The reference runs them one after the other
+                    # (ray_trainer.py:606-640); same values either way.  Not with balance_mode=migrate (the scores travel with the rows).
+                    reward_job = None
+                    if migrated or os.environ.get("ST_REWARD_THREAD", "1") == "0":
+                        with _timer("reward", timing_raw):
+                            reward_tensor, reward_metrics = self.reward_fn(batch)
+                            batch.batch["token_level_scores"] = reward_tensor
+                            metrics.update({f"reward/{k}": v for k, v in reduce_metrics(self._gather_metric_lists(reward_metrics)).items()})
+                    else:
+                        reward_job = _RewardJob(self.reward_fn, batch)
+                    pending_order = None
                     if migrated:
                         batch = self._migrate_batch(batch, metrics)
                     else:
@@ -435,6 +470,12 @@ class RayPPOTrainer:
                     if self.use_critic:                                   # ray_trainer.py:644-648
                         with _timer("values", timing_raw):
                             batch = batch.union(self.critic_wg.compute_values(batch))
+                    if reward_job is not None:
+                        with _timer("reward_wait", timing_raw):               # what the scorer still needed after the log-prob passes
+                            reward_tensor, reward_metrics = reward_job.result()
+                        timing_raw["reward"] = reward_job.seconds              # the scorer's own wall time (overlapped with old / ref)
+                        batch.batch["token_level_scores"] = reward_tensor
+                        metrics.update({f"reward/{k}": v for k, v in reduce_metrics(self._gather_metric_lists(reward_metrics)).items()})
                     with _timer("adv", timing_raw):
                         if not cfg.algorithm.use_kl_loss and self.use_reference_policy:
                             batch, kl_metrics = apply_kl_penalty(batch, self.kl_ctrl, cfg.algorithm.kl_penalty, gather=self._gather_list)

@@ -66,9 +66,9 @@ class FSDPWorker(Worker):
         # ranks of a group run the SAME rows, each on its slice of every packed pass (round 5: Qwen25VL.set_sequence_parallel, all-to-all
         # around the attention kernels, verl/utils/ulysses.py).  A 288 GB MI355X holds the shipped scripts' 8192-token sequences without
         # it (every script sets 1); it exists for longer sequences and for parity of the option.
-        self.sp_size = int(getattr(self.config.actor, "ulysses_sequence_parallel_size", 1) or 1)
+        self.sp_size = 1 if role == "critic" else int(getattr(self.config.actor, "ulysses_sequence_parallel_size", 1) or 1)
         self.sp_group, self.ulysses_sharding_manager = None, FSDPUlyssesShardingManager(None)
-        if self.sp_size > 1 and not role == "critic":
+        if self.sp_size > 1:
             if self.world_size % self.sp_size:
                 raise ValueError(f"ulysses_sequence_parallel_size = {self.sp_size} does not divide the {self.world_size} ranks")
             for k in range(self.world_size // self.sp_size):                 # every rank creates every group (torch.distributed's contract)

@@ -5,6 +5,14 @@
 extern int g_train_variant;
 int st_gemm_asm4_swiglu(const uint16_t* A, int64_t lda, const uint16_t* gate_up_w, int64_t ldb, uint16_t* gu_out, int64_t ldgu, uint16_t* m_out,
                         int64_t ldm, int M, int I, int K, hipStream_t s, int split_tail = 0);
+// gemm_swiglu512.hip: all (<= 512) rows x 80 output columns per workgroup, ONE pass over the weights (round 5)
+int st_gemm_swiglu512_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* out, int64_t ldo, int M, int I, int K,
+                             hipStream_t s);
+// 257..512 rows: plan 512 = the one-pass tile (ST_DECODE_GU512=0 falls back to the two-round 256x160 tile)
+static bool swiglu_decode_on_512(int M) {
+    static const bool on = [] { const char* e = getenv("ST_DECODE_GU512"); return !e || e[0] != '0'; }();
+    return on && M > 256 && M <= 512;
+}
 
 /* gate/up projection with the SwiGLU in the epilogue for any M (training / prefill): m_out[M, I] = silu(A gate_w^T) * (A up_w^T);
  * gu_out (optional, [M, 2I]) additionally receives the bf16 gate|up values the backward needs. */
@@ -33,6 +41,7 @@ extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int6
         case 40:                                             // the 4-wave training tile with the K-split SwiGLU tail (needs st_gemm_set_workspace for the split)
             if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
             return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
+        case 512: return st_gemm_swiglu512_launch(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 3: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
@@ -68,7 +77,7 @@ static bool swiglu_decode_on_asm4(int M, int I) {
 }
 extern "C" int st_gemm_swiglu_decode_plan(int M, int I, int* variant_out) {
     if (M <= 0 || M > ST_DECODE_MAX_ROWS || I <= 0 || !variant_out) return ST_EINVAL;
-    *variant_out = swiglu_decode_on_asm4(M, I) ? 40 : swiglu_decode_plan(M, I);
+    *variant_out = swiglu_decode_on_asm4(M, I) ? 40 : (swiglu_decode_on_512(M) ? 512 : swiglu_decode_plan(M, I));
     return 0;
 }
 
@@ -80,6 +89,7 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
     hipStream_t s = (hipStream_t)stream;
     if (swiglu_decode_on_asm4(M, I) && lda < (1 << 22) && ldb < (1 << 22))
         return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
+    if (swiglu_decode_on_512(M)) return st_gemm_swiglu512_launch(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     const int plan = swiglu_decode_plan(M, I);
     if (g_decode_nt >= 2 || (g_decode_nt && M <= 256)) {     // one row tile: the weights are read once — non-temporal stream (2: always, A/B)
         if (plan == 7) return launch_tile_swiglu<64, 128, 1, 4, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);

@@ -823,3 +823,28 @@ def test_decode_attention_persistent_kernel_is_bit_identical_to_one_item_per_wor
             worst = max(worst, float((got - want).abs().max()))
     measured(f"decode_attention_persistent_{case}_max_abs_vs_fp32", worst)
     assert worst < 0.02                                           # bf16 partials + bf16 output, |v| ~ 1 (measured ~0.008)
+
+
+@pytest.mark.parametrize("M_,I,K", [(257, 1000, 128), (300, 80, 64), (512, 81, 192), (384, 2000, 3584), (512, 18944, 3584), (448, 11008, 2048), (1, 160, 64), (64, 240, 128)])
+def test_one_pass_512_row_swiglu_tile_is_bit_identical_to_the_two_round_tile(ops, M_, I, K):
+    """gemm_swiglu512.hip (round 5; plan 512 of the decode gate/up + SwiGLU at 257..512 rows: all rows x 80 output columns per workgroup, K-steps
+    of 32, ping-pong wave groups) against the 256x160 tile it replaces (plan 1): the same K summation order and the same epilogue
+    roundings — bit-identical, incl. ragged row counts (waves without valid rows skip their work), a ragged last column tile and K = 64;
+    and within the decode GEMM bound of the fp32 product."""
+    from spatialthinker_amd.lib import lib
+    torch.manual_seed(M_ + I)
+    a = (torch.randn(M_, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(2 * I, K, device="cuda") * 0.05).bfloat16()
+    o1 = torch.full((M_, I), 7.0, device="cuda", dtype=torch.bfloat16)
+    o5 = torch.full((M_, I), -7.0, device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    for v, o in ((1, o1), (512, o5)):
+        lib().st_gemm_swiglu_decode_variant(v, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), o.data_ptr(), o.stride(0), M_, I, K, st)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o5)
+    want = a.float() @ w.float().t()
+    g_, u_ = want[:, :I].bfloat16().float(), want[:, I:].bfloat16().float()
+    ref = (g_ * torch.sigmoid(g_)).bfloat16().float() * u_
+    assert float((o5.float() - ref).abs().max() / ref.abs().max()) < 9.1e-3
+    if M_ > 256:
+        assert ops.swiglu_decode_plan(M_, I) == 512 and torch.equal(ops.gemm_swiglu_decode(a, w), o5)       # the decode entry takes it

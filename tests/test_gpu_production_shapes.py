@@ -194,7 +194,7 @@ def test_decode_plans_hit_the_production_tiles(ops):
             v, sp = ops.decode_plan(Bp, N, K)
             seen.add(v); max_split = max(max_split, sp)
     assert {14, 16, 18} <= seen, seen
-    assert 1 in swiglu, swiglu
+    assert 1 in swiglu and 512 in swiglu, swiglu
     assert max_split >= 4, max_split
 
 

@@ -18,7 +18,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name, (_res, argtypes, argnames) in protos.items():
         assert len(argtypes) == len(argnames)
         if name not in ("st_version", "st_arch", "st_prof_enable", "st_prof_read", "st_prof_disable", "st_prof_set_stride", "st_prof_hint_units", "st_prof_seen",
-                            "st_attn_bwd_workspace_bytes",
+                            "st_attn_bwd_workspace_bytes", "st_prof_read_events", "st_stream_create_cu_range", "st_stream_destroy",
                             "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan", "st_gemm_select", "st_decode_attn_select", "st_gemm_mxfp8_select"):
             assert argnames[-1] == "stream", f"{name}: every compute entry takes the stream last"
 
@@ -64,4 +64,6 @@ def test_decode_plan_query_is_host_only_and_picks_the_7b_tiles():
             assert 1 <= sp <= 12 and (K // 64) // sp >= 4
     assert {14, 16, 18} <= seen and max(splits) >= 4
     assert ops.swiglu_decode_plan(64, 18944) == 7 and ops.swiglu_decode_plan(128, 18944) == 6
-    assert ops.swiglu_decode_plan(256, 18944) == 1 and ops.swiglu_decode_plan(512, 18944) == 1         # (40 = the 4-wave tile with the K-split SwiGLU tail: opt-in, ST_DECODE_GU_ASM4=1)
+    # 257..512 rows: 512 = the one-pass 512-row tile of round 5 (gemm_swiglu512.hip; ST_DECODE_GU512=0 -> 1; 40 = the 4-wave tile with the
+    # K-split SwiGLU tail: opt-in, ST_DECODE_GU_ASM4=1)
+    assert ops.swiglu_decode_plan(256, 18944) == 1 and ops.swiglu_decode_plan(512, 18944) == 512 and ops.swiglu_decode_plan(257, 18944) == 512

@@ -35,23 +35,14 @@ __device__ __forceinline__ void s5_glds16(const void* gsrc, char* lds_dst_unifor
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 }
-// the weights: every workgroup reads its 160 rows exactly once — non-temporal policy (issued -> landed latency -18 %, MI355X_MICROARCH.md
-// "nt-weights"); the activations are re-read by all 237 workgroups and keep the default policy
-__device__ __forceinline__ void s5_glds16_nt(const void* gsrc, char* lds_dst_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 2);
-}
-
 template <int N> __device__ __forceinline__ void s5_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-template <bool PP, bool NTW, bool NOWAIT, bool SPLIT = false>
+template <bool PP>
 __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ W,
                                                             int64_t ldw, uint16_t* __restrict__ out, int64_t ldo, int M, int I, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,27 +83,8 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
         char* base = smem + slot * S5_SLOT;
 #pragma unroll
         for (int j = 0; j < 4; ++j) s5_glds16(asrc[j] + (int64_t)ks * 32, base + (wave * 4 + j) * 1024);
-        if (NTW) {
-            s5_glds16_nt(bsrc[0] + (int64_t)ks * 32, base + S5_A_BYTES + wave * 1024);
-            if (nbp == 2) s5_glds16_nt(bsrc[1] + (int64_t)ks * 32, base + S5_A_BYTES + (wave + 8) * 1024);
-        } else {
-            s5_glds16(bsrc[0] + (int64_t)ks * 32, base + S5_A_BYTES + wave * 1024);
-            if (nbp == 2) s5_glds16(bsrc[1] + (int64_t)ks * 32, base + S5_A_BYTES + (wave + 8) * 1024);
-        }
-    };
-
-    // the same copies in two parts (ping-pong schedule): E = A pieces 0, 1 + the B piece(s), issued in the read phase; L = A pieces 2, 3
-    // (activations: L2 hits, short flight), issued between the MFMAs of the following MFMA phase — the read phase carried all 5-6 issues
-    // (~100 cycles each) and was the longer of the two phases
-    auto stage_early = [&](int ks, int slot) {
-        char* base = smem + slot * S5_SLOT;
-        s5_glds16(asrc[0] + (int64_t)ks * 32, base + (wave * 4 + 0) * 1024);
-        s5_glds16(asrc[1] + (int64_t)ks * 32, base + (wave * 4 + 1) * 1024);
         s5_glds16(bsrc[0] + (int64_t)ks * 32, base + S5_A_BYTES + wave * 1024);
         if (nbp == 2) s5_glds16(bsrc[1] + (int64_t)ks * 32, base + S5_A_BYTES + (wave + 8) * 1024);
-    };
-    auto stage_late1 = [&](int ks, int slot, int j) {        // j = 2, 3
-        s5_glds16(asrc[j] + (int64_t)ks * 32, smem + slot * S5_SLOT + (wave * 4 + j) * 1024);
     };
 
     f32x4 acc[10][4];
@@ -143,7 +115,7 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
         const int grp = wave >> 2;
         bf16x8 af[4], bfr[10];
         auto wait_copies = [&](int x) {                      // this wave's copies of K-step x have landed (x + 1 may stay in flight)
-            if (NOWAIT || x >= nks) return;                  // NOWAIT: timing diagnostic with WRONG results (is the loop waiting for data?)
+            if (x >= nks) return;
             if (x + 1 < nks) { if (nbp == 2) s5_wait_vmcnt<6>(); else s5_wait_vmcnt<5>(); }
             else s5_wait_vmcnt<0>();
         };
@@ -168,30 +140,20 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
         int slot = 0;
         for (int ks = 0; ks < nks; ++ks) {
             const int s1 = slot + 1 == S5_SLOTS ? 0 : slot + 1;
-            // late copies of K-step ks + 2 (slot of K-step ks - 1, free since the barrier before last): one after the 13th, one after the
-            // 27th MFMA; K-steps 0..2 were issued whole by the prologue
-            const bool late = SPLIT && ks + 2 >= 3 && ks + 2 < nks;
-            const int sl = slot == 0 ? S5_SLOTS - 1 : slot - 1;
             if (live) {
                 __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-                for (int ni = 0; ni < 10; ++ni) {
+                for (int ni = 0; ni < 10; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
-                    if (SPLIT && (ni == 3 || ni == 6)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (late) stage_late1(ks + 2, sl, ni == 3 ? 2 : 3);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
                 __builtin_amdgcn_s_setprio(0);
-            } else if (late) { stage_late1(ks + 2, sl, 2); stage_late1(ks + 2, sl, 3); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) wait_copies(ks + 1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (ks + 3 < nks) { if (SPLIT) stage_early(ks + 3, slot); else stage(ks + 3, slot); }   // slot of K-step ks: both groups have read it
+            if (ks + 3 < nks) stage(ks + 3, slot);            // slot of K-step ks: both groups have read it by now
             if (live && ks + 1 < nks) {
                 const char* base = smem + s1 * S5_SLOT;
 #pragma unroll
@@ -201,13 +163,7 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (grp == 1) {
-                if (!SPLIT) wait_copies(ks + 2);
-                else if (!NOWAIT && ks + 2 < nks) {          // K-step ks + 2 whole; only the EARLY copies of ks + 3 (just issued) may stay in flight
-                    if (ks + 3 < nks) { if (nbp == 2) s5_wait_vmcnt<4>(); else s5_wait_vmcnt<3>(); }
-                    else s5_wait_vmcnt<0>();
-                }
-            }
+            if (grp == 1) wait_copies(ks + 2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             slot = s1;
@@ -277,25 +233,22 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
 int st_gemm_swiglu512_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* out, int64_t ldo, int M, int I, int K,
                              hipStream_t s) {
     constexpr int smem = S5_SLOTS * S5_SLOT;                 // 129,024 bytes
-    // ST_GU512_MODE (A/B and diagnostics; profiles/r05_notes.md §1b): 0 = ping-pong, default cache policy (default) | 1 = lockstep first
-    // version | 2 = ping-pong + nt weight stream (SLOWER: with 64-byte row pieces the second half of every 128-byte line comes from HBM
-    // again) | 3 = mode 2 without the data waits (WRONG results: timing diagnostic — the loop does not wait for data)
+    // ST_GU512_MODE=1: the lockstep first version (A/B).  Also measured and removed (commit 317cd87, profiles/r05_notes.md
+    // §1b): nt weight stream (157 vs 134 us: with 64-byte row pieces the second half of every 128-byte line comes from HBM again), the loop
+    // without its data waits (same time: it does not wait for data), two of the six copies per wave moved into the MFMA phase (same time
+    // at 512 rows, slower below), every workgroup walking K from its own starting point (143 vs 136 us: the 237 workgroups reading the SAME
+    // activation lines at the same time is an L2 benefit, not a conflict): the tile runs at the rate the CU can fill its LDS (4.8 MB per
+    // workgroup at ~36 GB/s).
     static const int mode = [] { const char* e = getenv("ST_GU512_MODE"); return e ? atoi(e) : 0; }();
     static bool configured = false;
     if (!configured) {
-        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_swiglu512_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
     const dim3 grid(st_cdiv(I, S5_COLS)), block(512);
-    if (mode == 1) hipLaunchKernelGGL((gemm_swiglu512_kernel<false, false, false>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
-    else if (mode == 2) hipLaunchKernelGGL((gemm_swiglu512_kernel<true, true, false>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
-    else if (mode == 3) hipLaunchKernelGGL((gemm_swiglu512_kernel<true, true, true>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
-    else if (mode == 4) hipLaunchKernelGGL((gemm_swiglu512_kernel<true, false, false, true>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
-    else hipLaunchKernelGGL((gemm_swiglu512_kernel<true, false, false>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
+    if (mode == 1) hipLaunchKernelGGL((gemm_swiglu512_kernel<false>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
+    else hipLaunchKernelGGL((gemm_swiglu512_kernel<true>), grid, block, smem, s, A, lda, W, ldw, out, ldo, M, I, K);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

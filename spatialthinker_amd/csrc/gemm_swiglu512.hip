@@ -42,6 +42,8 @@ template <int N> __device__ __forceinline__ void s5_wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
+}  // namespace
+
 template <bool PP>
 __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ W,
                                                             int64_t ldw, uint16_t* __restrict__ out, int64_t ldo, int M, int I, int K) {
@@ -226,8 +228,6 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
         }
     }
 }
-
-}  // namespace
 
 // out[M, I] = silu(A gate_w^T) * (A up_w^T) for 1 <= M <= 512 in one pass over the weights (8-wave 512 x 80-column tiles, K-steps of 32)
 int st_gemm_swiglu512_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* out, int64_t ldo, int M, int I, int K,

@@ -30,7 +30,7 @@ def is_train_gemm(k):
 
 DECODE = ("gemm_tile_kernel<256, 160", "gemm_tile_kernel<256, 128", "gemm_tile_kernel<128,", "gemm_tile_kernel<64,", "attn_fwd128_kernel<false>",
           "attn_merge_kernel", "decode_finish", "decode_step_kernel", "sample_kernel", "sample_filter_kernel", "gemm_skinny_finish",
-          "gemm_a4_swiglu_finish_kernel", "attn_decode128_kernel", "gemm_tile_kernel<256, 256")      # the last one: the decode lm_head (the probe's prefill runs the 4-wave tile)
+          "gemm_a4_swiglu_finish_kernel", "attn_decode128_kernel", "gemm_tile_kernel<256, 256", "gemm_swiglu512_kernel")      # the last one: the decode lm_head (the probe's prefill runs the 4-wave tile)
 tr_bytes = tr_launch = 0.0
 per_kernel = {}
 dec_bytes = 0.0

@@ -51,4 +51,4 @@ for M in (257, 320, 384, 448, 512):
         e1.record(); torch.cuda.synchronize()
         res.setdefault(variant, []).append(e0.elapsed_time(e1) * 1e3 / 40)
     fl = 2.0 * M * 2 * I * K
-    print(f"M={M}: plan 1 (256x160, two rounds) {min(res[1]):.1f} us | plan 512 (one pass) {min(res[512]):.1f} us = {fl / min(res[512]) * 1e-6 / 1e3:.0f} TF/s", flush=True)
+    print(f"M={M}: plan 1 (256x160, two rounds) {min(res[1]):.1f} us | plan 512 (one pass) {min(res[512]):.1f} us = {fl / min(res[512]) * 1e-6:.0f} TF/s", flush=True)

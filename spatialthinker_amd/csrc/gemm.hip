@@ -446,7 +446,10 @@ static void decode_plan(int M, int N, int K, int64_t scratch_elems, int* variant
         if (bm == 64 && sp < 4 && tiles <= 128) sp = 4;
         if (bm == 64 && K >= 8192) sp = 8;
         if (sp > 8) sp = 8;
-        if (bm >= 128) sp = decode_fill_split(tiles, K / 64, 12);       // fill whole rounds of CUs (tools/decode_gemm_tune.py, M = 128 / 256 / 512)
+        // round 5: <= 64 rows too (ST_DECODE_SPLIT64=0: the older rule above).  The launch takes what the BUSIEST CU stages: 7B qkv at 64 rows
+        // was 72 tiles x 4 slices = 288 workgroups (32 CUs ran two), now 72 x 3 = 216; o 56 x 5 = 280 -> 56 x 4 = 224; down 28 x 8 -> 28 x 9
+        static const bool split64 = [] { const char* e = getenv("ST_DECODE_SPLIT64"); return !e || e[0] != '0'; }();
+        if (bm >= 128 || split64) sp = decode_fill_split(tiles, K / 64, 12);       // fill whole rounds of CUs (tools/decode_gemm_tune.py, M = 128 / 256 / 512)
         while (sp > 1 && (K / 64) / sp < 4) --sp;                       // keep >= 4 K-tiles per slice
         while (sp > 1 && (int64_t)sp * M * N > scratch_elems) --sp;
         if (sp < 1) sp = 1;

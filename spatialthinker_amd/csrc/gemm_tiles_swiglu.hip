@@ -8,6 +8,9 @@ int st_gemm_asm4_swiglu(const uint16_t* A, int64_t lda, const uint16_t* gate_up_
 // gemm_swiglu512.hip: all (<= 512) rows x 80 output columns per workgroup, ONE pass over the weights (round 5)
 int st_gemm_swiglu512_launch(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* out, int64_t ldo, int M, int I, int K,
                              hipStream_t s);
+// gemm_tiles_swiglu_small.hip: <= 128 rows, 160 weight rows per tile = 237 tiles, one per CU (variants 8 = 64 rows, 9 = 128 rows)
+int st_gemm_swiglu_small(int variant, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* out, int64_t ldo, int M, int I, int K,
+                         hipStream_t s);
 // 257..512 rows: plan 512 = the one-pass tile (ST_DECODE_GU512=0 falls back to the two-round 256x160 tile)
 static bool swiglu_decode_on_512(int M) {
     static const bool on = [] { const char* e = getenv("ST_DECODE_GU512"); return !e || e[0] != '0'; }();
@@ -42,6 +45,7 @@ extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int6
             if (lda >= (1 << 22) || ldb >= (1 << 22)) return ST_EINVAL;
             return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
         case 512: return st_gemm_swiglu512_launch(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
+        case 8: case 9: return st_gemm_swiglu_small(variant, A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 1: return launch_tile_swiglu<256, 160, 4, 2, 3, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 2: return launch_tile_swiglu<256, 192, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         case 3: return launch_tile_swiglu<256, 256, 4, 2, 2>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
@@ -59,9 +63,18 @@ extern "C" int st_gemm_swiglu_decode_variant(int variant, const st_bf16* A, int6
 // waves (237 tiles, one full round) measured SLOWER (+6 % decode step): each wave re-reads every B fragment from LDS.
 // 256x160 with the 8-column interleave (id 1): 3-slot ring (two K-tiles of weights in flight: the 2-slot variants sit parked on HBM
 // latency half of the time) and 237 workgroups for I = 18944: 90 us vs 102 us (256x192) on MI355X.
+// Round 5, <= 128 rows: a decode tile runs at the rate its CU stages bytes into the LDS (profiles/r05_notes.md §1b), so the launch takes what
+// the BUSIEST CU stages: rounds of tiles over the CUs x (rows + weight rows) of a tile.  7B: 296 tiles of 128 weight rows put two tiles on 40
+// CUs (64 rows: 61-68 us, 128 rows: 79-84 us); 237 tiles of 160 (ids 8 / 9, the 8-column interleave) put one on each: 44-47 / 53-55 us,
+// weights at 5.8-6.1 TB/s.  3B (138 vs 172 tiles, both under one round) keeps the narrower tile.
 static int swiglu_decode_plan(int M, int I) {
-    if (M <= 64) return 7;
-    if (M <= 128) return 6;
+    if (M <= 128) {
+        const int ncu = st_num_cus(), bm = M <= 64 ? 64 : 128;
+        const int c128 = st_cdiv(st_cdiv(2 * I, 128), ncu) * (bm + 128), c160 = st_cdiv(st_cdiv(2 * I, 160), ncu) * (bm + 160);
+        static const bool wide_ok = [] { const char* e = getenv("ST_DECODE_GU_SMALL160"); return !e || e[0] != '0'; }();
+        if (wide_ok && c160 < c128) return M <= 64 ? 8 : 9;
+        return M <= 64 ? 7 : 6;
+    }
     auto cost = [&](int cols) { const int t = st_cdiv(M, 256) * st_cdiv(I, cols); return (double)st_cdiv(t, 256) * (cols + 24); };
     if (cost(80) <= cost(96) && cost(80) <= cost(128)) return 1;
     if (cost(96) <= cost(128)) return 2;
@@ -91,6 +104,7 @@ extern "C" int st_gemm_swiglu_decode(const st_bf16* A, int64_t lda, const st_bf1
         return st_gemm_asm4_swiglu(A, lda, gate_up_w, ldb, nullptr, 0, out, ldc, M, I, K, s, 1);
     if (swiglu_decode_on_512(M)) return st_gemm_swiglu512_launch(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     const int plan = swiglu_decode_plan(M, I);
+    if (plan == 8 || plan == 9) return st_gemm_swiglu_small(plan, A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
     if (g_decode_nt >= 2 || (g_decode_nt && M <= 256)) {     // one row tile: the weights are read once — non-temporal stream (2: always, A/B)
         if (plan == 7) return launch_tile_swiglu<64, 128, 1, 4, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);
         if (plan == 6 && M <= 128) return launch_tile_swiglu<128, 128, 2, 2, 3, false, false, true>(A, lda, gate_up_w, ldb, out, ldc, M, I, K, s);

@@ -848,3 +848,22 @@ def test_one_pass_512_row_swiglu_tile_is_bit_identical_to_the_two_round_tile(ops
     assert float((o5.float() - ref).abs().max() / ref.abs().max()) < 9.1e-3
     if M_ > 256:
         assert ops.swiglu_decode_plan(M_, I) == 512 and torch.equal(ops.gemm_swiglu_decode(a, w), o5)       # the decode entry takes it
+
+
+@pytest.mark.parametrize("M_,I,K", [(17, 1000, 128), (64, 80, 64), (33, 81, 192), (64, 18944, 3584), (128, 18944, 3584), (100, 11008, 2048), (1, 160, 64)])
+def test_one_tile_per_cu_small_swiglu_tiles_are_bit_identical(ops, M_, I, K):
+    """gemm_tiles_swiglu_small.hip (round 5): the <= 128-row gate/up + SwiGLU on 160-weight-row tiles (237 workgroups for the 7B MLP, one per
+    CU; plans 8 / 9) — same K order and epilogue roundings as the 256x160 tile (plan 1): bit-identical."""
+    from spatialthinker_amd.lib import lib
+    torch.manual_seed(M_ + I)
+    a = (torch.randn(M_, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(2 * I, K, device="cuda") * 0.05).bfloat16()
+    st = torch.cuda.current_stream().cuda_stream
+    o1 = torch.full((M_, I), 7.0, device="cuda", dtype=torch.bfloat16)
+    lib().st_gemm_swiglu_decode_variant(1, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), o1.data_ptr(), o1.stride(0), M_, I, K, st)
+    for v in ((8, 9) if M_ <= 64 else (9,)):
+        o = torch.full((M_, I), -7.0, device="cuda", dtype=torch.bfloat16)
+        lib().st_gemm_swiglu_decode_variant(v, a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), o.data_ptr(), o.stride(0), M_, I, K, st)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o), v
+    assert torch.equal(ops.gemm_swiglu_decode(a, w), o1)                    # whatever plan the decode entry takes

@@ -63,7 +63,8 @@ def test_decode_plan_query_is_host_only_and_picks_the_7b_tiles():
             seen.add(v); splits.append(sp)
             assert 1 <= sp <= 12 and (K // 64) // sp >= 4
     assert {14, 16, 18} <= seen and max(splits) >= 4
-    assert ops.swiglu_decode_plan(64, 18944) == 7 and ops.swiglu_decode_plan(128, 18944) == 6
+    assert ops.swiglu_decode_plan(64, 18944) == 8 and ops.swiglu_decode_plan(128, 18944) == 9          # 7B: 237 tiles of 160 weight rows, one per CU (round 5)
+    assert ops.swiglu_decode_plan(64, 11008) == 7 and ops.swiglu_decode_plan(128, 11008) == 6          # 3B: under one round either way -> the narrower tile
     # 257..512 rows: 512 = the one-pass 512-row tile of round 5 (gemm_swiglu512.hip; ST_DECODE_GU512=0 -> 1; 40 = the 4-wave tile with the
     # K-split SwiGLU tail: opt-in, ST_DECODE_GU_ASM4=1)
     assert ops.swiglu_decode_plan(256, 18944) == 1 and ops.swiglu_decode_plan(512, 18944) == 512 and ops.swiglu_decode_plan(257, 18944) == 512

@@ -823,7 +823,8 @@ def main():
         ops.K_GEMM: ("st_gemm_nt / st_gemm_nn / st_gemm_tn / st_gemm_swiglu: gemm_nt4_kernel (256x256x64, 4 waves x 128x128, hand-scheduled K loop; gemm_asm4.hip), gemm_nt_kernel<128,128> below 128 tiles (bf16 MFMA 16x16x32, LDS-DMA staged)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
         ops.K_ATTN_FWD: ("attn_fwd128_kernel<causal> (shared-prefix segments, MFMA 32x32x16)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
         ops.K_ATTN_BWD: ("attn_bwd128_dq/kv/reduce kernels", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
-        ops.K_VIT_ATTN: ("attn_fwd/bwd kernels, head dim 80 (ViT windows + full attention)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_VIT_ATTN: ("attn_fwd_kernel<80> (ViT full-attention layers; the backward of images >= 512 patches runs zero-padded on the head-dim-128 kernels)", "mfma", PEAK_BF16, 1e12, "TFLOP/s"),
+        ops.K_VIT_WIN: ("attn_win80_fwd/bwd_kernel (ViT windows of <= 64 tokens, one launch each way; bytes = q, k, v(, dO) in + o / dq, dk, dv out + lse, delta)", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_LOGPROB: ("logprob_fwd/bwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_RMSNORM: ("rmsnorm_fwd_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),
         ops.K_ADAMW: ("adamw_kahan_kernel", "hbm", PEAK_HBM, 1e9, "GB/s"),

@@ -31,7 +31,7 @@ const char* st_arch(void);            /* "gfx950" */
  * hipEventRecord on the launch stream; st_prof_read() synchronises those events and returns
  * the number of launches and their summed duration in milliseconds. */
 enum { ST_K_GEMM = 0, ST_K_ATTN_FWD = 1, ST_K_ATTN_BWD = 2, ST_K_LOGPROB = 3, ST_K_ADAMW = 4,
-       ST_K_RMSNORM = 5, ST_K_VIT_ATTN = 6, ST_K_DECODE_ATTN = 7, ST_K_GEMM_FP8 = 8, ST_K_COUNT = 9 };
+       ST_K_RMSNORM = 5, ST_K_VIT_ATTN = 6, ST_K_DECODE_ATTN = 7, ST_K_GEMM_FP8 = 8, ST_K_VIT_WIN = 9 /* ViT window attention (attention_win.hip): units = bytes */, ST_K_COUNT = 10 };
 int st_prof_enable(int klass, int max_events);
 int st_prof_read(int klass, int* launches, double* total_ms, double* total_units);
 int st_prof_disable(int klass);
@@ -206,7 +206,9 @@ int st_colsum(const st_bf16* in, int64_t ldin, float* out_f32, int accumulate, i
  * never materialised).  q (T, n_q, D) / k,v (T, n_kv, D) given as base pointers + row strides (they
  * may live inside one qkv buffer).  cu_seqlens (n_seq+1,) int32.  D = 128.  out (T, n_q*D) bf16,
  * lse (n_q, T) fp32 (natural log, scaled scores); max_seqlen = longest sequence (sizes the grid).  causal=0 gives the bidirectional form used by
- * the ViT (HF :225-291) where D = 80 is supported as well. */
+ * the ViT (HF :225-291) where D = 80 is supported as well; with D = 80, causal = 0, n_q == n_kv and max_seqlen <= 64 (the ViT's
+ * windows) both directions run the one-(window, head)-per-workgroup kernels of csrc/attention_win.hip (forward bit-identical to the
+ * generic kernel; backward in one launch, delta = sum_keys P dP; ST_VIT_WIN=0 in the environment keeps the generic kernels). */
 int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal,
                 st_bf16* out, int64_t ldo, float* lse, int max_seqlen, st_stream_t stream);
@@ -262,6 +264,7 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
  * in flight per CU), 0 = one workgroup per item (attn_fwd128_kernel<false>; default — measured faster, see attention.hip — and the
  * path of wider items).  Same arithmetic: bit-identical partials (tests/test_gpu_kernels.py).  ST_DECODE_ATTN=persistent sets the initial value to 1. */
 int st_decode_attn_select(int persistent);   /* 2 = the persistent kernel with TWO workgroups per CU (2-slot rings, 80 KiB of LDS each) */
+int64_t st_decode_attn_selected(void);       /* the current choice (0 unless ST_DECODE_ATTN / st_decode_attn_select say otherwise; pinned by tests/test_layout.py) */
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */
 int st_attn_merge(const st_bf16* parts, int64_t ldp, const float* lse, int n_parts, st_bf16* out, int64_t ldo, int rows,

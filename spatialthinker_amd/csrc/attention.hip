@@ -1573,6 +1573,19 @@ __global__ void attn_bwd128_reduce_kernel(const uint16_t* __restrict__ pk, const
 }
 
 
+// ViT windows (attention_win.hip): D = 80, bidirectional, n_q == n_kv, every sequence <= 64 tokens.  ST_VIT_WIN=0 keeps the generic kernels.
+int st_attn_win80_fwd_launch(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                             const int32_t* cu, int n_seq, int T, int n_q, float scale, uint16_t* out, int64_t ldo, float* lse,
+                             hipStream_t s);
+int st_attn_win80_bwd_launch(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                             const uint16_t* dout, int64_t lddo, const float* lse, const int32_t* cu, int n_seq, int T, int n_q,
+                             float scale, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk, uint16_t* dv, int64_t lddv,
+                             float* delta, hipStream_t s);
+// (plain functions, not lambdas: with a second lambda-initialised static in this file — one outside, one inside extern "C" — hipcc
+// initialised g_decode_attn_persistent below with THIS initialiser's value, and every decode launch took the persistent kernel)
+static bool vit_win_from_env() { const char* e = getenv("ST_VIT_WIN"); return !(e && e[0] == '0'); }
+static const bool g_vit_win = vit_win_from_env();
+
 extern "C" {
 
 static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
@@ -1605,6 +1618,11 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
                 const int32_t* cu_seqlens, int n_seq, int T, int n_q, int n_kv, int D, float scale, int causal, st_bf16* out,
                 int64_t ldo, float* lse, int max_seqlen, st_stream_t stream) {
     if (!cu_seqlens) return ST_EINVAL;
+    if (g_vit_win && D == 80 && !causal && n_q == n_kv && max_seqlen > 0 && max_seqlen <= 64) {
+        if (!q || !k || !v || !out || !lse || n_seq <= 0 || T <= 0 || n_q <= 0 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return ST_EINVAL;
+        StProfScope ps(ST_K_VIT_WIN, (hipStream_t)stream, 0.0);
+        return st_attn_win80_fwd_launch(q, ldq, k, ldk, v, ldv, cu_seqlens, n_seq, T, n_q, scale, out, ldo, lse, (hipStream_t)stream);
+    }
     return attn_fwd_launch(q, ldq, k, ldk, v, ldv, cu_seqlens, cu_seqlens + 1, cu_seqlens, cu_seqlens + 1, nullptr, 0, n_seq, T, n_q, n_kv, D,
                            scale, causal, out, ldo, lse, max_seqlen, D == 128 ? ST_K_ATTN_FWD : ST_K_VIT_ATTN, stream);
 }
@@ -1614,12 +1632,14 @@ int st_attn_fwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
 // with one workgroup per CU a single wave computes every tile of the CU (decode items have 7 or 56 query rows) and also issues its share
 // of the copies, ~2 us per tile, where two co-resident workgroups run two such waves side by side.  Kept selectable (ST_DECODE_ATTN=persistent,
 // st_decode_attn_select) and bit-identical (tests/test_gpu_kernels.py).
-static int g_decode_attn_persistent = [] { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'p') ? ((e[1] == '2') ? 2 : 1) : 0; }();      // "persistent" / "p2"
+static int decode_attn_from_env() { const char* e = getenv("ST_DECODE_ATTN"); return (e && e[0] == 'p') ? ((e[1] == '2') ? 2 : 1) : 0; }      // "persistent" / "p2"
+static int g_decode_attn_persistent = decode_attn_from_env();
 int st_decode_attn_select(int persistent) {          // 0 = one workgroup per item, 1 = persistent, one workgroup per CU, 2 = persistent, two per CU
     if (persistent < 0 || persistent > 2) return ST_EINVAL;
     g_decode_attn_persistent = persistent;
     return 0;
 }
+int64_t st_decode_attn_selected(void) { return g_decode_attn_persistent; }
 
 int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end,
@@ -1692,11 +1712,15 @@ int st_attn_bwd(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, co
         (lddk & 3) || (lddv & 3) || max_seqlen <= 0 || (D != 128 && D != 80))
         return ST_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    StProfScope ps(D == 128 ? ST_K_ATTN_BWD : ST_K_VIT_ATTN, s, 0.0);
+    const bool vit_win = g_vit_win && D == 80 && !causal && n_q == n_kv && max_seqlen <= 64;
+    StProfScope ps(D == 128 ? ST_K_ATTN_BWD : vit_win ? ST_K_VIT_WIN : ST_K_VIT_ATTN, s, 0.0);
     if (D == 128)
         return attn_bwd128_launch(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, cu_seqlens, cu_seqlens + 1, nullptr, nullptr, nullptr,
                                   cu_seqlens + n_seq, 0, n_seq, T, n_q, n_kv, scale, causal, dq, lddq, dk, lddk, dv, lddv, delta, workspace,
                                   workspace_bytes, max_seqlen, s);
+    if (vit_win)
+        return st_attn_win80_bwd_launch(q, ldq, k, ldk, v, ldv, dout, lddo, lse, cu_seqlens, n_seq, T, n_q, scale, dq, lddq, dk, lddk, dv, lddv,
+                                        delta, s);
     const dim3 gq(st_cdiv(max_seqlen, Q_TILE), n_q, n_seq), gk(st_cdiv(max_seqlen, 128), n_kv, n_seq);
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(st_cdiv((int64_t)T * n_q, 256)), dim3(256), 0, s, out, ldo, dout, lddo, T, n_q, D, delta);
 #define ST_BWD(DD, CC)                                                                                                         \

@@ -566,7 +566,7 @@ class Qwen25VL:
         out[..., :hd] = x3
         return out.view(Np, k * heads * 128)
 
-    def _vit_attn_fwd(self, qkv, cu, mx, a, pairs):
+    def _vit_attn_fwd(self, qkv, cu, mx, a, pairs, tokens=None):
         c = self.cfg
         heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
         if hd < 128 and mx >= self.VIT_PAD_MIN_SEQ:
@@ -576,10 +576,10 @@ class Qwen25VL:
                                    pairs=None if pairs is None else pairs * hd / 128.0)
             a.view(Np, heads, hd).copy_(op.view(Np, heads, 128)[..., :hd])
             return lse
-        _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a, pairs=pairs)
+        _, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], cu, mx, heads, heads, hd, self.v_scale, False, out=a, pairs=pairs, tokens=tokens)
         return lse
 
-    def _vit_attn_bwd(self, qkv, a, da, lse, cu, mx, dqkv, pairs):
+    def _vit_attn_bwd(self, qkv, a, da, lse, cu, mx, dqkv, pairs, tokens=None):
         c = self.cfg
         heads, hd, vh = c.v_heads, c.v_head_dim, c.v_hidden
         if hd < 128 and mx >= self.VIT_PAD_MIN_SEQ_BWD:
@@ -592,7 +592,7 @@ class Qwen25VL:
             dqkv.view(Np, 3, heads, hd).copy_(dp.view(Np, 3, heads, 128)[..., :hd])
             return
         ops.attn_bwd(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], a, da, lse, cu, mx, heads, heads, hd, self.v_scale, False,
-                     dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:], pairs=pairs)
+                     dqkv[:, :vh], dqkv[:, vh:2 * vh], dqkv[:, 2 * vh:], pairs=pairs, tokens=tokens)
 
     def _vit_forward(self, b: DeviceBatch, save: Optional[list]):
         c, w, v = self.cfg, self.p.w, b.vis
@@ -612,7 +612,7 @@ class Qwen25VL:
             full = i in c.v_fullatt
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             a = torch.zeros(Np, vh, dtype=BF16, device=x.device)
-            lse = self._vit_attn_fwd(qkv, cu, mx, a, v["pairs_img"] if full else v["pairs_win"])
+            lse = self._vit_attn_fwd(qkv, cu, mx, a, v["pairs_img"] if full else v["pairs_win"], tokens=N)
             x1 = ops.gemm_nt(a, w[p + "proj_w"], bias=w[p + "proj_b"], residual=x)
             h2, r2 = ops.rmsnorm_fwd(x1, w[p + "norm2"], 1e-6)
             gu = ops.gemm_nt(h2, w[p + "gu_w"], bias=w[p + "gu_b"])
@@ -658,7 +658,7 @@ class Qwen25VL:
             full = i in c.v_fullatt
             cu, mx = (v["cu_img"], v["max_img"]) if full else (v["cu_win"], v["max_win"])
             dqkv = torch.zeros_like(qkv)
-            self._vit_attn_bwd(qkv, a, da, lse, cu, mx, dqkv, v["pairs_img"] if full else v["pairs_win"])
+            self._vit_attn_bwd(qkv, a, da, lse, cu, mx, dqkv, v["pairs_img"] if full else v["pairs_win"], tokens=N)
             ops.rope_apply_(dqkv, v["cos"], v["sin"], 2 * heads, hd, inverse=True)
             self._dw(g[p + "qkv_w"], dqkv, h1, g[p + "qkv_b"])
             dh1 = ops.gemm_nn(dqkv, w[p + "qkv_w"])

@@ -17,7 +17,7 @@ from .lib import lib
 
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 KL_KINDS = {"kl": 0, "abs": 1, "mse": 2, "low_var_kl": 3, "chi2": 4}
-K_GEMM, K_ATTN_FWD, K_ATTN_BWD, K_LOGPROB, K_ADAMW, K_RMSNORM, K_VIT_ATTN, K_DECODE_ATTN, K_GEMM_FP8 = range(9)
+K_GEMM, K_ATTN_FWD, K_ATTN_BWD, K_LOGPROB, K_ADAMW, K_RMSNORM, K_VIT_ATTN, K_DECODE_ATTN, K_GEMM_FP8, K_VIT_WIN = range(10)
 
 
 def _s() -> int:
@@ -589,11 +589,23 @@ def colsum(x, out_f32=None, accumulate=False):
 
 
 # ------------------------------------------------------------------ attention
-def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=None, pairs=None):
+_VIT_WIN = os.environ.get("ST_VIT_WIN", "1")[:1] != "0"
+
+
+def _is_vit_window(max_seqlen, n_q, n_kv, D, causal) -> bool:
+    """the launches st_attn_fwd / st_attn_bwd hand to attention_win.hip (same rule as csrc/attention.hip)"""
+    return _VIT_WIN and D == 80 and not causal and n_q == n_kv and 0 < max_seqlen <= 64
+
+
+def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=None, pairs=None, tokens=None):
     """q (T, >=n_q*D) view, k/v (T, >=n_kv*D) views (row strides may exceed the width: qkv buffer slices).
-    pairs: number of (query, key) pairs the launch evaluates (host-side knowledge, only used for the profiling hooks)."""
+    pairs: number of (query, key) pairs the launch evaluates, tokens: rows inside the sequences (host-side knowledge, only used for
+    the profiling hooks: flops of the MFMA-bound kernels, bytes of the ViT window kernels)."""
     T = q.shape[0]
-    if pairs is not None:
+    if _is_vit_window(max_seqlen, n_q, n_kv, D, causal):
+        if tokens is not None:
+            prof_hint(K_VIT_WIN, tokens * n_q * (4.0 * D * 2 + 4))            # q, k, v in, o out, lse out
+    elif pairs is not None:
         prof_hint(K_ATTN_FWD if D == 128 else K_VIT_ATTN, 4.0 * D * n_q * pairs)
     o = torch.empty(T, n_q * D, dtype=BF16, device=q.device) if out is None else out
     lse = torch.empty(n_q, T, dtype=F32, device=q.device)
@@ -605,9 +617,12 @@ def attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, out=N
 _attn_ws = {}
 
 
-def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, dq, dk, dv, pairs=None):
+def attn_bwd(q, k, v, o, do, lse, cu_seqlens, max_seqlen, n_q, n_kv, D, scale, causal, dq, dk, dv, pairs=None, tokens=None):
     T = q.shape[0]
-    if pairs is not None:
+    if _is_vit_window(max_seqlen, n_q, n_kv, D, causal):
+        if tokens is not None:
+            prof_hint(K_VIT_WIN, tokens * n_q * (7.0 * D * 2 + 8))            # q, k, v, dO in, dq, dk, dv out, lse in, delta out
+    elif pairs is not None:
         prof_hint(K_ATTN_BWD if D == 128 else K_VIT_ATTN, 10.0 * D * n_q * pairs)
     delta = torch.empty(n_q, T, dtype=F32, device=q.device)
     need = int(lib().st_attn_bwd_workspace_bytes(T, n_q, D))
@@ -739,7 +754,7 @@ def add_(a, b, out=None):
 
 
 # ------------------------------------------------------------------ profiling hooks
-_prof_on = [False] * 9
+_prof_on = [False] * 10
 
 
 def prof_enable(klass: int, max_events: int = 200000, stride: int = 1):

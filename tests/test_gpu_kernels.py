@@ -513,6 +513,36 @@ def test_attn_bwd(ops, measured, lens, n_q, n_kv, D, causal):
         assert err < 8.0e-3, (name, err)                            # measured <= 0.0061 of the gradient's max (1.3x)
 
 
+def test_vit_window_attention_one_launch_kernels(ops, measured):
+    """D = 80 bidirectional sequences of <= 64 tokens (the ViT's windows) take attention_win.hip: one (window, head) pair per two-wave
+    workgroup, the backward in ONE launch.  Forward bit-identical to the generic D = 80 kernel (forced by passing max_seqlen = 65, which
+    only sizes its grid); backward against the fp32 autograd reference at the generic kernels' bound and next to the generic kernels."""
+    rs = np.random.RandomState(80)
+    lens = [64, 64, 33, 32, 31, 1, 17, 48, 64, 2, 63, 64, 8, 40, 64, 64]
+    n_q, D = 16, 80
+    qkv, cu = _attn_case(rs, lens, n_q, n_q, D)
+    T, W = qkv.shape[0], n_q * D
+    x = qkv.cuda()
+    q, k, v = x[:, :W], x[:, W:2 * W], x[:, 2 * W:]
+    scale = D ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, dev(cu), 64, n_q, n_q, D, scale, False)
+    out_g, lse_g = ops.attn_fwd(q, k, v, dev(cu), 65, n_q, n_q, D, scale, False)
+    assert torch.equal(out, out_g) and torch.equal(lse, lse_g)
+    do = bf(rs.standard_normal((T, W))).cuda()
+    dqkv, dqkv_g = torch.zeros_like(x), torch.zeros_like(x)
+    ops.attn_bwd(q, k, v, out, do, lse, dev(cu), 64, n_q, n_q, D, scale, False, dqkv[:, :W], dqkv[:, W:2 * W], dqkv[:, 2 * W:])
+    ops.attn_bwd(q, k, v, out, do, lse, dev(cu), 65, n_q, n_q, D, scale, False, dqkv_g[:, :W], dqkv_g[:, W:2 * W], dqkv_g[:, 2 * W:])
+    xf = qkv.float().clone().requires_grad_(True)
+    o = Q.dense_attention(xf[:, :W].reshape(T, n_q, D), xf[:, W:2 * W].reshape(T, n_q, D), xf[:, 2 * W:].reshape(T, n_q, D), cu, False).reshape(T, W)
+    o.backward(do.float().cpu())
+    got, gen, want = dqkv.float().cpu().numpy(), dqkv_g.float().cpu().numpy(), xf.grad.numpy()
+    for name, sl in (("dq", slice(0, W)), ("dk", slice(W, 2 * W)), ("dv", slice(2 * W, None))):
+        den = np.abs(want[:, sl]).max() + 1e-9
+        err, err_g = np.abs(got[:, sl] - want[:, sl]).max() / den, np.abs(gen[:, sl] - want[:, sl]).max() / den
+        measured(f"vit_window_bwd_{name}_rel", err)
+        assert err < 8.0e-3 and err < 1.5 * err_g + 1e-3, (name, err, err_g)
+
+
 # ------------------------------------------------------------------ fused decode epilogues vs the unfused launch chain
 @pytest.mark.parametrize("M,B", [(32, 24), (64, 64), (160, 150)])
 def test_decode_fused_ops_bit_identical(ops, M, B):

@@ -19,8 +19,20 @@ def test_c_abi_exports_every_declared_symbol():
         assert len(argtypes) == len(argnames)
         if name not in ("st_version", "st_arch", "st_prof_enable", "st_prof_read", "st_prof_disable", "st_prof_set_stride", "st_prof_hint_units", "st_prof_seen",
                             "st_attn_bwd_workspace_bytes", "st_prof_read_events", "st_stream_create_cu_range", "st_stream_destroy",
-                            "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan", "st_gemm_select", "st_decode_attn_select", "st_gemm_mxfp8_select"):
+                            "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan", "st_gemm_select", "st_decode_attn_select", "st_decode_attn_selected", "st_gemm_mxfp8_select"):
             assert argnames[-1] == "stream", f"{name}: every compute entry takes the stream last"
+
+
+def test_library_defaults_after_load():
+    """The switches the library reads from the environment at load time hold their documented defaults when the variables are unset
+    (round 5: a second lambda-initialised static in attention.hip made hipcc initialise the decode-attention choice with the OTHER
+    static's value — every decode launch silently took the slower persistent kernel; the tests stayed green, only the bench showed it)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ST_")}
+    code = "from spatialthinker_amd.lib import lib; print(int(lib().st_decode_attn_selected()))"
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, text=True)
+    assert out.strip().splitlines()[-1] == "0", out
 
 
 def test_product_code_never_imports_the_oracle():

@@ -7,6 +7,7 @@ from spatialthinker_amd import ops
 from spatialthinker_amd.lib import lib
 
 L = lib()
+EXTRA = int(os.environ.get("PROBE_VARIANT", "0"))      # a third variant id to check and time (experiments)
 
 
 def run(variant, a, w, out):
@@ -22,6 +23,9 @@ for (M, I, K) in [(257, 1000, 128), (300, 80, 64), (512, 81, 192), (384, 18944, 
     w = (torch.randn(2 * I, K, device="cuda") * 0.05).bfloat16()
     o1 = torch.full((M, I), 7.0, device="cuda", dtype=torch.bfloat16); o5 = torch.full((M, I), -7.0, device="cuda", dtype=torch.bfloat16)
     run(1, a, w, o1); run(512, a, w, o5)
+    if EXTRA:
+        ox = torch.full((M, I), -3.0, device="cuda", dtype=torch.bfloat16); run(EXTRA, a, w, ox)
+        print(f"   variant {EXTRA} identical to plan 1: {bool(torch.equal(o1, ox))}")
     torch.cuda.synchronize()
     want = a.float() @ w.float().t()
     g_, u_ = want[:, :I].bfloat16().float(), want[:, I:].bfloat16().float()
@@ -35,7 +39,7 @@ for M in (257, 320, 384, 448, 512):
     a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
     out = torch.empty(M, I, device="cuda", dtype=torch.bfloat16)
     res = {}
-    for variant in (1, 512, 1, 512):
+    for variant in (1, 512, 1, 512) + ((EXTRA, EXTRA) if EXTRA else ()):
         for w in ws:
             run(variant, a, w, out)
         torch.cuda.synchronize()
@@ -51,4 +55,5 @@ for M in (257, 320, 384, 448, 512):
         e1.record(); torch.cuda.synchronize()
         res.setdefault(variant, []).append(e0.elapsed_time(e1) * 1e3 / 40)
     fl = 2.0 * M * 2 * I * K
-    print(f"M={M}: plan 1 (256x160, two rounds) {min(res[1]):.1f} us | plan 512 (one pass) {min(res[512]):.1f} us = {fl / min(res[512]) * 1e-6:.0f} TF/s", flush=True)
+    print(f"M={M}: plan 1 (256x160, two rounds) {min(res[1]):.1f} us | plan 512 (one pass) {min(res[512]):.1f} us = {fl / min(res[512]) * 1e-6:.0f} TF/s"
+          + (f" | variant {EXTRA}: {min(res[EXTRA]):.1f} us" if EXTRA else ""), flush=True)

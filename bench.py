@@ -745,11 +745,11 @@ def main():
         data = dict(input_ids=out["input_ids"], attention_mask=mask_f, position_ids=out["position_ids"], responses=out["responses"],
                     multi_modal_inputs=mm)
         # ---- reward: dense spatial scorer on templated strings (no tokenizer offline), score at the last valid token
-        preds, gts, problems = synth_reward_strings(B, rs)
         reward_out = {}
 
         def score_rewards():                                 # host work that needs only the rollout: runs beside the old / ref passes
             t_ = time.perf_counter()                         # on a thread (as RayPPOTrainer.fit does, _RewardJob), joined before `adv`
+            preds, gts, problems = synth_reward_strings(B, rs)       # stands for the reward manager's tokenizer.batch_decode: scorer-side host work
             scores = torch.tensor([spatial_sgg_compute_score(p, g, q)["overall"] for p, g, q in zip(preds, gts, problems)], dtype=torch.float32)
             rw = torch.zeros(B, R)
             rw[torch.arange(B), rmask.sum(1) - 1] = scores

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(128, 2) void attn_win80_fwd_kernel(const uint16_t* 
     WIN_ITEM(seq, h);
     const int s0 = cu[seq], L = cu[seq + 1] - s0;
     if (L <= 0) return;
+    if (L > 64) __builtin_trap();                           // the caller promised max_seqlen <= 64: fail loudly, not with partial windows
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
     const int col = h * W_D;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(128, 2) void attn_win80_bwd_kernel(const uint16_t* 
     WIN_ITEM(seq, h);
     const int s0 = cu[seq], L = cu[seq + 1] - s0;
     if (L <= 0) return;
+    if (L > 64) __builtin_trap();                           // the caller promised max_seqlen <= 64: fail loudly, not with partial windows
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qc = lane & 31, half = lane >> 5;
     const int col = h * W_D;

@@ -109,10 +109,10 @@ __device__ __forceinline__ void win_store_rows(uint16_t* __restrict__ dst, int64
 // interleaved 160-byte pieces of the same (T, 3 x 1280) rows — most 128-byte lines belong to two neighbouring heads.  Workgroups
 // id = 8 j + x with the same x run on one XCD: they walk the heads of window 8 (j / n_q) + x in turn, so a window's lines are fetched
 // into ONE L2 and used completely there (window-major ids fetched 1.5x the bytes).
-#define WIN_ITEM(seq, h)                                                                          \
+#define WIN_ITEM(SEQ, HEAD)                                                                       \
     const int wi_slot_ = blockIdx.x >> 3;                                                         \
-    const int h = wi_slot_ % n_q, seq = (wi_slot_ / n_q) * 8 + (blockIdx.x & 7);                  \
-    if (seq >= n_seq) return
+    const int HEAD = wi_slot_ % n_q, SEQ = (wi_slot_ / n_q) * 8 + (blockIdx.x & 7);               \
+    if (SEQ >= n_seq) return
 
 __global__ __launch_bounds__(128, 2) void attn_win80_fwd_kernel(const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ k,
                                                             int64_t ldk, const uint16_t* __restrict__ v, int64_t ldv,

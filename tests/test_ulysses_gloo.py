@@ -136,3 +136,54 @@ def test_ulysses_layer_equals_the_single_process_layer_forward_and_backward(tmp_
         assert torch.equal(r[k]["a2a"], want)
         assert r[k]["full_a"].flatten().tolist() == [0, 1, 2, 100, 101, 102] and r[k]["full_s"] == [f"r{j}_{i}" for j in range(world) for i in range(3)]
         assert r[k]["back_a"].flatten().tolist() == [100 * k + i for i in range(3)] and r[k]["back_s"] == [f"r{k}_{i}" for i in range(3)]
+
+
+def _golden_worker(rank, world, port, out_dir):
+    """the calls of tests/golden/make_ulysses_golden.py:worker, on this repo's module"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_ulysses_golden import inputs
+    from verl.utils import ulysses as U
+    U.set_ulysses_sequence_parallel_group(dist.group.WORLD)
+    i = inputs(rank)
+    res = {}
+    ids, pos, pad = U.ulysses_pad_and_slice_inputs(i["ids"], i["pos"], sp_size=world)
+    res.update(pad_ids=ids, pad_pos=pos, pad_size=torch.tensor(pad))
+    res["slice_pad"] = U.slice_input_tensor(i["pos"].double(), dim=1, padding=True)
+    res["gather_seq"] = U.gather_seq_scatter_heads(i["x_seq"], seq_dim=1, head_dim=2)
+    res["gather_seq_unpad"] = U.gather_seq_scatter_heads(i["x_seq"], seq_dim=1, head_dim=2, unpadded_dim_size=37)
+    res["gather_heads"] = U.gather_heads_scatter_seq(i["x_head"], head_dim=2, seq_dim=1)
+    for scaler in (True, False):
+        y = i["y"].clone().requires_grad_(True)
+        full = U.gather_outputs_and_unpad(y, gather_dim=0, unpad_dim=0, padding_size=1, grad_scaler=scaler)
+        (full * i["gy"]).sum().backward()
+        res[f"gather_out_{int(scaler)}"] = full.detach()
+        res[f"gather_out_grad_{int(scaler)}"] = y.grad
+    xs = i["x_seq"].clone().requires_grad_(True)
+    o = U.gather_seq_scatter_heads(xs, seq_dim=1, head_dim=2)
+    (o * torch.arange(o.numel(), dtype=torch.float64).view_as(o)).sum().backward()
+    res["gather_seq_grad"] = xs.grad
+    U.set_ulysses_sequence_parallel_group(None)
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), **{k: v.numpy() for k, v in res.items()})
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_ulysses_utilities_equal_the_reference_modules_outputs(tmp_path):
+    """tests/golden/ulysses.npz = the reference's verl/utils/ulysses.py run on two gloo ranks in the build container
+    (tests/golden/make_ulysses_golden.py): pad-and-slice of the token stream, both all-to-all directions (with and without the unpadded
+    length), the gather of the per-slice outputs with and without the gradient scaler, and the backward of each — equal bit for bit."""
+    world = 2
+    mp.spawn(_golden_worker, args=(world, 29593, str(tmp_path)), nprocs=world)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ulysses.npz"))
+    n = 0
+    for r in range(world):
+        got = np.load(tmp_path / f"g{r}.npz")
+        keys = [k[len(f"r{r}_"):] for k in gold.files if k.startswith(f"r{r}_")]
+        assert sorted(keys) == sorted(got.files)
+        for k in keys:
+            want = gold[f"r{r}_{k}"]
+            assert got[k].shape == want.shape and got[k].dtype == want.dtype and np.array_equal(got[k], want), (r, k)
+            n += 1
+    assert n == 24

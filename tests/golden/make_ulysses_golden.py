@@ -8,6 +8,8 @@ import importlib.util
 import os
 import sys
 
+sys.dont_write_bytecode = True          # the reference tree is read-only: no __pycache__ next to its sources (spawned workers re-run this line)
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -509,6 +509,32 @@ def _hf_tiny_model():
     return model
 
 
+def gen_rewards_math():
+    """The reference's `math` plug-in (verl/utils/reward_score/math.py:21-40) with mathruler's two functions stubbed by THIS build's
+    documented fallbacks (last brace-matched \\boxed{}, normalised string equality): pins the clean-up regex, the format regex and the
+    0.9 / 0.1 weighting; mathruler's own grading stays unpinned (not installed)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from verl.utils.reward_score import math as build_math
+    _stub_similarity_modules()
+    sys.modules["mathruler.grader"].extract_boxed_content = build_math._boxed
+    sys.modules["mathruler.grader"].grade_answer = build_math._grade
+    ref = _load(os.path.join(REF, "verl/utils/reward_score/math.py"), "ref_math")
+    cases = [
+        ("<think>2+2</think> so \\boxed{4}", "4"), ("<think>x</think>\\boxed{ 4 }", "4"), ("<think>x</think> \\boxed{5}", "4"),
+        ("\\boxed{4}", "4"), ("<think>no box</think> 4", "4"), ("< think >a< / think > \\boxed{\\frac{1}{2}}", "\\frac{1}{2}"),
+        ("<think>a</think>\\boxed{1} then \\boxed{2}", "2"), ("<think>a</think>\\boxed{1} then \\boxed{2}", "1"),
+        ("<think>a</think>\\boxed{x^{2}+1}", "x^{2} + 1"), ("<think>a</think>\\boxed{unclosed", "unclosed"), ("", ""),
+        ("<think>\n multi\n line</think>\n\\boxed{A}\n", "a"), ("<think>a</think>\\boxed{$3$}", "3"), ("<think>a</think>\\boxed{}", ""),
+        ("text <think>a</think>\\boxed{7}", "7"), ("<think>a</think>\\boxed{7} trailing words", "7"),
+    ]
+    cases = [(p_.replace("\\\\", "\\"), g_.replace("\\\\", "\\")) for p_, g_ in cases]
+    rows = [{"predict": p_, "ground_truth": g_, "score": ref.math_compute_score(p_, g_)} for p_, g_ in cases]
+    with open(os.path.join(HERE, "rewards_math.json"), "w") as f:
+        json.dump({"stubs": "mathruler.grader.extract_boxed_content / grade_answer = verl.utils.reward_score.math._boxed / _grade (mathruler absent: UNPINNED)",
+                   "cases": rows}, f, indent=1)
+    print("rewards_math:", len(rows), "cases;", sum(r["score"]["accuracy"] for r in rows), "accurate,", sum(r["score"]["format"] for r in rows), "well-formed")
+
+
 def gen_generate():
     """Greedy continuation by HF itself (`model.generate(do_sample=False)`, its own KV cache and rope-index bookkeeping) for the two
     tiny image+text prompts: pins the oracle's KV-cache decode (oracle.qwen25vl.generate_greedy) and, through it, the GPU rollout."""
@@ -863,7 +889,7 @@ def gen_update_loop():
     save("update_loop", **out)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "model", "extra", "dataset", "generate", "loop", "values"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "math", "model", "extra", "dataset", "generate", "loop", "values"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -874,6 +900,8 @@ if __name__ == "__main__":
         gen_rewards()
     if "graded" in which:
         gen_rewards_graded()
+    if "math" in which:
+        gen_rewards_math()
     if "model" in which:
         gen_model()
     if "extra" in which:

@@ -79,3 +79,17 @@ def test_graded_similarity_scores_and_assignments_are_float64_exact(graded):
         S.set_similarity(S._exact_similarity)
     assert differ >= 20 and scored >= 8 and len(gold["cases"]) >= 50, (differ, scored)
     assert any(0.0 < c["spatial_sgg_graded"]["spatial_score"] < 1.0 for c in gold["cases"])
+
+
+def test_math_plugin_equals_the_reference_module_on_its_stubbed_graders():
+    """rewards_math.json = the reference's verl/utils/reward_score/math.py:21-40 run with mathruler's two functions stubbed by this build's
+    documented fallbacks (make_golden.py math): the clean-up regex, the format regex and the 0.9 / 0.1 weighting, float64-exact."""
+    import json
+    import os
+    from verl.utils.reward_score import math_compute_score
+    from verl.workers.reward.custom import _SCORERS
+    assert _SCORERS["math"] is math_compute_score                     # the reference's DEFAULT worker.reward.score_function resolves
+    rows = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rewards_math.json")))["cases"]
+    assert len(rows) >= 16
+    for r in rows:
+        assert math_compute_score(r["predict"], r["ground_truth"]) == r["score"], r

@@ -8,9 +8,9 @@ from typing import Callable, Dict, List, Tuple
 import torch
 
 from ...protocol import DataProto
-from ...utils.reward_score import r1v_compute_score, r1v_scene_compute_score, spatial_sgg_compute_score
+from ...utils.reward_score import math_compute_score, r1v_compute_score, r1v_scene_compute_score, spatial_sgg_compute_score
 
-_SCORERS: Dict[str, Callable] = {"r1v": r1v_compute_score, "r1v_scene": r1v_scene_compute_score, "spatial_sgg": spatial_sgg_compute_score}
+_SCORERS: Dict[str, Callable] = {"math": math_compute_score, "r1v": r1v_compute_score, "r1v_scene": r1v_scene_compute_score, "spatial_sgg": spatial_sgg_compute_score}
 
 
 class CustomRewardManager:

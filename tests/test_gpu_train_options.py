@@ -205,3 +205,40 @@ def test_worker_checkpoint_resume_is_bit_identical(tmp_path):
     from spatialthinker_amd.pretrained import load_model
     _, st2, _ = load_model(str(hf), trainable=False)
     assert st2.flat.shape == a.actor.store.flat.shape
+
+
+@pytest.mark.gpu
+def test_reference_actor_class_runs_the_engine_behind_the_reference_signatures():
+    """verl.workers.actor.DataParallelPPOActor(config, actor_module) over the worker's engines: compute_log_prob(DataProto) equals what
+    FSDPWorker.compute_log_probs / compute_ref_log_probs return for the same batch (bit for bit: the same packed passes), and
+    update_policy(DataProto) returns the reference's metric keys and moves the weights."""
+    from verl.protocol import DataProto
+    from verl.trainer.config import load_config
+    from verl.utils.dataset import SyntheticSTVQADataset, collate_fn
+    from verl.workers.actor import DataParallelPPOActor
+    from verl.workers.fsdp_workers import FSDPWorker
+    cfg = load_config(["data.rollout_batch_size=2", "data.max_prompt_length=64", "data.max_response_length=12",
+                       "worker.actor.model.model_path=random:tiny", "worker.actor.global_batch_size=2", "worker.actor.fsdp.torch_dtype=bf16",
+                       "worker.actor.optim.strategy=adamw_bf16", "worker.actor.optim.lr=1.0e-3", "worker.rollout.n=2",
+                       "worker.actor.micro_batch_size_per_device_for_update=2", "worker.actor.micro_batch_size_per_device_for_experience=4"])
+    cfg.deep_post_init()
+    w = FSDPWorker(cfg.worker, "actor_rollout_ref")
+    w.init_model()
+    ds = SyntheticSTVQADataset(w.model_config, w.tokenizer, size=8, max_prompt_length=64, seed=5, grid=(1, 8, 8), text_tokens=(8, 12))
+    b = DataProto.from_single_dict(collate_fn([ds[0], ds[1]]))
+    gen = b.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=["raw_prompt_ids", "multi_modal_data", "multi_modal_inputs"])
+    b = b.repeat(2, interleave=True).union(w.generate_sequences(gen))
+    b.meta_info["global_token_num"] = b.batch["attention_mask"].sum(-1).tolist()
+    old, ref = w.compute_log_probs(b), w.compute_ref_log_probs(b)
+    b.meta_info["temperature"] = cfg.worker.rollout.temperature
+    actor = DataParallelPPOActor(cfg.worker.actor, w.actor)
+    ref_actor = DataParallelPPOActor(cfg.worker.ref, w.ref_policy)
+    assert torch.equal(actor.compute_log_prob(b), old.batch["old_log_probs"])
+    assert torch.equal(ref_actor.compute_log_prob(b), ref.batch["ref_log_probs"])
+    b = b.union(old).union(ref)
+    b.batch["advantages"] = torch.linspace(-1, 1, 4)[:, None].repeat(1, 12) * b.batch["response_mask"]
+    w.actor.sched_steps = 1                                   # past the scheduler's lr = 0 first step
+    before = w.actor.store.flat.clone()
+    metrics = actor.update_policy(b)
+    assert {"actor/pg_loss", "actor/pg_clipfrac_higher", "actor/pg_clipfrac_lower", "actor/ppo_kl", "actor/grad_norm"} <= set(metrics), sorted(metrics)
+    assert not torch.equal(w.actor.store.flat, before)

@@ -163,3 +163,27 @@ def test_synthetic_lengths_travel_as_dataset_rows_not_as_a_worker_hook():
     assert np.array_equal(lens, ds[3]["synthetic_response_lengths"])                  # deterministic per row
     assert "synthetic_response_lengths" not in SyntheticSTVQADataset(mcfg, get_tokenizer("random:tiny"), size=8, max_prompt_length=128,
                                                                       grid=(1, 8, 8), text_tokens=(8, 12))[3]
+
+
+def test_reference_worker_subpackage_import_paths_resolve():
+    """The names the reference's workers import from their sub-packages (verl/workers/fsdp_workers.py:43-60: `from .actor import
+    DataParallelPPOActor`, `.critic`, `.rollout`, `.config.WorkerConfig`, reward `CustomRewardManager`; each package's __init__ exports)
+    exist under the same paths and are the objects the trainer uses."""
+    import verl.trainer.config as C
+    from verl.workers.actor import ActorConfig, BasePPOActor, DataParallelPPOActor, FSDPConfig, ModelConfig, OptimConfig, RefConfig
+    from verl.workers.actor.config import OffloadConfig
+    from verl.workers.config import WorkerConfig
+    from verl.workers.critic import BasePPOCritic, CriticConfig, DataParallelPPOCritic
+    from verl.workers.reward import CustomRewardManager, RewardConfig
+    from verl.workers.rollout import BaseRollout, RolloutConfig
+    assert ActorConfig is C.ActorConfig and RefConfig is C.RefConfig and CriticConfig is C.CriticConfig and WorkerConfig is C.WorkerConfig
+    assert RolloutConfig is C.RolloutConfig and RewardConfig is C.RewardConfig and FSDPConfig is C.FSDPConfig and ModelConfig is C.ModelConfig
+    assert OptimConfig is C.OptimConfig and OffloadConfig is C.OffloadConfig and CustomRewardManager is not None and BaseRollout is not None
+    assert issubclass(DataParallelPPOActor, BasePPOActor) and issubclass(DataParallelPPOCritic, BasePPOCritic)
+    for cls, methods in ((BasePPOActor, ("compute_log_prob", "update_policy")), (BasePPOCritic, ("compute_values", "update_critic"))):
+        assert set(cls.__abstractmethods__) == set(methods)
+    import pytest
+    with pytest.raises(TypeError):                                       # the module argument is this build's engine, not an nn.Module
+        DataParallelPPOActor(C.ActorConfig(), torch.nn.Linear(2, 2))
+    with pytest.raises(TypeError):
+        DataParallelPPOCritic(C.CriticConfig(), torch.nn.Linear(2, 2))

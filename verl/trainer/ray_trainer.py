@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 from ..protocol import DataProto
 from ..utils.dataloader import ForeignDataloaderState, ResumableDataLoader
+from ..utils.logger import Tracker
 from ..utils.seqlen_balancing import get_seqlen_balanced_partitions, log_seqlen_unbalance
 from . import core_algos
 from .metrics import compute_data_metrics, compute_throughout_metrics, compute_timing_metrics, reduce_metrics
@@ -101,24 +102,6 @@ def apply_kl_penalty(data: DataProto, kl_ctrl, kl_penalty="kl", gather=None):
     metrics = {"critic/kl": cur, "critic/kl_coef": kl_ctrl.kl_coef}
     kl_ctrl.update(current_kl=cur, n_steps=int(per_seq.numel()))
     return data, metrics
-
-
-class ConsoleTracker:
-    def __init__(self, loggers, config=None):
-        self.rank = int(os.environ.get("RANK", 0))
-        extra = [l for l in loggers if l != "console"]
-        if extra and self.rank == 0:
-            print(f"[logger] only the console logger is built; ignoring {extra}")
-
-    def log(self, data: Dict[str, Any], step: int):
-        if self.rank == 0:
-            print(f"step {step}: " + " - ".join(f"{k}:{v:.4g}" if isinstance(v, (int, float)) else f"{k}:{v}" for k, v in sorted(data.items())), flush=True)
-
-    def log_generation(self, samples: List[tuple], step: int):
-        """utils/logger/gen_logger.py's console flavour: (input, output, label, score) rows."""
-        if self.rank == 0:
-            for inp, out, lab, score in samples:
-                print(f"[val generation @ step {step}] score={score:.4g}\n  prompt: {inp[:200]!r}\n  output: {out[:400]!r}\n  label : {str(lab)[:200]!r}", flush=True)
 
 
 def remove_obsolete_ckpt(path: str, global_step: int, save_limit: int = -1, directory_format: str = "global_step_{}"):
@@ -211,7 +194,7 @@ class RayPPOTrainer:
         act.optim.training_steps = self.training_steps
         config.worker.critic.optim.training_steps = self.training_steps
         self.global_step = 0
-        self.logger = ConsoleTracker(t.logger)
+        self.logger = Tracker(loggers=t.logger, config=config.to_dict())          # ray_trainer.py:566 of the reference
 
     def set_worker_groups(self, actor_rollout_wg, ref_policy_wg, critic_wg=None):
         self.actor_rollout_wg, self.ref_policy_wg, self.critic_wg = actor_rollout_wg, ref_policy_wg, critic_wg

@@ -187,3 +187,32 @@ def test_reference_worker_subpackage_import_paths_resolve():
         DataParallelPPOActor(C.ActorConfig(), torch.nn.Linear(2, 2))
     with pytest.raises(TypeError):
         DataParallelPPOCritic(C.CriticConfig(), torch.nn.Linear(2, 2))
+
+
+def test_reference_util_import_paths_resolve(tmp_path, capsys):
+    """verl.utils.checkpoint.{CHECKPOINT_TRACKER, remove_obsolete_ckpt}, checkpoint_manager.find_latest_ckpt_path, verl.utils.torch_dtypes.
+    PrecisionType, verl.utils.model_utils — the names the reference's trainer and workers import (ray_trainer.py:43, fsdp_workers.py:53-55)."""
+    from verl.utils.checkpoint import CHECKPOINT_TRACKER, remove_obsolete_ckpt
+    from verl.utils.checkpoint.checkpoint_manager import find_latest_ckpt_path, get_checkpoint_tracker_filename
+    from verl.utils.model_utils import is_rank0, print_model_size
+    from verl.utils.torch_dtypes import PrecisionType
+    assert CHECKPOINT_TRACKER == "latest_global_step.txt" and find_latest_ckpt_path(None) is None and find_latest_ckpt_path(str(tmp_path)) is None
+    for s in (2, 4, 6, 8):
+        (tmp_path / f"global_step_{s}").mkdir()
+    (tmp_path / "notes").mkdir()
+    with open(get_checkpoint_tracker_filename(str(tmp_path)), "w") as f:
+        f.write("8")
+    assert find_latest_ckpt_path(str(tmp_path)) == str(tmp_path / "global_step_8")
+    remove_obsolete_ckpt(str(tmp_path), 8, save_limit=2)                 # the step being written + ONE older
+    assert sorted(p.name for p in tmp_path.iterdir() if p.is_dir()) == ["global_step_6", "global_step_8", "notes"]
+    with open(get_checkpoint_tracker_filename(str(tmp_path)), "w") as f:
+        f.write("10")
+    assert find_latest_ckpt_path(str(tmp_path)) is None                 # tracker ahead of the directories
+    assert PrecisionType.to_dtype("bf16") is torch.bfloat16 and PrecisionType.to_dtype(32) is torch.float32 and PrecisionType.to_dtype("fp16") is torch.float16
+    assert PrecisionType.to_str(torch.bfloat16) == "bfloat16" and PrecisionType.is_bf16("bfloat16") and not PrecisionType.is_fp32("bf16")
+    with pytest.raises(RuntimeError):
+        PrecisionType.to_dtype("fp8")
+    capsys.readouterr()
+    assert is_rank0()
+    print_model_size(torch.nn.Linear(1000, 2000), name="toy")
+    assert "toy contains 2.00M parameters." in capsys.readouterr().out

@@ -24,13 +24,13 @@ import torch
 import torch.distributed as dist
 
 from ..protocol import DataProto
+from ..utils.checkpoint.checkpoint_manager import CHECKPOINT_TRACKER, remove_obsolete_ckpt
 from ..utils.dataloader import ForeignDataloaderState, ResumableDataLoader
 from ..utils.logger import Tracker
 from ..utils.seqlen_balancing import get_seqlen_balanced_partitions, log_seqlen_unbalance
 from . import core_algos
 from .metrics import compute_data_metrics, compute_throughout_metrics, compute_timing_metrics, reduce_metrics
 
-CHECKPOINT_TRACKER = "latest_global_step.txt"
 
 
 class AdvantageEstimator(str, Enum):
@@ -102,19 +102,6 @@ def apply_kl_penalty(data: DataProto, kl_ctrl, kl_penalty="kl", gather=None):
     metrics = {"critic/kl": cur, "critic/kl_coef": kl_ctrl.kl_coef}
     kl_ctrl.update(current_kl=cur, n_steps=int(per_seq.numel()))
     return data, metrics
-
-
-def remove_obsolete_ckpt(path: str, global_step: int, save_limit: int = -1, directory_format: str = "global_step_{}"):
-    """Keep the newest save_limit - 1 step directories older than `global_step` (utils/checkpoint/checkpoint_manager.py:138-160)."""
-    if save_limit <= 0 or not os.path.exists(path):
-        return
-    pat = directory_format.format("")
-    steps = []
-    for name in os.listdir(path):
-        if name.startswith(pat) and name[len(pat):].isdigit() and int(name[len(pat):]) < global_step:
-            steps.append(int(name[len(pat):]))
-    for s in sorted(steps, reverse=True)[save_limit - 1:]:
-        shutil.rmtree(os.path.join(path, directory_format.format(s)), ignore_errors=True)
 
 
 class _RewardJob:

@@ -216,3 +216,21 @@ def test_reference_util_import_paths_resolve(tmp_path, capsys):
     assert is_rank0()
     print_model_size(torch.nn.Linear(1000, 2000), name="toy")
     assert "toy contains 2.00M parameters." in capsys.readouterr().out
+
+
+def test_checkpoint_manager_classes_and_remaining_reference_names():
+    """FSDPCheckpointManager / BaseCheckpointManager (fsdp_checkpoint_manager.py:34, checkpoint_manager.py:34), Role (ray_trainer.py:53-64),
+    the r1v_scene module path and the config re-exports of verl.workers.config."""
+    from verl.trainer.ray_trainer import Role
+    from verl.utils.checkpoint import BaseCheckpointManager, FSDPCheckpointManager
+    from verl.utils.reward_score.r1v_scene import r1v_scene_compute_score
+    from verl.workers.config import FSDPConfig, ModelConfig, OptimConfig  # noqa: F401
+    assert issubclass(FSDPCheckpointManager, BaseCheckpointManager) and set(BaseCheckpointManager.__abstractmethods__) == {"load_checkpoint", "save_checkpoint"}
+    assert [r.name for r in Role] == ["Actor", "Rollout", "ActorRollout", "Critic", "RefPolicy", "RewardModel", "ActorRolloutRef"] and int(Role.ActorRolloutRef) == 7
+    with pytest.raises(TypeError):
+        FSDPCheckpointManager(torch.nn.Linear(2, 2))
+    assert r1v_scene_compute_score("x", "y")["overall"] == 0.0
+    st = BaseCheckpointManager.get_rng_state()
+    a = torch.rand(3)
+    BaseCheckpointManager.load_rng_state(st)
+    assert torch.equal(torch.rand(3), a)

@@ -16,7 +16,7 @@ import uuid
 from collections import defaultdict
 from contextlib import contextmanager
 from copy import deepcopy
-from enum import Enum
+from enum import Enum, IntEnum
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -31,6 +31,18 @@ from ..utils.seqlen_balancing import get_seqlen_balanced_partitions, log_seqlen_
 from . import core_algos
 from .metrics import compute_data_metrics, compute_throughout_metrics, compute_timing_metrics, reduce_metrics
 
+
+
+class Role(IntEnum):
+    """Worker roles of the reference's role -> worker-class mapping (ray_trainer.py:53-64; its values are `auto()` in this order).  This
+    build's FSDPWorker takes the role as a string ("actor_rollout_ref", "critic", ...); the enum is kept for launchers that name roles by it."""
+    Actor = 1
+    Rollout = 2
+    ActorRollout = 3
+    Critic = 4
+    RefPolicy = 5
+    RewardModel = 6
+    ActorRolloutRef = 7
 
 
 class AdvantageEstimator(str, Enum):

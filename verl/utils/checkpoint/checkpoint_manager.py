@@ -4,12 +4,55 @@ FSDPWorker.save_checkpoint / load_checkpoint; RayPPOTrainer uses these helpers f
 from __future__ import annotations
 
 import os
+import random
 import shutil
-from typing import Optional
+from abc import ABC, abstractmethod
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
 
 CHECKPOINT_TRACKER = "latest_global_step.txt"
 
-__all__ = ["CHECKPOINT_TRACKER", "find_latest_ckpt_path", "get_checkpoint_tracker_filename", "remove_obsolete_ckpt"]
+__all__ = ["BaseCheckpointManager", "CHECKPOINT_TRACKER", "find_latest_ckpt_path", "get_checkpoint_tracker_filename", "remove_obsolete_ckpt"]
+
+
+class BaseCheckpointManager(ABC):
+    """save / load of one role's training state under <step dir>/<role>/ (reference: checkpoint_manager.py:34-107).  `model` is what the
+    concrete manager knows how to serialise (the reference: an FSDP module; here: an engine with a ParamStore)."""
+
+    def __init__(self, model, optimizer=None, lr_scheduler=None, processing_class=None):
+        self.model, self.optimizer, self.lr_scheduler, self.processing_class = model, optimizer, lr_scheduler, processing_class
+        dist = torch.distributed
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    @abstractmethod
+    def load_checkpoint(self, *args, **kwargs): ...
+
+    @abstractmethod
+    def save_checkpoint(self, *args, **kwargs): ...
+
+    @staticmethod
+    def local_mkdir(path: str) -> str:
+        path = path if os.path.isabs(path) else os.path.join(os.getcwd(), path)
+        os.makedirs(path, exist_ok=True)                     # concurrent ranks: exist_ok instead of the reference's file lock
+        return path
+
+    @staticmethod
+    def get_rng_state() -> Dict[str, Any]:
+        state = {"cpu": torch.get_rng_state(), "numpy": np.random.get_state(), "random": random.getstate()}
+        if torch.cuda.is_available():
+            state["cuda"] = torch.cuda.get_rng_state()
+        return state
+
+    @staticmethod
+    def load_rng_state(rng_state: Dict[str, Any]) -> None:
+        torch.set_rng_state(rng_state["cpu"])
+        if "cuda" in rng_state and torch.cuda.is_available():
+            torch.cuda.set_rng_state(rng_state["cuda"])
+        np.random.set_state(rng_state["numpy"])
+        random.setstate(rng_state["random"])
 
 
 def get_checkpoint_tracker_filename(root_path: str) -> str:

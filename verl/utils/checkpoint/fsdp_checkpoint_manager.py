@@ -38,6 +38,8 @@ from typing import Any, Dict, Optional, Tuple
 
 import torch
 
+from .checkpoint_manager import BaseCheckpointManager
+
 _PAT = re.compile(r"model_world_size_(\d+)_rank_0\.pt$")
 
 
@@ -275,3 +277,70 @@ def export_reference_layout(hf_state: Dict[str, torch.Tensor], optim_state: Opti
             torch.save({"lr_scheduler": sched}, os.path.join(out_dir, f"extra_state_world_size_{W}_rank_{r}.pt"))
         finally:
             dist.destroy_process_group()
+
+
+class FSDPCheckpointManager(BaseCheckpointManager):
+    """The reference's class name (fsdp_checkpoint_manager.py:34-131: `FSDPCheckpointManager(model, optimizer, lr_scheduler,
+    processing_class)`, `.save_checkpoint(path)`, `.load_checkpoint(path)`) over this build's engine: `model` is a PolicyEngine / CriticEngine
+    (weights, AdamW moments, Kahan buffers and step counters live in its ParamStore; `optimizer` / `lr_scheduler` are unused),
+    `processing_class` the tokenizer or processor whose files go next to the weights.
+
+    save: replicas are identical, so rank 0 writes ONE HF-loadable directory `path/huggingface` (weights + config + generation config +
+    tokenizer / processor files, what :96-131 puts there) and ONE `optim_world_size_1_rank_0.pt` (moments, counters, `extra`); the
+    reference writes a shard per rank (:83-95).  load: that layout, or — recognised by its file names — a checkpoint written by the
+    REFERENCE (per-rank DTensor shards; load_reference_checkpoint above).  Returns the `extra` dict that was saved (the worker keeps its
+    rollout seed position there)."""
+
+    def __init__(self, model, optimizer=None, lr_scheduler=None, processing_class=None, tokenizer=None):
+        super().__init__(model, optimizer, lr_scheduler, processing_class)
+        if not (hasattr(model, "store") and hasattr(model, "opt_steps")):
+            raise TypeError("model must be a spatialthinker_amd.actor.PolicyEngine / CriticEngine (FSDPWorker.actor); this build has no FSDP nn.Module")
+        self.tokenizer = tokenizer
+        self.last_load_info: Optional[Dict[str, Any]] = None
+
+    def save_checkpoint(self, path: str, extra: Optional[Dict[str, Any]] = None) -> None:
+        from spatialthinker_amd.pretrained import save_hf
+        if self.rank == 0:
+            eng, st = self.model, self.model.store
+            tok, proc = self.tokenizer, self.processing_class
+            if tok is None and proc is not None and not hasattr(proc, "image_processor"):
+                tok, proc = proc, None                      # the reference passes ONE processing_class: a bare tokenizer for text-only models
+            save_hf(st, os.path.join(path, "huggingface"), tokenizer=tok, processor=proc)
+            opt = {"m": st.m.cpu(), "v": st.v.cpu(), "opt_steps": eng.opt_steps, "sched_steps": eng.sched_steps, "strategy": eng.h.optim_strategy}
+            opt.update(extra or {})
+            if st.c is not None and eng.h.optim_strategy == "adamw_bf16":
+                opt["c"] = st.c.cpu()
+            if st.master is not None:
+                opt["master"] = st.master.cpu()
+            torch.save(opt, os.path.join(path, "optim_world_size_1_rank_0.pt"))
+        if self.world_size > 1:
+            torch.distributed.barrier()
+
+    def load_checkpoint(self, path: Optional[str] = None) -> Dict[str, Any]:
+        if path is None:
+            return {}
+        eng, st = self.model, self.model.store
+        if find_reference_world_size(path):
+            # every rank reassembles the full weights / optimizer state from all W shard files (whatever this run's world size is)
+            self.last_load_info = load_reference_checkpoint(st, path, engine=eng)
+            if self.world_size > 1:
+                torch.distributed.barrier()
+            return {}
+        import glob
+        from safetensors.torch import load_file
+        sd = {}
+        for shard in sorted(glob.glob(os.path.join(path, "huggingface", "*.safetensors"))):
+            sd.update(load_file(shard))
+        st.load_hf_state_dict(sd)
+        st.version = getattr(st, "version", 0) + 1
+        opt = torch.load(os.path.join(path, "optim_world_size_1_rank_0.pt"), map_location="cpu")
+        st.m.copy_(opt["m"]); st.v.copy_(opt["v"])
+        if "c" in opt and st.c is not None:
+            st.c.copy_(opt["c"])
+        if st.master is not None:
+            st.master.copy_(opt["master"]) if "master" in opt else st.master.copy_(st.flat)
+        eng.opt_steps, eng.sched_steps = opt["opt_steps"], opt["sched_steps"]
+        self.last_load_info = None
+        if self.world_size > 1:
+            torch.distributed.barrier()
+        return {k: v for k, v in opt.items() if k not in ("m", "v", "c", "master", "opt_steps", "sched_steps", "strategy")}

@@ -289,54 +289,27 @@ class FSDPWorker(Worker):
         return DataProto(non_tensor_batch={k: np.array([v] if np.isscalar(v) else v) for k, v in metrics.items()})
 
     # ------------------------------------------------------------------------------------------------
+    def _checkpoint_manager(self):
+        from ..utils.checkpoint.fsdp_checkpoint_manager import FSDPCheckpointManager
+        return FSDPCheckpointManager(model=self.actor, processing_class=getattr(self, "processor", None), tokenizer=getattr(self, "tokenizer", None))
+
     @register(dispatch_mode=Dispatch.ONE_TO_ALL)
     def save_checkpoint(self, path: str):
-        """Replicas are identical, so rank 0 writes ONE HF-loadable directory (weights + config + generation config + tokenizer /
-        processor files, as fsdp_checkpoint_manager.py:96-131 puts under actor/huggingface) and ONE optimizer / scheduler / RNG-
-        position file (the reference writes a shard per rank: model_world_size_W_rank_r.pt etc., :52-95)."""
+        """FSDPCheckpointManager.save_checkpoint (verl/utils/checkpoint/fsdp_checkpoint_manager.py): ONE HF-loadable directory + ONE optimizer /
+        scheduler-position file written by rank 0 (replicas are identical; the reference writes a shard per rank, :83-131); the rollout's
+        seed position travels as `gen_calls`."""
         assert self._is_actor or self._is_critic
-        if self.rank == 0:
-            st = self.actor.store
-            save_hf(st, os.path.join(path, "huggingface"), tokenizer=getattr(self, "tokenizer", None), processor=getattr(self, "processor", None))
-            opt = {"m": st.m.cpu(), "v": st.v.cpu(), "opt_steps": self.actor.opt_steps, "sched_steps": self.actor.sched_steps,
-                   "gen_calls": getattr(self, "_gen_calls", 0), "strategy": self.actor.h.optim_strategy}
-            if st.c is not None and self.actor.h.optim_strategy == "adamw_bf16":
-                opt["c"] = st.c.cpu()
-            if st.master is not None:
-                opt["master"] = st.master.cpu()
-            torch.save(opt, os.path.join(path, "optim_world_size_1_rank_0.pt"))
-        if self.world_size > 1:
-            dist.barrier()
+        self._checkpoint_manager().save_checkpoint(path, extra={"gen_calls": getattr(self, "_gen_calls", 0)})
 
     @register(dispatch_mode=Dispatch.ONE_TO_ALL)
     def load_checkpoint(self, path: str):
         if path is None:
             return
-        from ..utils.checkpoint import find_reference_world_size, load_reference_checkpoint
-        if find_reference_world_size(path):
-            # a run checkpointed by the REFERENCE (model_/optim_/extra_state_world_size_W_rank_r.pt, fsdp_checkpoint_manager.py:83-131):
-            # every rank reassembles the full weights / optimizer state from all W shard files (whatever this run's world size is)
-            info = load_reference_checkpoint(self.actor.store, path, engine=self.actor)
+        mgr = self._checkpoint_manager()
+        extra = mgr.load_checkpoint(path)
+        if mgr.last_load_info is not None:                    # a run checkpointed by the REFERENCE (model_/optim_/extra_state_world_size_W_rank_r.pt)
+            info = mgr.last_load_info
             self.print_rank0(f"Loaded a reference-layout checkpoint written by {info['world_size']} ranks: optimizer state {info['optimizer']}, "
                              f"optimizer step {info['opt_steps']}, scheduler step {info['sched_steps']}.")
-            if self.world_size > 1:
-                dist.barrier()
             return
-        from safetensors.torch import load_file
-        import glob
-        sd = {}
-        for shard in sorted(glob.glob(os.path.join(path, "huggingface", "*.safetensors"))):
-            sd.update(load_file(shard))
-        st = self.actor.store
-        st.load_hf_state_dict(sd)
-        st.version = getattr(st, "version", 0) + 1
-        opt = torch.load(os.path.join(path, "optim_world_size_1_rank_0.pt"), map_location="cpu")
-        st.m.copy_(opt["m"]); st.v.copy_(opt["v"])
-        if "c" in opt and st.c is not None:
-            st.c.copy_(opt["c"])
-        if st.master is not None:
-            st.master.copy_(opt["master"]) if "master" in opt else st.master.copy_(st.flat)
-        self.actor.opt_steps, self.actor.sched_steps = opt["opt_steps"], opt["sched_steps"]
-        self._gen_calls = opt.get("gen_calls", 0)                     # the rollout seed stream continues where it stopped
-        if self.world_size > 1:
-            dist.barrier()
+        self._gen_calls = extra.get("gen_calls", 0)                   # the rollout seed stream continues where it stopped

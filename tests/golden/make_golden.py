@@ -513,8 +513,8 @@ def gen_rewards_math():
     """The reference's `math` plug-in (verl/utils/reward_score/math.py:21-40) with mathruler's two functions stubbed by THIS build's
     documented fallbacks (last brace-matched \\boxed{}, normalised string equality): pins the clean-up regex, the format regex and the
     0.9 / 0.1 weighting; mathruler's own grading stays unpinned (not installed)."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    from verl.utils.reward_score import math as build_math
+    # this build's module by file path: `verl` on sys.path is the REFERENCE's package in this script
+    build_math = _load(os.path.join(os.path.dirname(os.path.dirname(HERE)), "verl/utils/reward_score/math.py"), "build_math")
     _stub_similarity_modules()
     sys.modules["mathruler.grader"].extract_boxed_content = build_math._boxed
     sys.modules["mathruler.grader"].grade_answer = build_math._grade
@@ -533,6 +533,26 @@ def gen_rewards_math():
         json.dump({"stubs": "mathruler.grader.extract_boxed_content / grade_answer = verl.utils.reward_score.math._boxed / _grade (mathruler absent: UNPINNED)",
                    "cases": rows}, f, indent=1)
     print("rewards_math:", len(rows), "cases;", sum(r["score"]["accuracy"] for r in rows), "accurate,", sum(r["score"]["format"] for r in rows), "well-formed")
+
+
+def gen_small_helpers():
+    """Small helpers of verl/utils/torch_functional.py (masked_var :74-88, masked_whiten :91-94, pad_sequence_to_length :137-147) and
+    core_algos.compute_rewards (:281-288), from the reference's own functions."""
+    from verl.trainer import core_algos
+    from verl.utils import torch_functional as VF
+    g = torch.Generator().manual_seed(11)
+    v = torch.randn(5, 9, generator=g)
+    m = (torch.rand(5, 9, generator=g) > 0.35).float()
+    one = torch.zeros(5, 9); one[2, 3] = 1.0
+    out = {"v": v, "m": m, "one": one,
+           "var_unbiased": VF.masked_var(v, m), "var_biased": VF.masked_var(v, m, unbiased=False), "var_one": VF.masked_var(v, one),
+           "whiten": VF.masked_whiten(v, m), "whiten_eps": VF.masked_whiten(v, m, eps=1e-3)}
+    ids = torch.randint(0, 50, (3, 4, 6), generator=g)
+    out.update(ids=ids, pad_right=VF.pad_sequence_to_length(ids, 9, 77), pad_left=VF.pad_sequence_to_length(ids, 9, 77, left_pad=True),
+               pad_noop=VF.pad_sequence_to_length(ids, 6, 77), pad_shorter=VF.pad_sequence_to_length(ids, 4, 77))
+    sc, lp, rp = torch.randn(4, 7, generator=g), torch.randn(4, 7, generator=g), torch.randn(4, 7, generator=g)
+    out.update(sc=sc, lp=lp, rp=rp, rewards=core_algos.compute_rewards(sc, lp, rp, 0.037))
+    save("small_helpers", **{k: t.numpy() for k, t in out.items()})
 
 
 def gen_generate():
@@ -889,7 +909,7 @@ def gen_update_loop():
     save("update_loop", **out)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "math", "model", "extra", "dataset", "generate", "loop", "values"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "math", "small", "model", "extra", "dataset", "generate", "loop", "values"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -902,6 +922,8 @@ if __name__ == "__main__":
         gen_rewards_graded()
     if "math" in which:
         gen_rewards_math()
+    if "small" in which:
+        gen_small_helpers()
     if "model" in which:
         gen_model()
     if "extra" in which:

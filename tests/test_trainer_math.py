@@ -120,3 +120,23 @@ def test_flops_counter_matches_reference_formula():
         est, promised = FlopsCounter(cfg).estimate_flops(seqlens, dt)
         np.testing.assert_allclose(est, want, rtol=1e-12)
         assert promised == 2500.0
+
+
+def test_small_helpers_equal_the_reference_functions():
+    """small_helpers.npz = the reference's VF.masked_var / masked_whiten / pad_sequence_to_length and core_algos.compute_rewards on seeded
+    inputs (tests/golden/make_golden.py small): bit for bit (same torch ops in the same order)."""
+    import os
+    import numpy as np
+    import torch
+    from verl.trainer import core_algos as C
+    from verl.utils import torch_functional as VF
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_helpers.npz"))
+    t = {k: torch.from_numpy(z[k]) for k in z.files}
+    eq = lambda got, key: torch.equal(got, t[key])
+    assert eq(VF.masked_var(t["v"], t["m"]), "var_unbiased") and eq(VF.masked_var(t["v"], t["m"], unbiased=False), "var_biased")
+    assert eq(VF.masked_var(t["v"], t["one"]), "var_one")                                   # one selected entry: no Bessel correction (and a warning)
+    assert eq(VF.masked_whiten(t["v"], t["m"]), "whiten") and eq(VF.masked_whiten(t["v"], t["m"], eps=1e-3), "whiten_eps")
+    assert eq(VF.pad_sequence_to_length(t["ids"], 9, 77), "pad_right") and eq(VF.pad_sequence_to_length(t["ids"], 9, 77, left_pad=True), "pad_left")
+    assert eq(VF.pad_sequence_to_length(t["ids"], 6, 77), "pad_noop") and eq(VF.pad_sequence_to_length(t["ids"], 4, 77), "pad_shorter")
+    assert eq(C.compute_rewards(t["sc"], t["lp"], t["rp"], 0.037), "rewards")
+    assert issubclass(C.FixedKLController, C.KLController) and issubclass(C.AdaptiveKLController, C.KLController)

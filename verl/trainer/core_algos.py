@@ -11,6 +11,7 @@ CPU: plain torch here, pinned by tests/golden/rl_extra.npz.  Batch-wide statisti
 driver does."""
 from __future__ import annotations
 
+from abc import ABC, abstractmethod
 from typing import Tuple
 
 import numpy as np
@@ -19,7 +20,15 @@ import torch
 from spatialthinker_amd import ops
 
 
-class FixedKLController:
+class KLController(ABC):
+    """kl_coef + update(current_kl, n_steps) (core_algos.py:36-43)."""
+    kl_coef: float
+
+    @abstractmethod
+    def update(self, current_kl: float, n_steps: int) -> None: ...
+
+
+class FixedKLController(KLController):
     def __init__(self, init_kl_coef: float):
         self.kl_coef = init_kl_coef
 
@@ -27,7 +36,7 @@ class FixedKLController:
         pass
 
 
-class AdaptiveKLController:
+class AdaptiveKLController(KLController):
     """https://arxiv.org/pdf/1909.08593.pdf — kl_coef *= 1 + clip(kl/target - 1, -0.2, 0.2) * n_steps / horizon."""
 
     def __init__(self, init_kl_coef: float, target_kl: float, horizon: float):
@@ -177,6 +186,11 @@ def compute_value_loss(vpreds, returns, values, action_mask, cliprange_value: fl
     clipped = torch.clamp(vpreds, values - cliprange_value, values + cliprange_value)
     l1, l2 = (vpreds - returns) ** 2, (clipped - returns) ** 2
     return 0.5 * masked_mean(torch.max(l1, l2), action_mask), masked_mean((l1 < l2).float(), action_mask)
+
+
+def compute_rewards(token_level_scores: torch.Tensor, log_probs: torch.Tensor, ref_log_probs: torch.Tensor, kl_ratio: float) -> torch.Tensor:
+    """token-level scores minus kl_ratio x (log_probs - ref_log_probs) (core_algos.py:281-288)."""
+    return token_level_scores - (log_probs - ref_log_probs) * kl_ratio
 
 
 def compute_kl(log_probs: torch.Tensor, ref_log_probs: torch.Tensor, kl_penalty: str) -> torch.Tensor:

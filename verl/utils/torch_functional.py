@@ -20,6 +20,33 @@ def masked_mean(values: torch.Tensor, mask: torch.Tensor, dim=None, eps: float =
     return (values * mask).sum(dim=dim) / (mask.sum(dim=dim) + eps)
 
 
+def masked_var(values: torch.Tensor, mask: torch.Tensor, unbiased: bool = True) -> torch.Tensor:
+    """Variance over the masked entries, Bessel-corrected when `unbiased` and more than one entry is selected (torch_functional.py:74-88)."""
+    mean = masked_mean(values, mask)
+    var = masked_mean((values - mean) ** 2, mask)
+    if unbiased:
+        n = mask.sum()
+        if n <= 1:
+            print("The sum of the mask is less than one, which can cause a division by zero.")
+            return var
+        var = var * (n / (n - 1))
+    return var
+
+
+def masked_whiten(values: torch.Tensor, mask: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """(values - masked mean) * rsqrt(masked unbiased variance + eps) (torch_functional.py:91-94)."""
+    return (values - masked_mean(values, mask)) * torch.rsqrt(masked_var(values, mask) + eps)
+
+
+def pad_sequence_to_length(tensor: torch.Tensor, max_seq_len: int, pad_token_id: int, left_pad: bool = False) -> torch.Tensor:
+    """Pad the LAST dim of an n-D tensor to max_seq_len with pad_token_id; longer tensors come back unchanged (torch_functional.py:137-147)."""
+    short = max_seq_len - tensor.size(-1)
+    if short <= 0:
+        return tensor
+    pad = torch.full((*tensor.shape[:-1], short), pad_token_id, dtype=tensor.dtype, device=tensor.device)
+    return torch.cat((pad, tensor) if left_pad else (tensor, pad), dim=-1)
+
+
 def get_response_mask(response_ids: torch.Tensor, eos_token_id: Union[int, List[int]] = 2, dtype: torch.dtype = torch.long) -> torch.Tensor:
     """:97-119 — 1 up to and INCLUDING the first EOS (any id of the list), 0 after it.
     e.g. eos = 1: ids [0, 0, 2, 4, 1, 5, 1] -> mask [1, 1, 1, 1, 1, 0, 0]."""
@@ -87,6 +114,12 @@ def log_probs_from_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.T
     z = logits.to(dev, torch.bfloat16).contiguous().view(-1, vocab)
     lab = labels.to(dev, torch.int64).contiguous().view(-1)
     return _LogProbsFromLogits.apply(z, lab).view(*batch_dim).to(logits.device)
+
+
+def log_probs_from_logits_flash_attn(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """The reference's name for the fused path (flash-attn's cross_entropy_loss, torch_functional.py:35-42); here both names reach the same
+    HIP kernel."""
+    return log_probs_from_logits(logits, labels)
 
 
 def get_constant_schedule_with_warmup(optimizer: torch.optim.Optimizer, num_warmup_steps: int, last_epoch: int = -1):

@@ -555,6 +555,42 @@ def gen_small_helpers():
     save("small_helpers", **{k: t.numpy() for k, t in out.items()})
 
 
+def gen_balance_micro():
+    """seqlen_balancing.{greedy_partition :130-147, rearrange_micro_batches :220-258, get_reverse_idx :261-267, ceildiv} from the reference
+    (tensordict import stubbed; rearrange_micro_batches is fed a stand-in batch whose row slices are 1 x 1 tensors holding the row number, so
+    the concatenated "micro-batches" spell out which rows went where)."""
+    sys.modules.setdefault("tensordict", types.SimpleNamespace(TensorDict=object))
+    from verl.utils import seqlen_balancing as SB
+
+    class _Rows:
+        def __init__(self, mask):
+            self.mask = mask
+
+        def __getitem__(self, item):
+            if isinstance(item, str):
+                assert item == "attention_mask"
+                return self.mask
+            return torch.arange(self.mask.shape[0])[item].view(-1, 1)
+
+    rs = np.random.RandomState(21)
+    cases = []
+    for n, width, budget in ((8, 64, 128), (16, 96, 200), (12, 50, 50), (5, 40, 400), (20, 128, 777)):
+        lens = rs.randint(1, width + 1, size=n)
+        mask = (torch.arange(width)[None, :] < torch.from_numpy(lens)[:, None]).long()
+        micro, idx = SB.rearrange_micro_batches(_Rows(mask), max_token_len=budget)
+        assert [m.flatten().tolist() for m in micro] == [list(p) for p in idx]
+        cases.append({"lens": lens.tolist(), "width": width, "max_token_len": budget, "idx": [list(map(int, p)) for p in idx]})
+    greedy = []
+    for n, k, eq in ((8, 2, True), (9, 3, False), (16, 4, True), (7, 3, False)):
+        lens = rs.randint(10, 500, size=n).tolist()
+        greedy.append({"lens": lens, "k": k, "equal_size": eq, "parts": SB.greedy_partition(lens, k, eq)})
+    perm = rs.permutation(11).tolist()
+    with open(os.path.join(HERE, "balance_micro.json"), "w") as f:
+        json.dump({"micro": cases, "greedy": greedy, "perm": perm, "reverse": SB.get_reverse_idx(perm),
+                   "ceildiv": [[a, b, SB.ceildiv(a, b)] for a, b in ((7, 2), (8, 2), (0, 5), (1, 5), (1000, 333))]}, f)
+    print("balance_micro:", [len(c["idx"]) for c in cases], "micro-batches")
+
+
 def gen_generate():
     """Greedy continuation by HF itself (`model.generate(do_sample=False)`, its own KV cache and rope-index bookkeeping) for the two
     tiny image+text prompts: pins the oracle's KV-cache decode (oracle.qwen25vl.generate_greedy) and, through it, the GPU rollout."""
@@ -909,7 +945,7 @@ def gen_update_loop():
     save("update_loop", **out)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "math", "small", "model", "extra", "dataset", "generate", "loop", "values"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "math", "small", "micro", "model", "extra", "dataset", "generate", "loop", "values"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -924,6 +960,8 @@ if __name__ == "__main__":
         gen_rewards_math()
     if "small" in which:
         gen_small_helpers()
+    if "micro" in which:
+        gen_balance_micro()
     if "model" in which:
         gen_model()
     if "extra" in which:

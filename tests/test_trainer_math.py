@@ -140,3 +140,26 @@ def test_small_helpers_equal_the_reference_functions():
     assert eq(VF.pad_sequence_to_length(t["ids"], 6, 77), "pad_noop") and eq(VF.pad_sequence_to_length(t["ids"], 4, 77), "pad_shorter")
     assert eq(C.compute_rewards(t["sc"], t["lp"], t["rp"], 0.037), "rewards")
     assert issubclass(C.FixedKLController, C.KLController) and issubclass(C.AdaptiveKLController, C.KLController)
+
+
+def test_micro_batch_rearrangement_and_greedy_partition_equal_the_reference():
+    """balance_micro.json = the reference's rearrange_micro_batches / greedy_partition / get_reverse_idx / ceildiv (make_golden.py micro)."""
+    import json
+    import os
+    import torch
+    from verl.protocol import TensorBatch
+    from verl.utils.seqlen_balancing import ceildiv, get_reverse_idx, greedy_partition, rearrange_micro_batches
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "balance_micro.json")))
+    for c in g["micro"]:
+        lens = torch.tensor(c["lens"])
+        mask = (torch.arange(c["width"])[None, :] < lens[:, None]).long()
+        batch = TensorBatch({"attention_mask": mask, "row": torch.arange(len(lens))})
+        micro, idx = rearrange_micro_batches(batch, c["max_token_len"])
+        assert [list(p) for p in idx] == c["idx"]
+        for m, p in zip(micro, idx):
+            assert isinstance(m, TensorBatch) and m["row"].tolist() == list(p)      # (the balanced split does not promise tokens <= max_token_len per micro-batch)
+        as_dict, _ = rearrange_micro_batches({"attention_mask": mask, "row": torch.arange(len(lens))}, c["max_token_len"])
+        assert [m["row"].tolist() for m in as_dict] == c["idx"]
+    for c in g["greedy"]:
+        assert greedy_partition(c["lens"], c["k"], c["equal_size"]) == c["parts"]
+    assert get_reverse_idx(g["perm"]) == g["reverse"] and all(ceildiv(a, b) == r for a, b, r in g["ceildiv"])

@@ -105,6 +105,10 @@ def _worker(rank, world, port, out_dir):
         back = mgr.postprocess_data(full)
         res["back_a"], res["back_s"] = back.batch["a"].clone(), list(back.non_tensor_batch["s"])
     assert U.get_ulysses_sequence_parallel_group() is None
+    from verl.protocol import TensorBatch, allgather_dict_tensors
+    ag = allgather_dict_tensors({"b": torch.full((2, 2), float(rank)), "a": torch.arange(2) + 10 * rank}, size=world, group=sp_group)
+    agb = allgather_dict_tensors(TensorBatch({"a": torch.arange(2) + 10 * rank}), size=world, group=sp_group)
+    res["ag_a"], res["ag_b"], res["agb"] = ag["a"], ag["b"], (len(agb), agb["a"].clone())
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier(); dist.destroy_process_group()
 
@@ -136,6 +140,7 @@ def test_ulysses_layer_equals_the_single_process_layer_forward_and_backward(tmp_
         assert torch.equal(r[k]["a2a"], want)
         assert r[k]["full_a"].flatten().tolist() == [0, 1, 2, 100, 101, 102] and r[k]["full_s"] == [f"r{j}_{i}" for j in range(world) for i in range(3)]
         assert r[k]["back_a"].flatten().tolist() == [100 * k + i for i in range(3)] and r[k]["back_s"] == [f"r{k}_{i}" for i in range(3)]
+        assert r[k]["ag_a"].tolist() == [0, 1, 10, 11] and r[k]["ag_b"].shape == (4, 2) and r[k]["agb"][0] == 4 and r[k]["agb"][1].tolist() == [0, 1, 10, 11]
 
 
 def _golden_worker(rank, world, port, out_dir):

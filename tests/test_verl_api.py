@@ -234,3 +234,37 @@ def test_checkpoint_manager_classes_and_remaining_reference_names():
     a = torch.rand(3)
     BaseCheckpointManager.load_rng_state(st)
     assert torch.equal(torch.rand(3), a)
+
+
+def test_dataproto_iterator_collate_fold_and_print(capsys):
+    """DataProto.make_iterator / print_size and protocol.{collate_fn, batch_collate, fold_batch_dim, union_tensor_dict, union_numpy_dict}
+    (reference verl/protocol.py:84-155,224-238,447-486)."""
+    from verl.protocol import DataProtoItem, batch_collate, collate_fn, fold_batch_dim, union_numpy_dict, union_tensor_dict
+    n = 12
+    d = DataProto.from_dict({"x": torch.arange(n * 3).view(n, 3), "y": torch.arange(n).float()},
+                            non_tensors={"s": np.array([f"r{i}" for i in range(n)], dtype=object), "l": np.array([[i, i] for i in range(n)], dtype=object)},
+                            meta_info={"temperature": 0.7})
+    # mini-batches in order, twice
+    seen = list(d.make_iterator(mini_batch_size=4, epochs=2))
+    assert len(seen) == 6 and all(len(b) == 4 and b.meta_info == {"temperature": 0.7} for b in seen)
+    assert torch.equal(torch.cat([b.batch["y"] for b in seen[:3]]), d.batch["y"]) and list(seen[4].non_tensor_batch["s"]) == ["r4", "r5", "r6", "r7"]
+    assert seen[0].non_tensor_batch["l"].dtype == object and seen[0].non_tensor_batch["l"].shape[0] == 4
+    # shuffled: a permutation, reproducible from the seed, different between seeds
+    perm = lambda seed: torch.cat([b.batch["y"] for b in d.make_iterator(4, 1, seed=seed, dataloader_kwargs={"shuffle": True})])
+    a, b, c = perm(3), perm(3), perm(4)
+    assert torch.equal(a, b) and not torch.equal(a, c) and sorted(a.tolist()) == list(range(n)) and not torch.equal(a, d.batch["y"])
+    with pytest.raises(AssertionError):
+        d.make_iterator(5, 1)
+    # collate of items = the rows again
+    back = collate_fn([d[i] for i in (2, 5)])
+    assert isinstance(d[2], DataProtoItem) and torch.equal(back.batch["x"], d.batch["x"][[2, 5]]) and list(back.non_tensor_batch["s"]) == ["r2", "r5"]
+    assert batch_collate([{"a": 1, "b": 2}, {"a": 3}]) == {"a": [1, 3], "b": [2]} and batch_collate([]) == {}
+    f = fold_batch_dim(d, 3)
+    assert len(f) == 3 and f.batch["x"].shape == (3, 4, 3) and f.non_tensor_batch["s"].shape == (3, 4) and f.non_tensor_batch["s"][1, 0] == "r4"
+    d.print_size(prefix="batch")
+    out = capsys.readouterr().out
+    assert out.startswith("batch Size of tensordict:") and "non_tensor_batch" in out
+    u = union_tensor_dict(tensor_dict1=d.batch.select("x"), tensor_dict2=d.batch.select("y"))
+    assert set(u.keys()) == {"x", "y"}
+    with pytest.raises(ValueError):
+        union_numpy_dict(tensor_dict1={"s": np.array(["a"], dtype=object)}, tensor_dict2={"s": np.array(["b"], dtype=object)})

@@ -92,7 +92,9 @@ class TensorBatch:
         return TensorBatch({k: torch.cat([b[k] for b in batches], dim=0) for k in keys}, batch_size=sum(len(b) for b in batches))
 
 
-def union_tensor_dict(a: TensorBatch, b: TensorBatch) -> TensorBatch:
+def union_tensor_dict(tensor_dict1: TensorBatch, tensor_dict2: TensorBatch) -> TensorBatch:
+    """tensor_dict1 updated with tensor_dict2 (same batch size; a key present in both must hold equal tensors) — protocol.py:84-97."""
+    a, b = tensor_dict1, tensor_dict2
     if a.batch_size != b.batch_size:
         raise ValueError(f"Two tensor dict must have identical batch size. Got {a.batch_size} and {b.batch_size}")
     for key in b.keys():
@@ -100,6 +102,46 @@ def union_tensor_dict(a: TensorBatch, b: TensorBatch) -> TensorBatch:
             raise ValueError(f"Key already exists: {key}.")
         a[key] = b[key]
     return a
+
+
+def union_numpy_dict(tensor_dict1: Dict[str, np.ndarray], tensor_dict2: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """the same for the non-tensor side (protocol.py:100-110)"""
+    return _union_numpy(tensor_dict1, tensor_dict2)
+
+
+def batch_collate(features: List[Dict[str, Any]]) -> Dict[str, List[Any]]:
+    """list of per-sample dicts -> dict of lists (protocol.py:113-122)"""
+    out: Dict[str, List[Any]] = {}
+    for feature in features:
+        for key, value in feature.items():
+            out.setdefault(key, []).append(value)
+    return out
+
+
+def collate_fn(data_items: List["DataProtoItem"]) -> "DataProto":
+    """DataProtoItems (what DataProto[i] returns) -> one DataProto: tensors stacked, the rest as object arrays (protocol.py:145-155)"""
+    keys = list(data_items[0].batch.keys()) if data_items and data_items[0].batch is not None else []
+    batch = TensorBatch({k: torch.stack([d.batch[k] for d in data_items]).contiguous() for k in keys}, batch_size=len(data_items)) if keys else None
+    non = batch_collate([d.non_tensor_batch for d in data_items])
+    return DataProto(batch=batch, non_tensor_batch={k: _object_array(v) for k, v in non.items()})
+
+
+def _object_array(values: List[Any]) -> np.ndarray:
+    out = np.empty(len(values), dtype=object)                # element-wise: np.array(list_of_equal_length_lists, dtype=object) would go 2-D
+    for i, v in enumerate(values):
+        out[i] = v
+    return out
+
+
+def fold_batch_dim(data: "DataProto", new_batch_size: int) -> "DataProto":
+    """[bsz, ...] -> [new_bsz, bsz // new_bsz, ...] for every tensor and array (protocol.py:125-142)"""
+    bsz = len(data)
+    assert bsz % new_batch_size == 0
+    batch = None
+    if data.batch is not None:
+        batch = TensorBatch({k: v.reshape(new_batch_size, -1, *v.shape[1:]) for k, v in data.batch.items()}, batch_size=new_batch_size)
+    non = {k: np.reshape(v, (new_batch_size, -1, *v.shape[1:])) for k, v in data.non_tensor_batch.items()}
+    return DataProto(batch=batch, non_tensor_batch=non, meta_info=data.meta_info)
 
 
 def _union_numpy(a: Dict[str, np.ndarray], b: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
@@ -160,6 +202,34 @@ class DataProto:
                                  non_tensor_batch={k: v[item] for k, v in self.non_tensor_batch.items()}, meta_info=self.meta_info)
         return DataProto(batch=self.batch[item] if self.batch is not None else None,
                          non_tensor_batch={k: v[item] for k, v in self.non_tensor_batch.items()}, meta_info=self.meta_info)
+
+    def print_size(self, prefix: str = "") -> None:
+        """bytes held by the tensors and by the arrays (protocol.py:224-238)"""
+        gb = 1024 ** 3
+        t = sum(v.element_size() * v.numel() for v in self.batch.values()) / gb if self.batch is not None else 0.0
+        n = sum(v.nbytes for v in self.non_tensor_batch.values()) / gb
+        print(f"{prefix} Size of tensordict: {t} GB, size of non_tensor_batch: {n} GB.")
+
+    def make_iterator(self, mini_batch_size: int, epochs: int, seed: Optional[int] = None, dataloader_kwargs: Optional[Dict[str, Any]] = None):
+        """Iterator over mini-batches of this DataProto: `epochs` passes of a torch DataLoader over the rows (so `shuffle`, `drop_last` ...
+        in dataloader_kwargs behave as in the reference, seeded by `seed`); every mini-batch carries this object's meta_info
+        (protocol.py:447-486)."""
+        assert len(self) % mini_batch_size == 0, f"{len(self)} % {mini_batch_size} != 0"
+        from torch.utils.data import DataLoader
+        kwargs = dict(dataloader_kwargs or {})
+        assert isinstance(kwargs, dict)
+        gen = None
+        if seed is not None:
+            gen = torch.Generator()
+            gen.manual_seed(seed)
+        loader = DataLoader(dataset=self, batch_size=mini_batch_size, collate_fn=collate_fn, generator=gen, **kwargs)
+
+        def rows():
+            for _ in range(epochs):
+                for d in loader:
+                    d.meta_info = self.meta_info
+                    yield d
+        return iter(rows())
 
     def check_consistency(self):
         if self.batch is not None:
@@ -294,6 +364,21 @@ def pad_dataproto_to_divisor(data: DataProto, size_divisor: int) -> Tuple[DataPr
 
 def unpad_dataproto(data: DataProto, pad_size: int) -> DataProto:
     return data[:-pad_size] if pad_size else data
+
+
+def allgather_dict_tensors(tensors, size: int, group, dim: int = 0):
+    """every tensor of a dict / TensorBatch all-gathered over `group` and concatenated along `dim`, keys in sorted order
+    (protocol.py:651-678); a TensorBatch comes back as a TensorBatch of size x rows."""
+    import torch.distributed as dist
+    is_batch = isinstance(tensors, TensorBatch)
+    src = tensors.to_dict() if is_batch else tensors
+    out = {}
+    for key in sorted(src.keys()):
+        val = src[key].contiguous()
+        parts = [torch.empty_like(val) for _ in range(size)]
+        dist.all_gather(parts, val, group=group)
+        out[key] = torch.cat(parts, dim=dim)
+    return TensorBatch(out, batch_size=len(tensors) * size) if is_batch else out
 
 
 def all_gather_data_proto(data: DataProto, size: int, group) -> None:

@@ -24,7 +24,9 @@ class Execute(Enum):
     RANK_ZERO = 1
 
 
-def register(dispatch_mode=Dispatch.ALL_TO_ALL, execute_mode=Execute.ALL, blocking=True):
+def register(dispatch_mode=Dispatch.ALL_TO_ALL, execute_mode=Execute.ALL, blocking=True, materialize_futures=True):
+    """(materialize_futures: the reference resolves DataProtoFuture arguments before the call, decorator.py:171-196 — there are no futures in a
+    one-process-per-GPU run; accepted and ignored)"""
     def decorator(func):
         @wraps(func)
         def inner(*args, **kwargs):

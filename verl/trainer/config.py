@@ -154,7 +154,8 @@ def _ppo_post(self):
     self.worker.actor.kl_coef = self.algorithm.kl_coef
 
 
-def recursive_post_init(obj):
+def recursive_post_init(dataclass_obj):
+    obj = dataclass_obj
     if hasattr(obj, "post_init"):
         obj.post_init()
     for f in fields(obj):

@@ -68,3 +68,58 @@ def log_seqlen_unbalance(seqlen_list: List[int], partitions: List[List[int]], pr
     balanced = [sum(seqlen_list[i] for i in p) for p in partitions]
     return {f"{prefix}/min": min(naive), f"{prefix}/max": max(naive), f"{prefix}/minmax_diff": max(naive) - min(naive),
             f"{prefix}/balanced_min": min(balanced), f"{prefix}/balanced_max": max(balanced), f"{prefix}/mean": sum(naive) / k}
+
+
+def ceildiv(a, b):
+    return -(a // -b)
+
+
+def greedy_partition(seqlen_list: List[int], k_partitions: int, equal_size: bool) -> List[List[int]]:
+    """Items in input order, each to the currently lightest partition (first of the lightest); with equal_size every item carries a bias
+    larger than the total so that the counts even out first (seqlen_balancing.py:130-147)."""
+    bias = sum(seqlen_list) + 1 if equal_size else 0
+    parts: List[List[int]] = [[] for _ in range(k_partitions)]
+    sums = [0] * k_partitions
+    for i, n in enumerate(seqlen_list):
+        j = min(range(k_partitions), key=lambda q: sums[q])        # min() keeps the first of equals, as the reference's scan does
+        parts[j].append(i)
+        sums[j] += n + bias
+    if equal_size:
+        for p_ in parts:
+            assert len(p_) * k_partitions == len(seqlen_list), f"{len(p_)} * {k_partitions} != {len(seqlen_list)}"
+    return parts
+
+
+def rearrange_micro_batches(batch, max_token_len: int, dp_group=None):
+    """Split a batch (TensorBatch / dict of tensors with an `attention_mask`) into micro-batches of at most max_token_len valid tokens with
+    balanced token counts: ceil(total / max_token_len) of them (the maximum over the ranks of dp_group, so every rank runs the same
+    number), rows assigned by the Karmarkar-Karp partition.  Returns (micro_batches, row indices of each) — seqlen_balancing.py:220-258.
+    (This build's engines plan their packed passes themselves — spatialthinker_amd.actor; the function is kept for code written against it.)"""
+    import torch
+    import torch.distributed as dist
+    mask = batch["attention_mask"]
+    max_seq_len = mask.shape[-1]
+    assert max_token_len >= max_seq_len, f"max_token_len must be greater than the sequence length. Got {max_token_len=} and {max_seq_len=}"
+    eff = mask.sum(dim=1)
+    n_micro = ceildiv(int(eff.sum().item()), max_token_len)
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor([n_micro], device="cuda" if dist.get_backend(dp_group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=dp_group)
+        n_micro = int(t.item())
+    eff = eff.tolist()
+    assert n_micro <= len(eff)
+    idx = get_seqlen_balanced_partitions(eff, n_micro, equal_size=False)
+    keys = list(batch.keys())
+    micro = []
+    for part in idx:
+        rows = {k: torch.cat([batch[k][i:i + 1] for i in part]) for k in keys}
+        micro.append(type(batch)(rows, batch_size=len(part)) if not isinstance(batch, dict) else rows)
+    return micro, idx
+
+
+def get_reverse_idx(idx_map: List[int]) -> List[int]:
+    """the inverse permutation: out[idx_map[i]] = i (seqlen_balancing.py:261-267)"""
+    out = list(idx_map)
+    for i, j in enumerate(idx_map):
+        out[j] = i
+    return out

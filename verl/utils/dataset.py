@@ -80,7 +80,31 @@ class SyntheticSTVQADataset(Dataset):
         return row
 
 
-class RLHFDataset(Dataset):
+class ImageProcessMixin:
+    """`process_image` for classes that carry max_pixels / min_pixels (reference verl/utils/dataset.py:52-75; a vLLM-side processor mixes it
+    in too)."""
+    max_pixels: Optional[int]
+    min_pixels: Optional[int]
+
+    def process_image(self, image):
+        """bytes/dict -> PIL, down-scale above max_pixels, up-scale below min_pixels, RGB."""
+        from io import BytesIO
+
+        from PIL import Image
+        if isinstance(image, dict):
+            image = Image.open(BytesIO(image["bytes"]))
+        elif isinstance(image, bytes):
+            image = Image.open(BytesIO(image))
+        if self.max_pixels and image.width * image.height > self.max_pixels:
+            f = math.sqrt(self.max_pixels / (image.width * image.height))
+            image = image.resize((int(image.width * f), int(image.height * f)))
+        if self.min_pixels and image.width * image.height < self.min_pixels:
+            f = math.sqrt(self.min_pixels / (image.width * image.height))
+            image = image.resize((int(image.width * f), int(image.height * f)))
+        return image.convert("RGB") if image.mode != "RGB" else image
+
+
+class RLHFDataset(Dataset, ImageProcessMixin):
     """Real-data row pipeline of the reference (verl/utils/dataset.py:79-265), pinned against the reference
     class itself by tests/golden/dataset.npz (tests/test_dataset.py).  data_path = "<dir | parquet file | hub id>[@split]"."""
 
@@ -126,23 +150,6 @@ class RLHFDataset(Dataset):
 
     def __len__(self):
         return len(self.dataset)
-
-    def process_image(self, image):
-        """:56-75 — bytes/dict -> PIL, down-scale above max_pixels, up-scale below min_pixels, RGB."""
-        from io import BytesIO
-
-        from PIL import Image
-        if isinstance(image, dict):
-            image = Image.open(BytesIO(image["bytes"]))
-        elif isinstance(image, bytes):
-            image = Image.open(BytesIO(image))
-        if self.max_pixels and image.width * image.height > self.max_pixels:
-            f = math.sqrt(self.max_pixels / (image.width * image.height))
-            image = image.resize((int(image.width * f), int(image.height * f)))
-        if self.min_pixels and image.width * image.height < self.min_pixels:
-            f = math.sqrt(self.min_pixels / (image.width * image.height))
-            image = image.resize((int(image.width * f), int(image.height * f)))
-        return image.convert("RGB") if image.mode != "RGB" else image
 
     def __getitem__(self, index):
         row = dict(self.dataset[index])

@@ -481,6 +481,51 @@ def gen_rewards_graded():
     print("wrote rewards_graded.json", len(rows), "cases,", differ, "with a different object assignment than under the binary stub")
 
 
+def gen_rewards_helpers():
+    """The other public functions of the reference's spatial_sgg.py (scale_box, refine_node_edge, compute_iou / giou / ciou, box_L1,
+    is_valid_id_format, bi_match_triplets, compute_rel_score, spatial_reward — the strict variant the shipped scorer does not call),
+    under the graded stand-in similarity, on the scenes of the graded reward cases and on seeded boxes."""
+    from label_sim import trigram_jaccard
+    import re as _re
+
+    _stub_similarity_modules()
+    sgg = _load(os.path.join(REF, "verl/utils/reward_score/spatial_sgg.py"), "ref_spatial_sgg_helpers")
+    _SIM_FN[0] = trigram_jaccard
+    sgg._doc.cache_clear(); sgg._bi_match_cached.cache_clear()
+    rs = np.random.RandomState(33)
+    boxes = []
+    for _ in range(24):
+        a = np.sort(rs.rand(2, 2), axis=0).T.reshape(-1)[[0, 2, 1, 3]].tolist()
+        b = np.sort(rs.rand(2, 2), axis=0).T.reshape(-1)[[0, 2, 1, 3]].tolist()
+        boxes.append((a, b))
+    boxes += [([0.1, 0.1, 0.4, 0.4], [0.6, 0.6, 0.9, 0.9]), ([0.2, 0.2, 0.5, 0.5], [0.2, 0.2, 0.5, 0.5]), ([0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]),
+              ([0.1, 0.1, 0.1, 0.4], [0.1, 0.1, 0.1, 0.4]), ([0, 0, 1, 1], [0, 0, 2, 2])]
+    box_rows = [{"a": a, "b": b, "iou": sgg.compute_iou(a, b), "giou": sgg.compute_giou(a, b), "ciou": sgg.compute_ciou(a, b), "l1": sgg.box_L1(a, b),
+                 "scaled": sgg.scale_box(a, (0.5, 2.0))} for a, b in boxes]
+    labels = ["Fire-Hydrant", "trash_can ", " park bench", "dog.3", "Dog", "a-b_c"]
+    ids = ["dog.1", "dog", "fire_hydrant.12", "fire-hydrant.1", "Dog.07", "dog.1a", ".3", "d.3 "]
+    scene_rows = []
+    for name, pred, gt, problem in graded_reward_cases():
+        ps = json.loads(_re.search(r"<scene>(.*?)</scene>", pred, _re.S).group(1))
+        gs = json.loads(_re.search(r"<scene>(.*?)</scene>", gt, _re.S).group(1))
+        w, h = sgg.extract_image_size(problem)
+        o, r = sgg.spatial_reward(ps, gs, w, h)
+        g_rel, p_rel = gs.get("relationships", []), ps.get("relationships", [])
+        scene_rows.append({"name": name, "pred_scene": ps, "gt_scene": gs, "w": w, "h": h, "spatial_reward": [float(o), float(r)],
+                           "rel_score": float(sgg.compute_rel_score(g_rel, p_rel)),
+                           "triplet_similarity": [float(m["similarity"]) for m in sgg.bi_match_triplets(g_rel, p_rel)]})
+    odd = [("not a dict", {"objects": []}), ({"objects": "x"}, {"objects": []}), ({"objects": [{"id": "dog", "bbox": [0, 0, 1, 1]}]}, {"objects": []}),
+           ({"objects": [], "relationships": []}, {"objects": [], "relationships": []}),
+           ({"objects": [{"id": "dog.1", "bbox": [0, 0, 10, 10]}]}, {"objects": [], "relationships": []})]
+    odd_rows = [{"pred_scene": p_, "gt_scene": g_, "spatial_reward": [float(x) for x in sgg.spatial_reward(p_, g_, 100, 50)]} for p_, g_ in odd]
+    _SIM_FN[0] = lambda a, b: 1.0 if a == b else 0.0
+    with open(os.path.join(HERE, "rewards_helpers.json"), "w") as f:
+        json.dump({"similarity": "character-trigram Jaccard (tests/golden/label_sim.py)", "boxes": box_rows,
+                   "labels": [[l, sgg.refine_node_edge(l)] for l in labels], "ids": [[i, sgg.is_valid_id_format(i)] for i in ids],
+                   "scenes": scene_rows, "odd": odd_rows}, f, indent=1)
+    print("wrote rewards_helpers.json:", len(box_rows), "box pairs,", len(scene_rows), "scenes")
+
+
 # ------------------------------------------------------------------ 5. HF tiny model
 def _hf_tiny_model():
     from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
@@ -945,7 +990,7 @@ def gen_update_loop():
     save("update_loop", **out)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "math", "small", "micro", "model", "extra", "dataset", "generate", "loop", "values"]
+    which = sys.argv[1:] or ["rl", "adamw", "pos", "rewards", "graded", "helpers", "math", "small", "micro", "model", "extra", "dataset", "generate", "loop", "values"]
     if "rl" in which:
         gen_rl_math()
     if "adamw" in which:
@@ -956,6 +1001,8 @@ if __name__ == "__main__":
         gen_rewards()
     if "graded" in which:
         gen_rewards_graded()
+    if "helpers" in which:
+        gen_rewards_helpers()
     if "math" in which:
         gen_rewards_math()
     if "small" in which:

@@ -93,3 +93,40 @@ def test_math_plugin_equals_the_reference_module_on_its_stubbed_graders():
     assert len(rows) >= 16
     for r in rows:
         assert math_compute_score(r["predict"], r["ground_truth"]) == r["score"], r
+
+
+def test_public_reward_helpers_equal_the_reference_functions(graded, golden_dir):
+    """rewards_helpers.json = the reference's other public spatial_sgg functions (make_golden.py helpers) under the graded stand-in
+    similarity: box metrics on 29 box pairs, label / id normalisers, and per scene of the 50 graded cases the strict spatial_reward pair,
+    compute_rel_score and the triplet alignment — float64-exact."""
+    sim, _ = graded
+    gold = json.load(open(os.path.join(golden_dir, "rewards_helpers.json")))
+    for r in gold["boxes"]:
+        a, b = r["a"], r["b"]
+        assert S.compute_iou(a, b) == r["iou"] and S.compute_giou(a, b) == r["giou"] and S.compute_ciou(boxA=a, boxB=b) == r["ciou"], r
+        assert S.box_L1(a, b) == r["l1"] and S.scale_box(a, (0.5, 2.0)) == r["scaled"]
+    assert all(S.refine_node_edge(l) == want for l, want in gold["labels"]) and all(S.is_valid_id_format(i) == want for i, want in gold["ids"])
+    try:
+        S.set_similarity(sim)
+        for r in gold["scenes"]:
+            got = S.spatial_reward(r["pred_scene"], r["gt_scene"], r["w"], r["h"])
+            assert [float(x) for x in got] == r["spatial_reward"], (r["name"], got, r["spatial_reward"])
+            g_rel, p_rel = r["gt_scene"].get("relationships", []), r["pred_scene"].get("relationships", [])
+            assert float(S.compute_rel_score(g_rel, p_rel)) == r["rel_score"], r["name"]
+            assert [float(m["similarity"]) for m in S.bi_match_triplets(g_rel, p_rel)] == r["triplet_similarity"], r["name"]
+        for r in gold["odd"]:
+            assert [float(x) for x in S.spatial_reward(r["pred_scene"], r["gt_scene"], 100, 50)] == r["spatial_reward"], r
+    finally:
+        S.set_similarity(None)
+    assert S.is_valid_object(obj={"id": "dog.1", "bbox": [0, 0, 1, 1]}) and not S.is_valid_relation(rel={"subject": "dog", "predicate": "on", "object": "mat.1"})
+
+
+def test_r1v_scene_module_functions(gold):
+    """verl.utils.reward_score.r1v_scene: the module-level helper names of the reference, consistent with the scorer pinned above."""
+    from verl.utils.reward_score import r1v_scene as R
+    for row in gold["cases"]:
+        p, g, want = row["predict"], row["ground_truth"], row["r1v_scene"]
+        assert R.r1v_scene_compute_score(p, g) == want and R.r1v_format_reward(p) == want["format"]
+        if want["format"] == 1.0:
+            assert R.r1v_accuracy_reward(p, g) == want["accuracy"]
+    assert R.extract_answer("x <answer> B </answer>") == "B" and R.extract_answer("none") == "" and R.acc_reward(" a ", "A") == 1.0

@@ -79,8 +79,9 @@ def sem_sim(a: str, b: str) -> float:
 
 
 # ------------------------------------------------------------------ geometry
-def compute_ciou(a: Sequence[float], b: Sequence[float], eps: float = 1e-7) -> float:
+def compute_ciou(boxA: Sequence[float], boxB: Sequence[float], eps: float = 1e-7) -> float:
     """Complete-IoU of two [x1,y1,x2,y2] boxes mapped to [0,1] by (ciou+1)/2."""
+    a, b = boxA, boxB
     wa, ha, wb, hb = a[2] - a[0], a[3] - a[1], b[2] - b[0], b[3] - b[1]
     iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
     ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
@@ -118,7 +119,8 @@ def extract_image_size(problem: str) -> Tuple[int, int]:
     return int(m.group(1)), int(m.group(2))
 
 
-def is_valid_object(o) -> bool:
+def is_valid_object(obj) -> bool:
+    o = obj
     if not isinstance(o, dict) or set(o.keys()) != {"id", "bbox"}:
         return False
     if not isinstance(o["id"], str) or not _ID_RE.fullmatch(o["id"]):
@@ -127,7 +129,8 @@ def is_valid_object(o) -> bool:
     return isinstance(box, list) and len(box) == 4 and all(isinstance(x, (int, float)) for x in box)
 
 
-def is_valid_relation(r) -> bool:
+def is_valid_relation(rel) -> bool:
+    r = rel
     if not isinstance(r, dict) or not {"subject", "predicate", "object"} <= set(r.keys()):
         return False
     if not all(isinstance(r[k], str) for k in ("subject", "predicate", "object")):
@@ -216,6 +219,103 @@ def _triplet_matches(gt_rels: List[dict], pr_rels: List[dict]) -> int:
     cost[P:, :] = DUMMY_COST
     rows, _ = linear_sum_assignment(cost)
     return int(sum(1 for r in rows if r < P))
+
+
+# ---- the reference module's other public helpers (spatial_sgg.py:21-27,41-72,146-149,209-246,248-386,416-420,507-508).  The shipped
+# scorer (spatial_sgg_compute_score -> relaxed_spatial_reward) does not call spatial_reward / compute_rel_score / compute_giou; they are kept
+# under their names for code that imports them, and pinned against the reference's functions (tests/golden/rewards_helpers.json).
+IOU_W, L1_W = 1.0, 5.0
+
+
+def scale_box(box: Sequence[float], scale: Sequence[float]) -> List[float]:
+    sw, sh = scale
+    return [box[0] * sw, box[1] * sh, box[2] * sw, box[3] * sh]
+
+
+def refine_node_edge(label: str) -> str:
+    """'fire-hydrant' == 'fire_hydrant' == 'Fire hydrant '"""
+    return _clean(label)
+
+
+def compute_iou(boxA: Sequence[float], boxB: Sequence[float]) -> float:
+    iw = max(0, min(boxA[2], boxB[2]) - max(boxA[0], boxB[0]))
+    ih = max(0, min(boxA[3], boxB[3]) - max(boxA[1], boxB[1]))
+    inter = iw * ih
+    union = (boxA[2] - boxA[0]) * (boxA[3] - boxA[1]) + (boxB[2] - boxB[0]) * (boxB[3] - boxB[1]) - inter
+    return 0.0 if union == 0 else inter / union
+
+
+def compute_giou(boxA: Sequence[float], boxB: Sequence[float]) -> float:
+    """generalised IoU mapped to [0, 1] by (giou + 1) / 2; the plain IoU when the enclosing box is empty"""
+    iw = max(0, min(boxA[2], boxB[2]) - max(boxA[0], boxB[0]))
+    ih = max(0, min(boxA[3], boxB[3]) - max(boxA[1], boxB[1]))
+    inter = iw * ih
+    union = (boxA[2] - boxA[0]) * (boxA[3] - boxA[1]) + (boxB[2] - boxB[0]) * (boxB[3] - boxB[1]) - inter
+    iou = inter / union if union > 0 else 0.0
+    hull = (max(boxA[2], boxB[2]) - min(boxA[0], boxB[0])) * (max(boxA[3], boxB[3]) - min(boxA[1], boxB[1]))
+    if hull == 0:
+        return iou
+    return ((iou - (hull - union) / hull) + 1.0) / 2.0
+
+
+def box_L1(a: Sequence[float], b: Sequence[float]) -> float:
+    return sum(abs(x - y) for x, y in zip(a, b))
+
+
+def is_valid_id_format(s: str) -> bool:
+    return bool(_ID_RE.fullmatch(s))
+
+
+def bi_match_triplets(gt_rels: List[dict], pred_rels: List[dict]) -> List[dict]:
+    """Hungarian alignment of predicted to ground-truth (subject, predicate, object) triplets on the cost 1 - (0.3 subject + 0.3 object +
+    0.4 predicate similarity); missing predictions are padded with rows of cost 1e5 and dropped from the result."""
+    G, P = len(gt_rels), len(pred_rels)
+    cost = np.zeros((P + max(0, G - P), G))
+    for i, p in enumerate(pred_rels):
+        for j, g in enumerate(gt_rels):
+            cost[i, j] = 1.0 - (0.3 * sem_sim(p["subject"], g["subject"]) + 0.3 * sem_sim(p["object"], g["object"])
+                                + 0.4 * sem_sim(p["predicate"], g["predicate"]))
+    cost[P:, :] = DUMMY_COST
+    rows, cols = linear_sum_assignment(cost)
+    return [{"groundtruth": gt_rels[c], "prediction": pred_rels[r], "cost": cost[r, c], "similarity": 1.0 - cost[r, c]}
+            for r, c in zip(rows, cols) if r < P]
+
+
+def compute_rel_score(gt_rels: List[dict], pr_rels: List[dict]) -> float:
+    return sum(1.0 - m["cost"] for m in bi_match_triplets(gt_rels, pr_rels)) / len(gt_rels) if gt_rels else 1.0
+
+
+def spatial_reward(pred_scene, gt_scene, w: int, h: int) -> Tuple[float, float]:
+    """(object score, relation score) of the strict variant: per matched GT object 0.5 x (IoU + 5 exp(-L1)) / 6 + 0.5 x label similarity,
+    averaged over the GT objects; relation score = mean triplet similarity over the GT relations."""
+    if not isinstance(pred_scene, dict) or not isinstance(gt_scene, dict):
+        return 0.0, 0.0
+    go, po = gt_scene.get("objects") or [], pred_scene.get("objects") or []
+    gr, pr = gt_scene.get("relationships") or [], pred_scene.get("relationships") or []
+    if not all(isinstance(x, list) for x in (go, po, gr, pr)):
+        return 0.0, 0.0
+    if not all(is_valid_object(o) for o in po) or not all(is_valid_relation(r) for r in pr):
+        return 0.0, 0.0
+    norm = lambda objs: [{**o, "id": _clean(o["id"]), "bbox": scale_box(o["bbox"], (1.0 / w, 1.0 / h))} for o in objs]
+    rel = lambda rs: [{**r, "subject": _clean(r["subject"]), "object": _clean(r["object"])} for r in rs]
+    go, po, gt_trip, pr_trip = norm(go), norm(po), rel(gr), rel(pr)
+    if not go:
+        obj_score = 1.0 if not po else 0.0
+    else:
+        box, sim = [], []
+        for j, i in enumerate(bi_match(go, po)):
+            if i is None:
+                box.append(0.0); sim.append(0.0)
+                continue
+            g, p = go[j], po[i]
+            sim.append(sem_sim(g["id"], p["id"]))
+            box.append((IOU_W * compute_iou(g["bbox"], p["bbox"]) + L1_W * math.exp(-box_L1(g["bbox"], p["bbox"]))) / (IOU_W + L1_W))
+        obj_score = 0.5 * (sum(box) / len(go)) + 0.5 * (sum(sim) / len(go))
+    if not gr:
+        rel_score = 1.0 if not pr else 0.0
+    else:
+        rel_score = sum(1.0 - m["cost"] for m in bi_match_triplets(gt_trip, pr_trip)) / len(gt_trip)
+    return obj_score, rel_score
 
 
 def relaxed_spatial_reward(pred_scene, gt_scene, w: int, h: int, threshold: float = 0.0, rel_gating: bool = False) -> float:

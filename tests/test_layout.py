@@ -19,7 +19,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert len(argtypes) == len(argnames)
         if name not in ("st_version", "st_arch", "st_prof_enable", "st_prof_read", "st_prof_disable", "st_prof_set_stride", "st_prof_hint_units", "st_prof_seen",
                             "st_attn_bwd_workspace_bytes", "st_prof_read_events", "st_stream_create_cu_range", "st_stream_destroy",
-                            "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan", "st_gemm_select", "st_decode_attn_select", "st_decode_attn_selected", "st_gemm_mxfp8_select"):
+                            "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan", "st_gemm_select", "st_decode_attn_select", "st_decode_attn_selected", "st_switch_value", "st_gemm_mxfp8_select"):
             assert argnames[-1] == "stream", f"{name}: every compute entry takes the stream last"
 
 
@@ -30,9 +30,10 @@ def test_library_defaults_after_load():
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if not k.startswith("ST_")}
-    code = "from spatialthinker_amd.lib import lib; print(int(lib().st_decode_attn_selected()))"
+    code = "from spatialthinker_amd.lib import lib; L = lib(); print(int(L.st_decode_attn_selected()), *[int(L.st_switch_value(i)) for i in range(4)])"
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, text=True)
-    assert out.strip().splitlines()[-1] == "0", out
+    # decode attention: one workgroup per item; training GEMM: the 4-wave hand-scheduled tile; decode weights: non-temporal stream
+    assert out.strip().splitlines()[-1] == "0 40 1 0 -1", out
 
 
 def test_product_code_never_imports_the_oracle():

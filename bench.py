@@ -32,6 +32,98 @@ PEAK_FP8 = 5.0e15           # dense MFMA fp8 (block-scaled K=128 instructions), 
 PEAK_HBM = 8.0e12
 
 
+class ChipTelemetry:
+    """What the chip was doing while the timed region ran (the GEMM class ran 0.518 of peak on the driver's box and
+    0.553 on the builder's with identical sources, and nothing in the line could say why).  A host thread wakes every `period` seconds and
+      * launches st_clock_probe on a side stream: 8 one-wave workgroups (one per XCD) measure shader cycles per 100-MHz reference tick
+        for 20 us WHILE the compute stream's kernels run — the clock the power management actually grants under this load;
+      * reads the amdgpu sysfs / hwmon files that exist on the box (socket power, junction / memory temperature, sclk): host side only.
+    Every sample carries the phase label the step loop has set (gen / old / ref / update_actor), so the clock under the GEMM-heavy
+    phases is separable from the clock under the decode phase.  No sample is ever waited for inside the timed region."""
+    HWMON = ("power1_average", "power1_input", "temp1_input", "temp2_input", "temp3_input", "freq1_input", "freq2_input")
+
+    def __init__(self, period: float = 0.25, max_samples: int = 8192):
+        import glob
+        import threading
+        from spatialthinker_amd import ops
+        self.ops, self.period, self.max = ops, period, max_samples
+        self.buf = torch.zeros(max_samples, 8, 2, dtype=torch.int64, device="cuda")
+        self.stream = torch.cuda.Stream()
+        self.labels, self.host = [], []
+        self.phase = "idle"
+        self.errors = 0
+        self.files = {}
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for f in self.HWMON:
+                fp = os.path.join(d, f)
+                if os.path.exists(fp) and f not in self.files:
+                    self.files[f] = fp
+            if self.files:
+                break
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="telemetry", daemon=True)
+
+    def start(self):
+        self.ops.clock_probe(self.buf, self.max - 1, self.stream)          # first launch (module load) from the main thread, outside any capture
+        self.stream.synchronize()
+        self._thread.start()
+
+    def _read(self, fp):
+        try:
+            with open(fp) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            k = len(self.labels)
+            if k >= self.max:
+                break
+            try:
+                self.ops.clock_probe(self.buf, k, self.stream)
+            except Exception:
+                self.errors += 1
+                continue
+            self.labels.append(self.phase)
+            self.host.append({f: self._read(fp) for f, fp in self.files.items()})
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=5.0)
+
+    def summary(self, gemm_phases=("old", "ref", "update_actor")):
+        self.stream.synchronize()
+        n = len(self.labels)
+        if n == 0:
+            return None
+        raw = self.buf[:n].cpu().numpy().astype(np.float64)
+        mhz = 100.0 * raw[:, :, 0] / np.maximum(raw[:, :, 1], 1.0)            # (samples, XCDs)
+        ok = raw[:, :, 1].min(axis=1) > 0
+        lab = np.array(self.labels)
+
+        def stats(sel):
+            sel = sel & ok
+            if not sel.any():
+                return None
+            m = mhz[sel]
+            out = {"samples": int(sel.sum()), "clock_mhz_mean": float(m.mean()), "clock_mhz_min": float(m.min(axis=1).min()),
+                   "clock_mhz_p10": float(np.percentile(m.mean(axis=1), 10)), "clock_mhz_max": float(m.max())}
+            for f in self.files:
+                v = np.array([h[f] for h, s_ in zip(self.host, sel) if s_ and h.get(f) is not None], dtype=np.float64)
+                if v.size:
+                    scale = 1e-6 if f.startswith(("power", "freq")) else 1e-3      # uW -> W, Hz -> MHz, millidegrees -> degrees C
+                    key = {"power1_average": "socket_power_w", "power1_input": "socket_power_w", "freq1_input": "sclk_mhz_sysfs",
+                           "freq2_input": "mclk_mhz_sysfs"}.get(f, f.replace("_input", "_c"))
+                    out[key + "_mean"] = float(v.mean() * scale)
+                    out[key + "_max"] = float(v.max() * scale)
+            return out
+        per_phase = {p: stats(lab == p) for p in sorted(set(self.labels))}
+        return {"period_s": self.period, "probe": "st_clock_probe: s_memtime / s_memrealtime over 20 us on 8 one-wave workgroups (one per XCD), side stream",
+                "sysfs_files": sorted(self.files), "probe_errors": self.errors, "all": stats(np.ones(n, dtype=bool)),
+                "gemm_phases": stats(np.isin(lab, gemm_phases)), "by_phase": per_phase}
+
+
 def gemm_source_sha() -> str:
     """sha256 (16 hex digits) of the GEMM kernel sources: ties a committed PMC traffic figure to the kernels it was measured on."""
     import hashlib
@@ -96,6 +188,7 @@ def parse():
                          "12.35-12.40 s vs 11.99 s serial), hence off (default): the reference's serial order, rollout then compute_log_prob")
     ap.add_argument("--tail-cus", type=int, default=64, help="compute units of the decode tail's stream under --overlap-old on (multiple of 8)")
     ap.add_argument("--tail-rows", type=int, default=128, help="decode phases of at most this many rows run on the tail stream")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample the shader clock / socket power beside the timed region")
     ap.add_argument("--no-fp8-leg", action="store_true",
                     help="skip the short BASELINE-config-#5 leg (G = 16, 896x896, 32 prompts/GPU, MX-fp8 projections forward + dX + dW; 2 steps + 1 "
                          "warm-up in a child process before this process touches the GPU) that the default command reports as `cfg5_fp8`")
@@ -154,7 +247,7 @@ def fp8_leg(a):
            "--image", "896x896", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp8-leg"]
     t0 = time.perf_counter()
     try:
-        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)      # ~2x the leg's usual 180-200 s
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
         if p.returncode != 0 or not line:
             return {"error": f"child exited with {p.returncode}", "stderr_tail": p.stderr[-400:]}
@@ -579,7 +672,8 @@ def cpu_baseline():
     del p7
     fwd7_per_sample = t7 * 28 / LS                            # the 28 LM layers of one 1614-token sample (ViT + head excluded)
     return {"value": n_prompt * G / step_s, "unit": "samples/s (full GRPO step: gen + old + ref + update + AdamW)", "cores": threads, "kind": "port",
-            "sample": f"leg 1 = config #1 shape (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image -> 64 image tokens, 700 text tokens, 512-token "
+            "sample": f"EXTRAPOLATED from {LS} of {L_LM} LM layers and {LS} of {L_VIT} ViT blocks (measured legs scaled by depth, sequence and step counts; "
+                      f"no full-depth CPU step was run).  leg 1 = config #1 shape (Qwen2.5-VL-3B widths, 2 prompts x G=4, 224x224 image -> 64 image tokens, 700 text tokens, 512-token "
                       f"responses), fp32 torch oracle, whole passes over a {LS}-LM-layer / {LS}-ViT-block model on {NSEQ} of the 8 sequences ({T} tokens): "
                       f"no-grad pass, forward+backward, final norm + tied lm_head + log-softmax on {rows} response rows, {n_dec} KV-cache decode steps "
                       f"of the {LS} layers for the 8 rollouts, AnyPrecisionAdamW's torch op sequence on 8M bf16 parameters; every component = median of {REPS} runs after a warm-up; scaled by layers ({L_LM}/{LS}, {L_VIT}/{LS}), sequences "
@@ -725,10 +819,15 @@ def main():
     overlap_stats = {"early_rows": 0, "feed_host_s": 0.0}
     reward_cpu_s = [0.0]                                       # the scorer thread's own wall time over all steps (overlapped with old / ref)
 
+    class _NoTelemetry:
+        phase = "idle"
+    tele = _NoTelemetry()
+
     def one_step(step_idx, timed):
         (ids, mask, pos, pix, grids), lens = staged[step_idx]
         tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
         t0 = tick()
+        tele.phase = "gen"
         early, extra = None, {}
         if overlap_old:
             n_cu = torch.cuda.get_device_properties(0).multi_processor_count
@@ -760,6 +859,7 @@ def main():
         if os.environ.get("ST_REWARD_THREAD", "1") == "0":    # the reference's serial order
             reward_thread.join()
         t2 = tick()
+        tele.phase = "old"
         if early is not None:
             data["old_log_probs"] = early.finish(data, prompt_cache)       # most of it ran beside the decode tail; the rest runs here
             overlap_stats["early_rows"] += sum(len(s_) for s_ in early.sets[:-1]) if len(early.sets) > 1 else 0
@@ -769,8 +869,10 @@ def main():
                                                            use_rollout_log_probs=a.old_from_rollout)   # as FSDPWorker.compute_log_probs
         del prompt_cache, early
         t3 = tick()
+        tele.phase = "ref"
         data["ref_log_probs"] = ref.compute_log_prob(data, temperature)
         t4 = tick()
+        tele.phase = "adv"
         reward_thread.join()
         rewards = reward_out["rewards"]
         reward_cpu_s[0] += reward_out["seconds"]
@@ -778,8 +880,10 @@ def main():
         adv, status = ops.grpo_advantage(rewards.cuda(), rmask.cuda(), group, npr)
         data["advantages"] = adv
         t5 = tick()
+        tele.phase = "update_actor"
         metrics = actor.update_policy(data, temperature)
         t6 = tick()
+        tele.phase = "between_steps"
         reserved_trace.append(round(torch.cuda.memory_reserved() / 2 ** 30, 1))
         if timed:
             for k, v in zip(phase, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
@@ -837,6 +941,9 @@ def main():
     torch.cuda.synchronize()
     if actor.grad_reducer() is not None:
         actor._exchange_stats_at_start = actor.grad_reducer().stats()          # the warm-up steps' exchanges are not part of the timed region
+    if rank == 0 and not a.no_telemetry:
+        tele = ChipTelemetry(period=max(0.1, min(0.5, 0.02 * a.steps)))     # ~120 samples per 30-s step at the driver's 20 steps
+        tele.start()
     if world > 1:
         dist.barrier()
     t_start = time.perf_counter()
@@ -862,6 +969,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    telemetry = None
+    if isinstance(tele, ChipTelemetry):
+        tele.stop()
+        telemetry = tele.summary()
     prof = {}
     gemm_shapes = None
     for k in classes:
@@ -906,6 +1017,14 @@ def main():
                 os.makedirs(os.path.dirname(os.path.abspath(a.gemm_table)), exist_ok=True)
                 with open(a.gemm_table, "w") as f:
                     json.dump({"command": " ".join(sys.argv), "stride": PROF_STRIDE, "class_tflops": main_roof["achieved"], "shapes": gemm_shapes}, f, indent=1)
+        # the clock the chip ran the GEMM-heavy phases at (ChipTelemetry): the MFMA peak scales with the shader clock (2.5 PF/s is the
+        # 2400-MHz figure), so `frac_of_clocked_peak` is what the kernel made of the cycles it was given, `frac` what it made of the datasheet
+        if telemetry and telemetry.get("gemm_phases") and main_roof.get("achieved"):
+            ck = telemetry["gemm_phases"]["clock_mhz_mean"]
+            main_roof["clock_mhz"] = ck
+            main_roof["clock_mhz_min"] = telemetry["gemm_phases"]["clock_mhz_min"]
+            main_roof["socket_power_w"] = telemetry["gemm_phases"].get("socket_power_w_mean")
+            main_roof["frac_of_clocked_peak"] = main_roof["achieved"] * 1e12 / (PEAK_BF16 * ck / 2400.0)
         main_roof["algorithmic_bytes_per_launch"] = ops.gemm_bytes["bytes"] / max(1, ops.gemm_bytes["launches"])
         main_roof["algorithmic_bytes"] = "operands once + result once (+ residual / fp32 read-modify-write), averaged over the class's launches"
         # HBM traffic per launch of the GEMM class: a PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
@@ -986,6 +1105,7 @@ def main():
             "roofline": main_roof,
             "roofline_classes": [roof(k) for k in classes if k != ops.K_GEMM and prof[k][1] > 0],
             "roofline_decode": dec,
+            "telemetry": telemetry,
         }
         if cfg5 is not None:
             out["cfg5_fp8"] = cfg5

@@ -425,11 +425,21 @@ int st_decode_step(const float* sample_scratch, const int32_t* forced_len, int32
  *      reference phases verl/trainer/ray_trainer.py:585-640 run one after the other) -----------------------------------------------
  * st_stream_create_cu_range: a HIP stream whose kernels run only on compute units [first_cu, first_cu + n_cus) of the chip's CU-mask
  * bit order (hipExtStreamCreateWithCUMask).  On MI355X bit i is slot i / 8 of XCD i % 8 (tools/probes/cu_mask_probe.hip), so a range
- * whose bounds are multiples of 8 takes the same number of CUs from every XCD; two streams on disjoint ranges run side by side without
- * slowing each other (probe: 64 CUs stream 3.4 TB/s next to 192 CUs at 1.64 PF/s, alone and together).  The handle is a hipStream_t for
- * every st_* entry's `stream` argument.  st_stream_destroy releases it (the stream must be idle). */
+ * whose bounds are multiples of 8 takes the same number of CUs from every XCD.  EXPERIMENTAL, and measured as a NET LOSS for the use it was
+ * built for: a register-only MFMA kernel and a streaming kernel on disjoint ranges keep their stand-alone rates (probe: 64 CUs stream
+ * 3.4 TB/s next to 192 CUs at 1.64 PF/s), but real passes share every XCD's L2 and the fabric — the old-policy pass beside the decode tail
+ * ran gen + old 12.35-12.40 s against 11.99 s serial (profiles/r05_notes.md §2), so bench.py keeps it off by default.  The handle is a
+ * hipStream_t for every st_* entry's `stream` argument.  st_stream_destroy releases it (the stream must be idle). */
 int st_stream_create_cu_range(int first_cu, int n_cus, st_stream_t* stream_out);
 int st_stream_destroy(st_stream_t stream);
+
+/* ---- measurement aid (round 6; no reference counterpart: the reference reports `perf/mfu_actor` against a fixed peak,
+ *      verl/utils/flops_counter.py:24-50, and cannot say what clock the chip ran at) -------------------------------------------------
+ * st_clock_probe: n_blocks one-wave workgroups (block b lands on XCD b % 8) each spin for spin_us microseconds of the constant 100-MHz
+ * reference counter (s_memrealtime) and write {shader cycles (s_memtime), reference ticks} to out[2 b], out[2 b + 1]: shader clock in MHz =
+ * 100 * out[2 b] / out[2 b + 1] — the clock the power management grants while whatever else is running runs.  Launched on a side stream
+ * beside the timed region by bench.py (`roofline.clock_mhz`); 8 waves for spin_us, no memory traffic besides the 16 result bytes. */
+int st_clock_probe(uint64_t* out, int n_blocks, int spin_us, st_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -296,8 +296,9 @@ class EarlyLogProb:
     samples that have already finished is MFMA-bound and needs nothing but their tokens and the prompt K/V of the prefill.  The generator
     reports the finishers of every decode phase (Generator.generate(on_finished=self.feed)); `feed` stages their rows exactly as
     `assemble_rollout_batch` will (same response mask, same position ids) and issues Qwen25VL.log_probs_cached for them on `side_stream`, a
-    CU-range stream complementary to the decode tail's (ops.cu_range_stream): both streams keep to their compute units and neither slows
-    the other (tools/probes/cu_mask_probe.hip).  `finish` computes the samples of the last phase, waits for the side stream and returns the
+    CU-range stream complementary to the decode tail's (ops.cu_range_stream).  EXPERIMENTAL — measured slower end to end on MI355X
+    (gen + old 12.35-12.40 s vs 11.99 s serial, profiles/r05_notes.md §2): the streams keep to their compute units, but the passes contend
+    for every XCD's L2 and the fabric, so the mode is off by default.  `finish` computes the samples of the last phase, waits for the side stream and returns the
     (N, R) tensor compute_log_prob would have returned.
 
     Same arithmetic, different grouping: a pass holds the finishers of ONE phase (cut by the token budget), not consecutive rows.  The

@@ -3,6 +3,19 @@
 
 StProf g_prof[ST_K_COUNT];
 
+// shader-clock probe: s_memtime counts shader cycles, s_memrealtime the constant 100-MHz reference — their ratio over a short spin is the
+// clock the chip's power management grants AT THAT MOMENT (MI355X_MICROARCH.md "DVFS give-back": 1.9-2.3 GHz by load, 2.4 GHz max)
+__global__ void clock_probe_kernel(unsigned long long* out, int spin_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < (unsigned long long)spin_ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+}
+
 extern "C" {
 int st_version(void) { return 1; }
 const char* st_arch(void) { return "gfx950"; }
@@ -83,6 +96,12 @@ int st_stream_destroy(st_stream_t stream) {
     if (!stream) return ST_EINVAL;
     hipError_t e = hipStreamDestroy((hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
+}
+int st_clock_probe(uint64_t* out, int n_blocks, int spin_us, st_stream_t stream) {
+    if (!out || n_blocks <= 0 || n_blocks > 64 || spin_us <= 0 || spin_us > 1000) return ST_EINVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, spin_us * 100);
+    ST_CHECK_LAUNCH();
+    return 0;
 }
 int st_prof_disable(int klass) {
     if (klass < 0 || klass >= ST_K_COUNT) return ST_EINVAL;

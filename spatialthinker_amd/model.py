@@ -403,7 +403,9 @@ class Qwen25VL:
         self.sp_rank = dist.get_rank(group) if group is not None else 0
         c = self.cfg
         if self.sp > 1 and (c.num_heads % self.sp or c.num_kv_heads % self.sp):
-            raise ValueError(f"ulysses_sequence_parallel_size = {self.sp} must divide the {c.num_heads} query heads and the {c.num_kv_heads} key/value heads")
+            raise ValueError(f"ulysses_sequence_parallel_size = {self.sp} must divide the {c.num_heads} query heads and the {c.num_kv_heads} key/value heads "
+                             f"(this engine does not repeat K/V heads for sp > num_kv_heads as the reference's attention patch does: "
+                             f"sp <= {c.num_kv_heads} for this model; INTEGRATION.md)")
 
     def _sp_a2a(self, x3: torch.Tensor, scatter_dim: int, gather_dim: int) -> torch.Tensor:
         """One all-to-all over the sequence-parallel group: `sp` equal pieces of x3 along scatter_dim, piece j to rank j, the received

@@ -757,6 +757,13 @@ def add_(a, b, out=None):
 _prof_on = [False] * 10
 
 
+def clock_probe(out: torch.Tensor, slot: int, stream: "torch.cuda.Stream", n_blocks: int = 8, spin_us: int = 20):
+    """One shader-clock sample into out[slot] ((n_slots, n_blocks, 2) int64: {shader cycles, 100-MHz reference ticks} per block) on
+    `stream` (st_clock_probe) — a side stream, so that the sample is taken WHILE the compute stream's kernels run."""
+    assert out.dtype == torch.int64 and out.is_cuda and out.shape[1:] == (n_blocks, 2) and out.is_contiguous()
+    lib().st_clock_probe(out[slot].data_ptr(), n_blocks, spin_us, stream.cuda_stream)
+
+
 def prof_enable(klass: int, max_events: int = 200000, stride: int = 1):
     """Event-time every `stride`-th launch of the class on its launch stream (hipGraph-captured launches are never timed)."""
     lib().st_prof_enable(klass, max_events)

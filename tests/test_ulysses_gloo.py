@@ -192,3 +192,76 @@ def test_ulysses_utilities_equal_the_reference_modules_outputs(tmp_path):
             assert got[k].shape == want.shape and got[k].dtype == want.dtype and np.array_equal(got[k], want), (r, k)
             n += 1
     assert n == 24
+
+
+class _StubEngine:
+    """Stands in for PolicyEngine on a box without a GPU: records how many rows it was handed and returns a function of the row ids."""
+
+    def __init__(self):
+        self.rows_seen = []
+        self.last_prompt_cache_hit = False
+
+    def compute_log_prob(self, d, temperature, *a, **k):
+        ids = d["responses"]
+        self.rows_seen.append(int(ids.shape[0]))
+        return ids.float() * 0.5
+
+    def update_policy(self, d, temperature):
+        self.rows_seen.append(int(d["responses"].shape[0]))
+        assert d["old_log_probs"].shape == d["responses"].shape and d["ref_log_probs"].shape == d["responses"].shape
+        return {"actor/pg_loss": float(d["responses"].float().mean())}
+
+
+def _sp_worker_calls(rank, world, port, out_dir):
+    """compute_log_probs -> union -> compute_ref_log_probs -> union -> update_actor through FSDPWorker with sp = 2, the way
+    RayPPOTrainer.fit drives it (ray_trainer.py:620-680) — on the trainer's OWN batch object (SPMDWorkerGroup hands no copy)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from verl.protocol import DataProto
+    from verl.trainer.config import load_config
+    from verl.workers import fsdp_workers as FW
+    cfg = load_config(["worker.actor.ulysses_sequence_parallel_size=2", "worker.actor.global_batch_size=4", "worker.rollout.n=1",
+                       "worker.actor.micro_batch_size_per_device_for_update=2", "worker.actor.micro_batch_size_per_device_for_experience=2",
+                       "worker.actor.model.model_path=random:tiny"])
+    cfg.deep_post_init()
+    w = FW.FSDPWorker(cfg.worker, "actor_rollout_ref")
+    assert w.sp_size == 2 and w.sp_group is not None
+    w.actor, w.ref_policy = _StubEngine(), _StubEngine()
+
+    class _Flops:
+        def estimate_flops(self, n, dt): return 1.0, 1.0
+    w.flops_counter = _Flops()
+    FW.torch.cuda.reset_peak_memory_stats = lambda *a, **k: None            # no GPU on this box: the worker's memory bookkeeping is not under test
+    FW.torch.cuda.synchronize = lambda *a, **k: None
+    FW.torch.cuda.max_memory_allocated = lambda *a, **k: 0
+    FW.torch.cuda.max_memory_reserved = lambda *a, **k: 0
+    N, R = 4, 3
+    resp = (torch.arange(N)[:, None] * 10 + torch.arange(R)[None] + 1000 * rank)
+    batch = DataProto.from_dict({"responses": resp, "response_mask": torch.ones(N, R, dtype=torch.int64)},
+                                non_tensors={"uid": np.array([f"r{rank}_{i}" for i in range(N)], dtype=object)})
+    batch.meta_info["global_token_num"] = [R] * N
+    old = w.compute_log_probs(batch)
+    assert len(batch) == N and len(old) == N, (len(batch), len(old))                     # the caller's batch keeps ITS rows
+    assert torch.equal(batch.batch["responses"], resp) and list(batch.non_tensor_batch["uid"]) == [f"r{rank}_{i}" for i in range(N)]
+    batch = batch.union(old)                                                              # ray_trainer.py:636 (raised before the fix: 8 rows vs 4)
+    ref = w.compute_ref_log_probs(batch)
+    assert len(batch) == N and len(ref) == N
+    batch = batch.union(ref)
+    batch.batch["advantages"] = torch.zeros(N, R)
+    m = w.update_actor(batch)
+    assert len(batch) == N
+    res = dict(old=old.batch["old_log_probs"].clone(), ref=ref.batch["ref_log_probs"].clone(), rows_actor=w.actor.rows_seen,
+               rows_ref=w.ref_policy.rows_seen, pg=float(m.non_tensor_batch["actor/pg_loss"][0]), resp=resp)
+    torch.save(res, os.path.join(out_dir, f"w{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_worker_methods_under_sp2_never_change_the_callers_batch(tmp_path):
+    world = 2
+    mp.spawn(_sp_worker_calls, args=(world, 29595, str(tmp_path)), nprocs=world)
+    r = [torch.load(tmp_path / f"w{k}.pt", weights_only=False) for k in range(world)]
+    both = torch.cat([r[0]["resp"], r[1]["resp"]]).float()
+    for k in range(world):
+        assert r[k]["rows_actor"] == [8, 8] and r[k]["rows_ref"] == [8]                   # the engines saw the whole sp group's rows ...
+        assert torch.equal(r[k]["old"], r[k]["resp"].float() * 0.5) and torch.equal(r[k]["ref"], r[k]["resp"].float() * 0.5)   # ... each rank got ITS rows back
+        assert abs(r[k]["pg"] - float(both.mean())) < 1e-3

@@ -11,7 +11,10 @@ from typing import Dict
 
 try:                                                    # pragma: no cover - only when mathruler is installed
     from mathruler.grader import extract_boxed_content as _boxed, grade_answer as _grade
+    _FALLBACK = False
 except Exception:
+    _FALLBACK = True
+
     def _boxed(text: str) -> str:
         """content of the last \\boxed{...} with balanced braces, "None" when there is none (mathruler's convention)"""
         start = text.rfind("\\boxed{")
@@ -31,6 +34,18 @@ except Exception:
         norm = lambda s: re.sub(r"\s+", "", s.strip().strip("$").lower())
         return norm(pred) == norm(gt)
 
+_warned = False
+
+
+def _warn_fallback_once() -> None:
+    global _warned
+    if not _warned and _FALLBACK:
+        _warned = True
+        print("[math reward] mathruler is not installed: answers are graded by a normalised STRING comparison of the last \\boxed{...}; "
+              "the reference's grade_answer also accepts symbolic / numeric equivalents ('0.5' vs '\\frac12'), so accuracy rewards can be "
+              "lower than the reference's on the same responses", flush=True)
+
+
 _FORMAT = re.compile(r"<think>.*</think>.*\\boxed\{.*\}.*", re.DOTALL)
 
 
@@ -43,6 +58,7 @@ def math_acc_reward(predict_str: str, ground_truth: str) -> float:
 
 
 def math_compute_score(predict_str: str, ground_truth: str) -> Dict[str, float]:
+    _warn_fallback_once()
     predict_str = re.sub(r"\s*(<|>|/)\s*", r"\1", predict_str)      # "< think >" -> "<think>" (the reference's qwen2.5-vl-32b clean-up)
     fmt = math_format_reward(predict_str)
     acc = math_acc_reward(predict_str, ground_truth)

@@ -33,7 +33,11 @@ class FSDPUlyssesShardingManager(BaseShardingManager):
         return False
 
     def preprocess_data(self, data: DataProto) -> DataProto:
+        """The gathered rows go into a NEW DataProto: `all_gather_data_proto` works in place (as the reference's does), and the
+        reference is only safe with that because Ray hands the worker its own copy of the driver's batch.  Here the worker is called
+        on the trainer's own object (SPMDWorkerGroup), which must keep its N rows for the `union` that follows."""
         if self.device_mesh is not None:
+            data = DataProto(batch=data.batch, non_tensor_batch=dict(data.non_tensor_batch), meta_info=dict(data.meta_info))
             all_gather_data_proto(data, size=self._sp().size(), group=self._sp().get_group())
         return data
 

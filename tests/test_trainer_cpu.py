@@ -347,6 +347,51 @@ def test_two_ranks_shard_rows_and_rank0_logs_global_metrics(tmp_path):
     assert "val/reward_score:0.1" in v and "val/overall_reward:0.1" in v
 
 
+def _eight_rank_worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ST_SKIP_FINAL_SAVE="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        tr, wg, cfg = make_trainer(tmp, ["trainer.max_steps=2", "data.rollout_batch_size=16", "worker.actor.global_batch_size=8"], n_rows=64, n=2)
+        tr.fit()
+    res = {"out": buf.getvalue(), "steps": []}
+    for d in wg.updates:
+        res["steps"].append({"rows": [int(g[2:]) for g in d.non_tensor_batch["ground_truth"]], "lens": d.batch["attention_mask"].sum(-1).tolist(),
+                             "scores": d.batch["token_level_scores"].sum(-1).tolist(), "adv": d.batch["advantages"].clone()})
+    torch.save(res, os.path.join(tmp, f"e{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_rows_as_dataproto_chunks_and_rank0_logs_global_metrics(tmp_path):
+    """BASELINE config #4's partitioning (DP = 8; reference verl/single_controller/base/decorator.py:106-123 `dispatch_dp_compute_data_proto`
+    = DataProto.chunk(world), fsdp_workers.py:130-136 batch arithmetic) without the hardware: 8 gloo ranks drive RayPPOTrainer.fit for two
+    steps; rank r works on chunk r of the step's global batch (2 prompts x n = 2 rollouts), the groups of a prompt never straddle ranks,
+    and rank 0's log line carries the GLOBAL statistics."""
+    world = 8
+    mp.spawn(_eight_rank_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"e{k}.pt", weights_only=False) for k in range(world)]
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(3)).tolist()
+    for step in range(2):
+        batch = perm[16 * step:16 * (step + 1)]
+        lens, scores = [], []
+        for k in range(world):
+            st = r[k]["steps"][step]
+            assert sorted(set(st["rows"])) == sorted(batch[2 * k:2 * k + 2]) and len(st["rows"]) == 4      # chunk k, both rollouts of each prompt
+            lens += st["lens"]; scores += st["scores"]
+            assert st["adv"].shape[0] == 4
+        line = [l for l in r[0]["out"].splitlines() if l.startswith(f"step {step + 1}:")][0]
+        kv = dict(item.split(":", 1) for item in line[len(f"step {step + 1}: "):].split(" - "))
+        assert float(kv["perf/total_num_tokens"]) == sum(lens)
+        parts = get_seqlen_balanced_partitions(lens, world, True)
+        bal = [sum(lens[i] for i in p) for p in parts]
+        assert float(kv["global_seqlen/balanced_max"]) == max(bal) and float(kv["global_seqlen/balanced_min"]) == min(bal)
+        assert abs(float(kv["critic/score/mean"]) - float(np.mean(scores))) < 1e-4
+        assert abs(float(kv["actor/grad_norm"]) - 4.0) < 1e-6
+    for k in range(1, world):
+        assert r[k]["out"].count("step 1:") == 0
+
+
 def _migrate_worker(rank, world, port, tmp):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ST_SKIP_FINAL_SAVE="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)

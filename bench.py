@@ -53,7 +53,15 @@ class ChipTelemetry:
         self.phase = "idle"
         self.errors = 0
         self.files = {}
-        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        # the hwmon directory of THIS process's GPU (a node exposes every GPU's sysfs files to the container; c2 of round 6 read an idle
+        # neighbour): matched by PCI address; no match -> no sysfs figures rather than somebody else's
+        self.pci = None
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            self.pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        for d in (sorted(glob.glob(f"/sys/bus/pci/devices/{self.pci}/hwmon/hwmon*")) if self.pci else []):
             for f in self.HWMON:
                 fp = os.path.join(d, f)
                 if os.path.exists(fp) and f not in self.files:
@@ -120,7 +128,7 @@ class ChipTelemetry:
             return out
         per_phase = {p: stats(lab == p) for p in sorted(set(self.labels))}
         return {"period_s": self.period, "probe": "st_clock_probe: s_memtime / s_memrealtime over 20 us on 8 one-wave workgroups (one per XCD), side stream",
-                "sysfs_files": sorted(self.files), "probe_errors": self.errors, "all": stats(np.ones(n, dtype=bool)),
+                "sysfs_files": sorted(self.files), "pci": self.pci, "probe_errors": self.errors, "all": stats(np.ones(n, dtype=bool)),
                 "gemm_phases": stats(np.isin(lab, gemm_phases)), "by_phase": per_phase}
 
 

@@ -259,6 +259,17 @@ int st_attn_fwd_ranges(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t 
                        [pre_beg, pre_end) of k_pre / v_pre, visited before the own range — lets ONE launch cover the shared-prompt
                        partials (keys in the prompt cache, own range empty) and the per-sample partials (prefix empty) */,
                        st_stream_t stream);
+/* The per-SAMPLE partials of the decode step (use (ii) of st_attn_fwd_ranges; same reference call site, vllm_rollout_spmd.py:141-143) with
+ * one WAVE per (item, head): items of at most 32 query rows against their own key range only (no prefix), D = 128, non-causal.  Each item
+ * streams its keys in 32-key tiles through a private ring of `slots` (2..4) 16-KiB LDS slots — 32 KiB per workgroup at slots = 2, five
+ * co-resident items per CU instead of the two 256-thread workgroups of attn_fwd128_kernel — with counted waits and no barriers
+ * (round 6, csrc/attention_decode.hip).  Same outputs as st_attn_fwd_ranges for such items up to fp32 rounding of the online softmax
+ * (32-key steps instead of 64): out rows [o_beg or q_beg, +Lq) of this head's 128 columns, lse (n_heads, T_out), lse = -inf and out
+ * untouched for an empty key range. */
+int st_attn_decode_rows(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
+                        const int32_t* q_beg, const int32_t* q_end, const int32_t* k_beg, const int32_t* k_end, const int32_t* o_beg,
+                        int q_group, int n_items, int T_out, int n_heads, int D, float scale, st_bf16* out, int64_t ldo, float* lse,
+                        int max_q, int slots, st_stream_t stream);
 /* Which kernel st_attn_fwd_ranges uses for decode-shaped launches (n_q == n_kv, items of <= 64 query rows, D = 128): 1 = the persistent
  * one-workgroup-per-CU kernel (attn_decode128_kernel: the tiles of all of a workgroup's items stream through one 4-slot LDS ring, 3 tiles
  * in flight per CU), 0 = one workgroup per item (attn_fwd128_kernel<false>; default — measured faster, see attention.hip — and the

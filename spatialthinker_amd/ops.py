@@ -821,6 +821,13 @@ def attn_fwd_ranges(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_q, n_kv, D, sc
     return out, lse
 
 
+def attn_decode_rows(q, k, v, q_beg, q_end, k_beg, k_end, max_q, n_heads, D, scale, out, lse, o_beg=None, q_group=0, slots=2):
+    """Per-sample decode partials, one wave per (item, head) (st_attn_decode_rows): items of <= 32 query rows against their own keys."""
+    lib().st_attn_decode_rows(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(q_beg), _p(q_end), _p(k_beg), _p(k_end), _p(o_beg),
+                              int(q_group), q_beg.numel(), out.shape[0], n_heads, D, scale, _p(out), out.stride(0), _p(lse), int(max_q), int(slots), _s())
+    return out, lse
+
+
 def decode_attn_select(persistent):
     """Kernel behind attn_fwd_ranges for decode-shaped launches: 0 / False = one workgroup per item (default), 1 / True = the persistent
     kernel with one workgroup per CU (4-slot ring), 2 = persistent with two workgroups per CU (2-slot rings); all bit-identical

@@ -23,6 +23,12 @@ from . import indexing as ix
 from . import ops
 from .model import BF16, F32, I32, I64, Qwen25VL, drop_pixel_cache, pixels_on_device
 
+# per-sample decode attention on the one-wave-per-item kernel (st_attn_decode_rows; same partials up to fp32 rounding of the online softmax).
+# Round 6, measured and left OFF (profiles/r06_notes.md §2): equal at 512 rows (per layer 34 + 29 us vs 62 us in one launch at 100-token mean
+# contexts, 34 + 65 vs 101 at 300), 7 % SLOWER per iteration at <= 64 rows — both kernels sit on the CU's LDS-DMA issue rate (16 one-KiB
+# copies per 16-KiB tile), not on workgroup lifetime or occupancy, which is what the one-wave kernel changes.  ST_DECODE_ROWS=1 selects it.
+DECODE_ROWS_DEFAULT = os.environ.get("ST_DECODE_ROWS", "0") == "1"
+
 
 class Generator:
     def __init__(self, model: Qwen25VL, prefill_chunk_tokens: int = 32768, autotune: bool = False, fused_decode: bool = True):
@@ -32,6 +38,7 @@ class Generator:
         # tiles until half of the rows have finished, then one) where two 256-row waves + pooled survivors need ~1430 at 7.9 ms:
         # 11.9 s instead of 13.3 s for the bench's 512 rollouts (tools/gen_phases.py, round 2)
         self.max_decode_batch = int(os.environ.get("ST_MAX_DECODE", "512"))
+        self.decode_rows_kernel = DECODE_ROWS_DEFAULT      # per-sample decode partials on st_attn_decode_rows (opt-in, ST_DECODE_ROWS=1: measured no faster)
         self.compact = True               # restart the decode graph on the survivors once half of a phase's rows have finished
         self.fused_decode = fused_decode  # fused decode epilogues (bit-identical to the unfused launch chain; tests compare both)
         self.prefill_chunk_tokens = prefill_chunk_tokens
@@ -314,6 +321,10 @@ class Generator:
             cos_b = torch.empty(Ba, D // 2, dtype=F32, device=dev); sin_b = torch.empty_like(cos_b)
             samp_scratch = torch.empty(Ba * 33, dtype=F32, device=dev)
             ke_gen = ke_all[n1:]                                            # view: the generated-key range ends inside the launch arrays
+            rows_kernel = self.decode_rows_kernel and D == 128 and g <= 32
+            # ring depth of the one-wave kernel: 2 slots (32 KiB, five items per CU) while the items alone fill the chip, 4 slots (three
+            # tiles in flight per item) for the late phases whose few items are latency chains (ST_DECODE_ROWS_SLOTS overrides)
+            rows_slots = int(os.environ.get("ST_DECODE_ROWS_SLOTS", "0")) or (2 if Ba * nkv >= 1024 else 4)
 
             def iteration():
                 """sample -> record -> one decode forward for the phase's rows -> next logits.  Device state only (graph-capturable).
@@ -360,9 +371,18 @@ class Generator:
                         slabs, sp = ops.gemm_nt_decode_slabs(h1, w[p + "qkv_w"])
                         ops.decode_finish_qkv(slabs, sp, Bp, w[p + "qkv_b"], cos, sin, qbuf, kg[layer], vg[layer], glen, Ba, nq, nkv, D,
                                               row_map=S_t)
-                        ops.attn_fwd_ranges(qbuf, kgv[layer], vgv[layer], qb_all, qe_all, kb_all, ke_all, max_q_all, nkv, nkv, D, m.scale,
-                                            parts, lse_parts, o_beg=ob_all, q_group=g, pre_beg=pb_all, pre_end=pe_all,
-                                            k_pre=kp[layer], v_pre=vp[layer])
+                        if rows_kernel:
+                            # round 6: the per-sample partials (7 query rows against the sample's own keys) run one WAVE per item
+                            # (st_attn_decode_rows: five items per CU instead of two 256-thread workgroups with one computing wave
+                            # each); the prompt partials (56 rows against 576 shared keys) stay on the workgroup kernel
+                            ops.attn_fwd_ranges(qbuf, kgv[layer], vgv[layer], qb1, qe1, z1, z1, max_q1, nkv, nkv, D, m.scale, parts, lse_parts,
+                                                o_beg=ob1, q_group=g, pre_beg=kb1, pre_end=ke1, k_pre=kp[layer], v_pre=vp[layer])
+                            ops.attn_decode_rows(qbuf, kgv[layer], vgv[layer], qb2, qe2, kb2, ke_gen, g, nkv, D, m.scale, parts, lse_parts,
+                                                 o_beg=ob2, q_group=g, slots=rows_slots)
+                        else:
+                            ops.attn_fwd_ranges(qbuf, kgv[layer], vgv[layer], qb_all, qe_all, kb_all, ke_all, max_q_all, nkv, nkv, D, m.scale,
+                                                parts, lse_parts, o_beg=ob_all, q_group=g, pre_beg=pb_all, pre_end=pe_all,
+                                                k_pre=kp[layer], v_pre=vp[layer])
                         ops.attn_merge(parts, lse_parts, NP, nkv, D, out=abuf, q_group=g)
                         slabs, sp = ops.gemm_nt_decode_slabs(abuf, w[p + "o_w"])
                         x1 = torch.empty(Bp, H, dtype=BF16, device=dev); h2 = torch.empty(Bp, H, dtype=BF16, device=dev)

@@ -3,7 +3,7 @@ log-probs of one rollout group (2 rollouts behind one image + text prompt) from 
 attention dispatch) against the fp32 CPU oracle run sequence by sequence — with a plain torch bf16 evaluation of the SAME model on the
 same GPU (the oracle's own torch code on bf16 CUDA tensors: hipBLASLt matmuls, fp32 softmax / norm statistics as HF's eager path) as
 the yardstick of what 60 layers of bf16 rounding cost.  Criterion (as tests/test_gpu_model.py): the engine's error
-against fp32 is no larger than 1.5x the plain bf16 evaluation's own error.
+against fp32 is no larger than (factor 1.0, round 6) the plain bf16 evaluation's own error.
 
 Weights are generated once, tensor by tensor, on the GPU (8.3 B parameters: no host copy at all), into the engine's flat store and into a
 bf16 CUDA dict; the CPU oracle pulls each tensor back as fp32 when it needs it."""
@@ -115,4 +115,4 @@ def test_full_depth_7b_log_probs_vs_fp32_oracle_with_a_torch_bf16_yardstick(meas
     measured("depth7b_torch_bf16_rms_dlogp", rms_b)
     assert np.all(lp_e[~m] == 0)
     assert np.isfinite(lp_o[m]).all() and lp_o[m].std() > 0.05          # the comparison is not vacuous
-    assert err_e <= 1.5 * err_b and rms_e <= 1.5 * rms_b
+    assert err_e <= 1.0 * err_b and rms_e <= 1.0 * rms_b          # round 6: factor 1.0 (SURVEY 8c iii as written); measured 0.105 vs 0.220 max, 0.045 vs 0.078 rms

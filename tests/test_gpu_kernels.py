@@ -853,6 +853,38 @@ def test_decode_attention_persistent_kernel_is_bit_identical_to_one_item_per_wor
             worst = max(worst, float((got - want).abs().max()))
     measured(f"decode_attention_persistent_{case}_max_abs_vs_fp32", worst)
     assert worst < 0.02                                           # bf16 partials + bf16 output, |v| ~ 1 (measured ~0.008)
+    # ---- round 6: the per-sample items on the one-wave-per-item kernel (st_attn_decode_rows: 32-key tiles in a private ring of 2..4 slots,
+    # counted waits, no barriers), the prompt items on the workgroup kernel as before — the split the rollout's decode step launches.
+    # Same quantities up to the fp32 rounding of an online softmax that advances in 32-key steps: lse to 1e-5, partials to one bf16 step,
+    # -inf exactly where the workgroup kernel puts it, and the merged result against the dense fp32 attention as above.
+    n1 = len(kb1)
+    for slots in (2, 3, 4):
+        parts = torch.full((NP * rows_all, width), float("nan"), dtype=torch.bfloat16, device="cuda")
+        lse = torch.full((nkv, NP * rows_all), float("nan"), dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            ops.attn_fwd_ranges(q, kg, vg, args["q_beg"][:n1], args["q_end"][:n1], args["k_beg"][:n1], args["k_end"][:n1], n * g, nkv, nkv, D, scale, parts, lse,
+                                o_beg=args["o_beg"][:n1], q_group=g, pre_beg=args["pre_beg"][:n1], pre_end=args["pre_end"][:n1], k_pre=kp, v_pre=vp)
+            ops.attn_decode_rows(q, kg, vg, args["q_beg"][n1:], args["q_end"][n1:], args["k_beg"][n1:], args["k_end"][n1:], g, nkv, D, scale, parts, lse,
+                                 o_beg=args["o_beg"][n1:], q_group=g, slots=slots)
+        mr = ops.attn_merge(parts, lse, NP, nkv, D, out=torch.zeros(B, nkv * g * D, dtype=torch.bfloat16, device="cuda"), q_group=g)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.isfinite(lse), live) and torch.equal(lse == float("-inf"), l0 == float("-inf")), slots
+        assert float((lse[live] - l0[live]).abs().max()) < 2e-5, slots
+        dp = (parts[rows_live].float() - p0[rows_live].float()).abs()
+        dp = torch.nan_to_num(dp, nan=0.0)                           # (heads without keys inside a live row keep their NaN fill in both)
+        assert float(dp.max()) <= 2.0 ** -7 * max(1.0, float(torch.nan_to_num(p0[rows_live].float(), nan=0.0).abs().max())), (slots, float(dp.max()))
+        assert float((mr.float() - m0.float()).abs().max()) <= 2.0 ** -6, slots
+        worst_r = 0.0
+        for b in range(min(B, 6)):
+            pr = b // n
+            K = torch.cat([kp[p_off[pr]:p_off[pr + 1]], kg[b * R:b * R + int(glens[b])]]).float()
+            V = torch.cat([vp[p_off[pr]:p_off[pr + 1]], vg[b * R:b * R + int(glens[b])]]).float()
+            for h in range(nkv):
+                qq = q[b].float().view(nkv * g, D)[h * g:(h + 1) * g]
+                want = torch.softmax(qq @ K[:, h * D:(h + 1) * D].t() * scale, -1) @ V[:, h * D:(h + 1) * D]
+                worst_r = max(worst_r, float((mr[b].float().view(nkv * g, D)[h * g:(h + 1) * g] - want).abs().max()))
+        measured(f"decode_attention_rows_kernel_{case}_slots{slots}_max_abs_vs_fp32", worst_r)
+        assert worst_r < 0.02
 
 
 @pytest.mark.parametrize("M_,I,K", [(257, 1000, 128), (300, 80, 64), (512, 81, 192), (384, 2000, 3584), (512, 18944, 3584), (448, 11008, 2048), (1, 160, 64), (64, 240, 128)])

@@ -1,8 +1,13 @@
 """End-to-end parity of the HIP engine (bf16, spatialthinker_amd.model) on the tiny Qwen2.5-VL config:
   * log-probs vs the fp32 oracle AND vs the HF-derived golden fixture (tests/golden/model_tiny.npz);
-    criterion: the engine's error against fp32 is no larger than a bf16 evaluation's
-    own error — measured here by running HF transformers itself in bf16 on the GPU next to it;
-  * gradients of the GRPO micro-batch loss vs autograd through the oracle."""
+    criterion: the engine's error against fp32 is NO LARGER (factor 1.0) than a bf16 evaluation's
+    own error — measured here by running HF transformers itself in bf16 on the GPU next to it.  Round 6: the yardstick is POOLED over
+    16 random batches (tools/parity_probe.py: rms, mean of the per-batch maxima, overall maximum of |dlogp| over ~290 response tokens).
+    The earlier form compared the maximum over the 18 response tokens of ONE batch with a 1.5x allowance; that statistic is one draw
+    of a heavy-tailed quantity — over 16 batches the engine / HF-bf16 ratio of it ranges 0.43 .. 1.61 (median 0.91) while every pooled
+    statistic has the engine BELOW HF-bf16 (rms 0.0080 vs 0.0091, per-tap hidden-state errors 0.88-0.99x; profiles/r06_parity_probe.txt);
+  * gradients of the GRPO micro-batch loss vs autograd through the oracle, next to HF-bf16's own autograd gradients of the same scalar."""
+import importlib.util
 import os
 
 import numpy as np
@@ -29,6 +34,23 @@ def env(golden_dir):
     return z, cfg, params, store, eng, batch
 
 
+def _probe():
+    spec = importlib.util.spec_from_file_location("parity_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "parity_probe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def yardstick():
+    """pooled |dlogp| statistics of the engine and of HF-bf16 against HF-fp32 over 16 random tiny batches, measured live on this GPU"""
+    res = _probe().run(16, verbose=False)
+    e, h = res["logp"]["engine"], res["logp"]["hf_bf16"]
+    print(f"pooled over {e['tokens']} response tokens: engine rms {e['rms']:.5f} / mean per-batch max {e['mean_of_per_batch_max']:.4f} / max {e['max']:.4f}; "
+          f"HF-bf16 rms {h['rms']:.5f} / {h['mean_of_per_batch_max']:.4f} / {h['max']:.4f}")
+    return res
+
+
 def _stage(eng, z, batch):
     return eng.stage(batch["input_ids"], batch["attention_mask"], z["position_ids"], batch["R"], batch["pixel_values"], batch["image_grid_thw"])
 
@@ -40,16 +62,28 @@ def test_hf_roundtrip_of_param_layout(env):
         assert torch.equal(back[k].float().cpu(), torch.from_numpy(v)), k
 
 
-def test_log_probs_vs_fp32_oracle_and_hf_golden(env):
+def test_engine_error_is_no_larger_than_hf_bf16s_own_pooled_over_16_batches(yardstick):
+    """SURVEY 8c (iii) at factor 1.0: every pooled statistic of the engine's |dlogp| against fp32 is at most HF-bf16's own, and so is the
+    relative L2 error of every hidden-state tap (image features merged in, after each LM layer, final norm) — the per-block view that
+    would name the op if one of them added error."""
+    e, h = yardstick["logp"]["engine"], yardstick["logp"]["hf_bf16"]
+    assert e["rms"] <= h["rms"] and e["mean_abs"] <= h["mean_abs"], (e, h)                        # measured 0.0080 vs 0.0091, 0.0066 vs 0.0072
+    assert e["mean_of_per_batch_max"] <= h["mean_of_per_batch_max"] and e["max"] <= h["max"], (e, h)   # 0.0171 vs 0.0194, 0.0214 vs 0.0296
+    for t in yardstick["taps"]:
+        assert t["engine_rel_l2"] <= 1.0 * t["hf_bf16_rel_l2"], t                                 # 0.99 / 0.98 / 0.94 / 0.88 x
+
+
+def test_log_probs_vs_fp32_oracle_and_hf_golden(env, yardstick):
     z, cfg, params, store, eng, batch = env
     b = _stage(eng, z, batch)
     lp = eng.log_probs(b, temperature=1.0).cpu().numpy()
     mask = batch["attention_mask"][:, -batch["R"]:].astype(bool)
     err_golden = np.abs(lp[mask] - z["logp"][mask]).max()
-    # HF itself in bf16 on this GPU: the size of a bf16 evaluation's own error
+    # HF itself in bf16 on this GPU: the size of a bf16 evaluation's own error on THIS batch (one draw) and pooled (the bound)
     err_hf = _hf_bf16_error(z, cfg, params, batch)
-    print(f"engine max|dlogp| vs HF-fp32 golden: {err_golden:.4f}; HF-bf16 vs HF-fp32: {err_hf:.4f}")
-    assert err_golden <= 1.5 * err_hf              # measured 0.0158 vs 0.0137: the side-by-side ratio decides, no absolute floor
+    yard_max = yardstick["logp"]["hf_bf16"]["max"]
+    print(f"engine max|dlogp| vs HF-fp32 golden: {err_golden:.4f}; HF-bf16 vs HF-fp32 on this batch: {err_hf:.4f}, pooled maximum: {yard_max:.4f}")
+    assert err_golden <= yard_max                  # the committed HF-fp32 fixture: within what HF-bf16 itself shows over 16 batches (0.0158 vs 0.0296)
     assert np.all(lp[~mask] == 0)
     # temperature is applied to the logits (dp_actor.py:126)
     lp2 = eng.log_probs(b, temperature=0.5).cpu().numpy()
@@ -59,7 +93,7 @@ def test_log_probs_vs_fp32_oracle_and_hf_golden(env):
                                batch["image_grid_thw"]).numpy()
     err_t = np.abs(lp2[mask] - orc[mask]).max()
     print(f"temperature 0.5: max|dlogp| vs fp32 oracle {err_t:.4f}")
-    assert err_t <= 3 * err_hf                      # logits are doubled before the softmax: ~2x the temperature-1 error
+    assert err_t <= 2 * yard_max                    # logits are doubled before the softmax: 2x the temperature-1 yardstick
 
 
 def _hf_bf16_error(z, cfg, params, batch):
@@ -103,7 +137,7 @@ def _hf_bf16_error(z, cfg, params, batch):
     return float(max(errs))
 
 
-def test_grpo_micro_batch_gradients_vs_oracle_autograd(env):
+def test_grpo_micro_batch_gradients_vs_oracle_autograd(env, yardstick):
     z, cfg, params, store, eng, batch = env
     rs = np.random.RandomState(21)
     B, R = batch["input_ids"].shape[0], batch["R"]
@@ -124,17 +158,30 @@ def test_grpo_micro_batch_gradients_vs_oracle_autograd(env):
                                                    response_mask=dv(rmask, torch.int64)), 1.0,
                                            clip_low=0.2, clip_high=0.3, clip_dual=3.0, kl_kind="low_var_kl", kl_coef=1e-2, grad_accum=2.0)
     mask = rmask.astype(bool)
-    assert np.abs(lp_eng.cpu().numpy()[mask] - lp.detach().numpy()[mask]).max() < 2.1e-2         # measured 0.0158
+    assert np.abs(lp_eng.cpu().numpy()[mask] - lp.detach().numpy()[mask]).max() <= yardstick["logp"]["hf_bf16"]["max"]      # measured 0.0158 vs 0.0296
     grads = store.export_hf(store.g)
-    worst = []
+    # the yardstick for gradients (round 6): HF transformers in bf16 differentiating the SAME scalar sum(logp * g) with its own autograd on
+    # this GPU, against the same fp32 truth — per tensor, side by side.  (HF keeps bf16 gradients; the engine accumulates fp32 and rounds
+    # the operands of each product once.)
+    hf_rel = _probe().grad_yardstick(params, batch, z["position_ids"], g, {k: t.grad.numpy() for k, t in p32.items()})
+    worst, table = [], []
     for k, t in p32.items():
         want = t.grad.numpy()
         got = grads[k].float().cpu().numpy()
         rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-12)
         worst.append((rel, k))
+        if k in hf_rel and not k.endswith("k_proj.bias"):     # a key bias shifts every score of a query alike: its true gradient is ZERO up to
+            table.append((rel, hf_rel[k], k))                 # rounding, so a relative error measures nothing (engine 0.030, HF-bf16 0.022: both noise)
     worst.sort(reverse=True)
     print("worst gradient relative errors:", worst[:6])
-    assert worst[0][0] < 3.9e-2 and worst[1][0] < 2.5e-2, worst[:5]      # measured 0.0296 (a 256-element bias), then 0.0189
+    ratios = np.array([e / max(h, 1e-12) for e, h, _ in table])
+    e_all, h_all = np.array([e for e, _, _ in table]), np.array([h for _, h, _ in table])
+    print(f"engine vs HF-bf16 gradient error over {len(table)} tensors: worst {e_all.max():.4f} vs {h_all.max():.4f}, median {np.median(e_all):.4f} vs "
+          f"{np.median(h_all):.4f}; engine / HF-bf16 ratio: median {np.median(ratios):.2f}, max {ratios.max():.2f} "
+          f"({table[int(ratios.argmax())][2]}), tensors where the engine is worse: {int((ratios > 1).sum())}")
+    assert len(table) == len(p32) - cfg.num_layers
+    assert e_all.max() <= h_all.max() and np.median(e_all) <= np.median(h_all), (e_all.max(), h_all.max())
+    assert (ratios > 1).mean() <= GRAD_WORSE_FRACTION, sorted(((e / h, k) for e, h, k in table), reverse=True)[:6]
     # padded parameter regions must receive exactly zero gradient
     vi, vip = cfg.v_intermediate, cfg.v_inter_pad
     assert float(store.g["v.0.gu_w"][vi:vip].abs().max()) == 0 and float(store.g["v.0.down_w"][:, vi:].abs().max()) == 0
@@ -300,4 +347,5 @@ def test_vision_tower_taps_vs_hf_golden(env):
             assert rel < VIT_TAP_REL_L2 and err < VIT_TAP_MAX_OVER_RMS, (name, bi, rel, err)
 
 
+GRAD_WORSE_FRACTION = 0.25        # share of tensors whose engine gradient error may exceed HF-bf16's own on this one batch (set from the first measurement)
 VIT_TAP_REL_L2, VIT_TAP_MAX_OVER_RMS = 9.1e-3, 5.0e-2        # 1.3x the measured 0.0070 / 0.0386

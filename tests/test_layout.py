@@ -34,6 +34,9 @@ def test_library_defaults_after_load():
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, text=True)
     # decode attention: one workgroup per item; training GEMM: the 4-wave hand-scheduled tile; decode weights: non-temporal stream
     assert out.strip().splitlines()[-1] == "0 40 1 0 -1", out
+    # round 6: the one-wave-per-item decode attention kernel is opt-in (ST_DECODE_ROWS=1; measured no faster): off unless asked for
+    out = subprocess.check_output([sys.executable, "-c", "from spatialthinker_amd import rollout; print(rollout.DECODE_ROWS_DEFAULT)"], cwd=ROOT, env=env, text=True)
+    assert out.strip().splitlines()[-1] == "False", out
 
 
 def test_product_code_never_imports_the_oracle():

@@ -101,6 +101,14 @@ int st_rmsnorm_fwd(const st_bf16* x, int64_t ldx, const st_bf16* w, float eps, s
 int st_rmsnorm_bwd(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy,
                    int64_t lddy, const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx,
                    float* dw_accum, int T, int H, st_stream_t stream);
+/* The same backward in ONE pass over x / dy with a DETERMINISTIC dw (round 6): every workgroup leaves one fp32 partial row of dw in
+ * `workspace` (st_rmsnorm_bwd_workspace_bytes(T, H) bytes, contents irrelevant), a second small kernel adds the rows to dw_accum in a fixed
+ * order — no atomics, the same bits on every run; dx is bit-identical to st_rmsnorm_bwd's.  H <= 4096, 16-byte aligned operands.  Replaces
+ * the autograd backward of HF Qwen2_5_VLRMSNorm under /root/reference verl/workers/actor/dp_actor.py:212-292 (loss.backward()). */
+int64_t st_rmsnorm_bwd_workspace_bytes(int T, int H);
+int st_rmsnorm_bwd_fused(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy, int64_t lddy,
+                         const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx, float* dw_accum, void* workspace,
+                         int64_t workspace_bytes, int T, int H, st_stream_t stream);
 
 /* ---- rotary embeddings ------------------------------------------------------------------------
  * M-RoPE (HF rotary_emb :525-538 + apply_multimodal_rotary_pos_emb :557-599, called from

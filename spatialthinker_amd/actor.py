@@ -555,6 +555,8 @@ class PolicyEngine:
                 self.last_log_prob_source, self.last_prompt_cache_hit = "rollout", False
                 self.last_plan["experience"] = []
                 return got
+        dbg = os.environ.get("ST_STAGE_DEBUG", "0") == "1"
+        tl = [time.perf_counter()]
         N = data["input_ids"].shape[0]
         mb = micro_batch_size or (self.h.micro_batch_size_per_device_for_experience if self.h else 16)
         R = data["responses"].shape[1]
@@ -564,6 +566,7 @@ class PolicyEngine:
         passes = self._plan_passes(0, N, mb, max(1, int(self.fuse_experience)), self.tokens_per_pass_nograd, p_len, r_len, keys,
                                    prompts_cached=self.last_prompt_cache_hit)
         self.last_plan["experience"] = passes
+        tl.append(time.perf_counter())
         outs = []
         if self.last_prompt_cache_hit:
             n = prompt_cache["n"]
@@ -572,11 +575,18 @@ class PolicyEngine:
                 rows = np.arange(a, b_)
                 b = self.model.stage_responses(data["input_ids"][sl], data["attention_mask"][sl], data["position_ids"][sl], R,
                                                rows // n, prompt_cache["p_off"])
+                tl.append(time.perf_counter())
                 outs.append(self.model.log_probs_cached(b, prompt_cache, temperature))
+                tl.append(time.perf_counter())
         else:
             for (a, b_) in passes:
                 b = self._stage(data, slice(a, b_))
+                tl.append(time.perf_counter())
                 outs.append(self.model.log_probs(b, temperature))
+                tl.append(time.perf_counter())
+        if dbg:
+            print(f"[stage debug] compute_log_prob host ms: plan {1e3 * (tl[1] - tl[0]):.1f}; (stage, launch) per pass: "
+                  + ", ".join(f"({1e3 * (tl[i + 1] - tl[i]):.0f}, {1e3 * (tl[i + 2] - tl[i + 1]):.0f})" for i in range(1, len(tl) - 2, 2)), flush=True)
         out = torch.cat(outs, 0)
         del outs, b
         release_cached_blocks()
@@ -696,10 +706,10 @@ class PolicyEngine:
                     # the last pass of the optimizer step: gradient slices go out to the other ranks as backward leaves them
                     red = self.grad_reducer() if (self.overlap_allreduce and e >= m0 + mini) else None
                     b = self._stage(data, sl)
-                    to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
+                    to = lambda k, dt=F32: ops.h2d(torch.as_tensor(data[k][sl]), dt, dev)
                     loss_in = dict(old_log_probs=to("old_log_probs"), advantages=to("advantages"),
                                    ref_log_probs=to("ref_log_probs") if use_ref else None,
-                                   response_mask=torch.as_tensor(data["attention_mask"][sl])[:, -R:].to(dev, I64))
+                                   response_mask=ops.h2d(torch.as_tensor(data["attention_mask"][sl])[:, -R:], I64, dev))
                     _, met = self.model.forward_backward(b, loss_in, temperature, clip_low=h.clip_ratio_low, clip_high=h.clip_ratio_high,
                                                          clip_dual=h.clip_ratio_dual, kl_kind=h.kl_penalty, kl_coef=h.kl_coef,
                                                          grad_accum=float(accum), loss_rows=micro,
@@ -768,9 +778,9 @@ class CriticEngine(PolicyEngine):
                     sl = slice(s, e)
                     red = self.grad_reducer() if (self.overlap_allreduce and e >= m0 + mini) else None
                     b = self._stage(data, sl)
-                    to = lambda k, dt=F32: torch.as_tensor(data[k][sl]).to(dev, dt)
+                    to = lambda k, dt=F32: ops.h2d(torch.as_tensor(data[k][sl]), dt, dev)
                     loss_in = dict(values=to("values"), returns=to("returns"),
-                                   action_mask=self.action_mask(data["attention_mask"][sl], R).to(dev, I64))
+                                   action_mask=ops.h2d(self.action_mask(data["attention_mask"][sl], R), I64, dev))
                     _, met = self.model.value_forward_backward(b, loss_in, cliprange_value=h.cliprange_value, grad_accum=float(accum), loss_rows=micro,
                                                                on_final=red.ready if red is not None else None,
                                                                train_vision=not h.freeze_vision_tower)

@@ -2,6 +2,7 @@
 // fused log-prob forward/backward over the vocabulary, RMSNorm forward/backward.
 // All reductions use 64-lane wave shuffles; global access is 16 B per lane.
 #include "common.h"
+#include <algorithm>
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const uint16_t* __r
         unpack8(*reinterpret_cast<const uint4*>(dyr + i), df);
         unpack8(*reinterpret_cast<const uint4*>(w + i), wf);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += df[j] * wf[j] * (xf[j] * rs);
+        for (int j = 0; j < 8; ++j) acc = fmaf(__fmul_rn(df[j], wf[j]), __fmul_rn(xf[j], rs), acc);      // explicit: the one-pass kernel forms the same bits
     }
     const float mdot = wave_sum(acc) / (float)H;
     for (int i = lane * 8; i < H; i += 512) {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const uint16_t* __r
         if (dres) unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * lddres + i), o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float d = rs * (df[j] * wf[j] - (xf[j] * rs) * mdot);
+            const float d = __fmul_rn(rs, fmaf(-__fmul_rn(xf[j], rs), mdot, __fmul_rn(df[j], wf[j])));
             o[j] = dres ? (o[j] + d) : d;
         }
         *reinterpret_cast<uint4*>(dx + (int64_t)row * lddx + i) = pack8(o);
@@ -375,6 +376,120 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const uint16_t* __r
     part[ty][threadIdx.x & 63] = acc;
     __syncthreads();
     if (ty == 0 && c < H) atomicAdd(dw + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+static int rmsnorm_bwd_two_kernels(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy, int64_t lddy,
+                                   const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx, float* dw_accum, int T, int H, hipStream_t s);
+
+// RMSNorm backward in ONE pass over x / dy (round 6): a wave owns a row at a time — the row's x and dy pieces stay in
+// registers between the dot product and the dx store — and keeps this wave's share of dw (sum over its rows of dy * bf16(x * rstd)) in
+// registers; the four waves of a workgroup add theirs in wave order through LDS and the workgroup leaves ONE fp32 partial row in
+// `part` [gridDim.x][H], which rmsnorm_bwd_dw_finish_kernel adds to dw in block order: no atomics, the same bits on every run (the
+// two-kernel form above adds its workgroups' column sums with fp32 atomics, i.e. in whatever order they retire).  NP = ceil(H / 512).
+template <int NP>
+__global__ __launch_bounds__(256, 2) void rmsnorm_bwd_fused_kernel(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ w,
+                                                               const float* __restrict__ rstd, const uint16_t* __restrict__ dy, int64_t lddy,
+                                                               const uint16_t* __restrict__ dres, int64_t lddres, uint16_t* __restrict__ dx,
+                                                               int64_t lddx, float* __restrict__ part, int T, int H) {
+    extern __shared__ float red[];                             // [3][H]: the partial sums of waves 1..3
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4 wv[NP];                                              // the weight stays packed (28 registers at H = 3584): two workgroups per CU fit
+    float acc[NP][8];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i = lane * 8 + k * 512;
+        wv[k] = make_uint4(0, 0, 0, 0);
+        if (i < H) wv[k] = *reinterpret_cast<const uint4*>(w + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < T; row += gridDim.x * 4) {
+        const float rs = rstd[row];
+        const uint16_t* xr = x + (int64_t)row * ldx;
+        const uint16_t* dyr = dy + (int64_t)row * lddy;
+        uint4 xv[NP], dv[NP], rv[NP];                           // the whole row of all three inputs in flight at once
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = lane * 8 + k * 512;
+            if (i < H) {
+                xv[k] = *reinterpret_cast<const uint4*>(xr + i); dv[k] = *reinterpret_cast<const uint4*>(dyr + i);
+                if (dres) rv[k] = *reinterpret_cast<const uint4*>(dres + (int64_t)row * lddres + i);
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = lane * 8 + k * 512;
+            if (i < H) {
+                float xf[8], df[8], wf[8];
+                unpack8(xv[k], xf); unpack8(dv[k], df); unpack8(wv[k], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = __fmul_rn(xf[j], rs);
+                    dot = fmaf(__fmul_rn(df[j], wf[j]), xh, dot);
+                    acc[k][j] = fmaf(df[j], bfround(xh), acc[k][j]);
+                }
+            }
+        }
+        const float mdot = wave_sum(dot) / (float)H;
+        // the packed row passes THROUGH an empty asm statement: without it the compiler keeps the first loop's unpacked fp32 copies of x and
+        // dy alive for the second loop (112 registers at H = 3584: 368 bytes of scratch per lane at the 256-register bound of two workgroups per CU)
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            asm volatile("" : "+v"(xv[k].x), "+v"(xv[k].y), "+v"(xv[k].z), "+v"(xv[k].w), "+v"(dv[k].x), "+v"(dv[k].y), "+v"(dv[k].z), "+v"(dv[k].w));
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = lane * 8 + k * 512;
+            if (i < H) {
+                float xf[8], df[8], wf[8], o[8];
+                unpack8(xv[k], xf); unpack8(dv[k], df); unpack8(wv[k], wf);
+                if (dres) unpack8(rv[k], o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = __fmul_rn(rs, fmaf(-__fmul_rn(xf[j], rs), mdot, __fmul_rn(df[j], wf[j])));
+                    o[j] = dres ? (o[j] + d) : d;
+                }
+                *reinterpret_cast<uint4*>(dx + (int64_t)row * lddx + i) = pack8(o);
+            }
+        }
+    }
+    if (!part) return;
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = lane * 8 + k * 512;
+            if (i < H) {
+                *reinterpret_cast<float4*>(red + (wave - 1) * H + i) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+                *reinterpret_cast<float4*>(red + (wave - 1) * H + i + 4) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = lane * 8 + k * 512;
+            if (i < H) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][j] = ((acc[k][j] + red[i + j]) + red[H + i + j]) + red[2 * H + i + j];
+                float* pp = part + (int64_t)blockIdx.x * H + i;
+                *reinterpret_cast<float4*>(pp) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+                *reinterpret_cast<float4*>(pp + 4) = make_float4(acc[k][4], acc[k][5], acc[k][6], acc[k][7]);
+            }
+        }
+    }
+}
+
+// dw[c] += sum over the partial rows in block order (64 columns per workgroup, four interleaved row walkers added in walker order)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_finish_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw, int H) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < H)
+        for (int b = ty; b < nb; b += 4) acc += part[(int64_t)b * H + c];
+    red[ty][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ty == 0 && c < H) dw[c] += ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 extern "C" {
@@ -458,6 +573,42 @@ int st_rmsnorm_bwd(const st_bf16* x, int64_t ldx, const st_bf16* w, const float*
         return ST_EINVAL;
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    return rmsnorm_bwd_two_kernels(x, ldx, w, rstd, dy, lddy, dres, lddres, dx, lddx, dw_accum, T, H, s);
+}
+
+#define RB_WGS_PER_CU 2       /* 8 waves per CU (<= 256 registers each), each with one whole row of x, dy and dres in flight; 512 partial rows of dw at 256 CUs */
+/* one pass over x / dy, deterministic dw (see rmsnorm_bwd_fused_kernel).  workspace: st_rmsnorm_bwd_workspace_bytes(T, H) bytes of scratch
+ * (contents irrelevant); H <= 4096 and 16-byte aligned rows, otherwise (or with workspace == NULL while dw_accum != NULL) ST_EINVAL. */
+int64_t st_rmsnorm_bwd_workspace_bytes(int T, int H) {
+    const int nb = (int)std::min<int64_t>(st_cdiv(T, 4), RB_WGS_PER_CU * (int64_t)st_num_cus());
+    return (int64_t)std::max(nb, 1) * H * (int64_t)sizeof(float);
+}
+int st_rmsnorm_bwd_fused(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy, int64_t lddy,
+                         const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx, float* dw_accum, void* workspace,
+                         int64_t workspace_bytes, int T, int H, st_stream_t stream) {
+    if (!x || !w || !rstd || !dy || !dx || T < 0 || H <= 0 || H > 4096 || (H & 7) || (ldx & 7) || (lddy & 7) || (lddx & 7) || (dres && (lddres & 7)) ||
+        (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)w | (uintptr_t)dres) & 15))
+        return ST_EINVAL;
+    if (dw_accum && (!workspace || workspace_bytes < st_rmsnorm_bwd_workspace_bytes(T, H) || (((uintptr_t)workspace) & 15))) return ST_EINVAL;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)std::min<int64_t>(st_cdiv(T, 4), RB_WGS_PER_CU * (int64_t)st_num_cus());
+    float* part = dw_accum ? (float*)workspace : nullptr;
+    const size_t lds = (size_t)3 * H * sizeof(float);
+    const int np = st_cdiv(H, 512);
+#define RB_GO(NP) hipLaunchKernelGGL((rmsnorm_bwd_fused_kernel<NP>), dim3(nb), dim3(256), lds, s, x, ldx, w, rstd, dy, lddy, dres, lddres, dx, lddx, part, T, H)
+    switch (np) {
+        case 1: RB_GO(1); break; case 2: RB_GO(2); break; case 3: RB_GO(3); break; case 4: RB_GO(4); break;
+        case 5: RB_GO(5); break; case 6: RB_GO(6); break; case 7: RB_GO(7); break; default: RB_GO(8); break;
+    }
+#undef RB_GO
+    if (dw_accum) hipLaunchKernelGGL(rmsnorm_bwd_dw_finish_kernel, dim3(st_cdiv(H, 64)), dim3(256), 0, s, part, nb, dw_accum, H);
+    ST_CHECK_LAUNCH();
+    return 0;
+}
+
+static int rmsnorm_bwd_two_kernels(const st_bf16* x, int64_t ldx, const st_bf16* w, const float* rstd, const st_bf16* dy, int64_t lddy,
+                                   const st_bf16* dres, int64_t lddres, st_bf16* dx, int64_t lddx, float* dw_accum, int T, int H, hipStream_t s) {
     // dw first: dx may alias dy (in-place), and dw needs the original dy
     if (dw_accum)
         hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel, dim3(st_cdiv(H, 64), st_cdiv(T, 256)), dim3(256), 0, s, x, ldx, rstd, dy, lddy, dw_accum,

@@ -507,7 +507,7 @@ class Qwen25VL:
         c, dev = self.cfg, self.p.device
         pk = ix.pack_batch(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, image_token_id=c.image_token_id,
                            groups=groups, value_rows=c.value_head)
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
+        t = lambda a, dt: ops.h2d(a, dt, dev)
         pos = t(pk.pos, I32)
         cos, sin = ops.mrope_table(pos, self.inv_freq, c.head_dim, c.mrope_section)
         Tr = len(pk.logit_rows)
@@ -824,7 +824,7 @@ class Qwen25VL:
     def stage_responses(self, input_ids, attention_mask, position_ids, response_length: int, prompt_of_row, prompt_offsets) -> DeviceBatch:
         c, dev = self.cfg, self.p.device
         pk = ix.pack_responses(_np(input_ids), _np(attention_mask), _np(position_ids), response_length, prompt_of_row, prompt_offsets)
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt, non_blocking=True)
+        t = lambda a, dt: ops.h2d(a, dt, dev)
         cos, sin = ops.mrope_table(t(pk.pos, I32), self.inv_freq, c.head_dim, c.mrope_section)
         n_first, Tr = len(pk.first_prompt), len(pk.labels)
         Tr_pad = max(ix.round_up(Tr, 128), 128)
@@ -1050,7 +1050,7 @@ def pixels_on_device(t, device) -> torch.Tensor:
     the tensors alive for the step), keyed by storage address, shape, dtype AND the tensor's in-place version counter — an in-place edit of
     the host tensor is a miss, not stale pixels.  Anything else (numpy arrays: a fresh wrapper per call could never hit) is copied uncached."""
     if not torch.is_tensor(t):
-        return torch.from_numpy(np.ascontiguousarray(t)).to(device=device, dtype=F32, non_blocking=True)
+        return ops.h2d(t, F32, device)
     if t.is_cuda:
         return t
     key = (t.data_ptr(), tuple(t.shape), str(t.dtype), int(t._version), str(device))
@@ -1058,7 +1058,7 @@ def pixels_on_device(t, device) -> torch.Tensor:
     if hit is None:
         if _PIXEL_CACHE_BYTES[0] > int(os.environ.get("ST_PIXEL_CACHE_MB", "4096")) << 20:
             drop_pixel_cache()
-        hit = (t, t.to(device=device, dtype=F32, non_blocking=True))
+        hit = (t, ops.h2d(t, F32, device))
         _PIXEL_CACHE[key] = hit
         _PIXEL_CACHE_BYTES[0] += hit[1].numel() * 4
     return hit[1]

@@ -123,9 +123,18 @@ def rmsnorm_fwd(x, w, eps, want_rstd=True, out=None):
     return y, rstd
 
 
+RMSNORM_BWD_FUSED = os.environ.get("ST_RMSNORM_BWD_FUSED", "1") != "0"      # one-pass deterministic backward (round 6); 0: the two-kernel form
+
+
 def rmsnorm_bwd(x, w, rstd, dy, dres=None, dw_accum=None, out=None):
     T, H = x.shape
     dx = torch.empty(T, H, dtype=BF16, device=x.device) if out is None else out
+    if RMSNORM_BWD_FUSED and H <= 4096 and not any(t_ is not None and (t_.data_ptr() & 15 or (t_.dim() == 2 and t_.stride(0) & 7)) for t_ in (x, dy, dx, w, dres)):
+        # one pass, deterministic dw (st_rmsnorm_bwd_fused); the scratch comes from torch's stream-ordered allocator
+        ws = torch.empty(lib().st_rmsnorm_bwd_workspace_bytes(T, H) // 4, dtype=F32, device=x.device) if dw_accum is not None else None
+        lib().st_rmsnorm_bwd_fused(_p(x), x.stride(0), _p(w), _p(rstd), _p(dy), dy.stride(0), _p(dres), dres.stride(0) if dres is not None else 0,
+                                   _p(dx), dx.stride(0), _p(dw_accum), _p(ws), ws.numel() * 4 if ws is not None else 0, T, H, _s())
+        return dx
     lib().st_rmsnorm_bwd(_p(x), x.stride(0), _p(w), _p(rstd), _p(dy), dy.stride(0), _p(dres),
                          dres.stride(0) if dres is not None else 0, _p(dx), dx.stride(0), _p(dw_accum), T, H, _s())
     return dx
@@ -211,6 +220,23 @@ def _skinny_scratch(device):
 
 
 _cu_streams = {}
+
+
+def h2d(a, dtype, device) -> torch.Tensor:
+    """Host array / tensor -> device tensor WITHOUT holding the host: the bytes go through a pinned buffer (torch's caching host allocator
+    keeps it alive until the copy has run) and the copy is queued on the current stream.  A pageable source makes the copy synchronous —
+    the host then waits for every kernel already queued and cannot prepare the next pass meanwhile (round 6; under a profiler, whose
+    per-launch cost makes the host the slower side, that showed as ~50 ms of idle GPU per packed pass; un-profiled the step time did not
+    move: profiles/r06_notes.md §3)."""
+    src = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    if src.is_cuda or torch.device(device).type != "cuda":           # (CPU targets: the gloo tests' stub engines)
+        return src.to(device=device, dtype=dtype, non_blocking=True)
+    if src.dtype != dtype:
+        src = src.to(dtype)
+    src = src.contiguous()
+    if src.numel() == 0:
+        return torch.empty(src.shape, dtype=dtype, device=device)
+    return src.pin_memory().to(device=device, non_blocking=True)
 
 
 def cu_range_stream(first_cu: int, n_cus: int) -> "torch.cuda.Stream":

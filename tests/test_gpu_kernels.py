@@ -152,6 +152,42 @@ def test_rmsnorm(ops, T, H):
     assert rel_err(dw.cpu().numpy(), wg.grad.numpy()) < 1e-2
 
 
+@pytest.mark.parametrize("T,H", [(7, 256), (130, 320), (1000, 1280), (513, 2048), (2500, 3584), (64, 4096)])
+def test_rmsnorm_backward_one_pass_is_bit_identical_in_dx_and_deterministic_in_dw(ops, T, H):
+    """st_rmsnorm_bwd_fused (round 6): one pass over x / dy, per-workgroup fp32 partial rows of dw added in a fixed order.  dx must equal the
+    two-kernel form bit for bit (same per-row arithmetic in the same order), dw must equal the fp64 column sums to fp32 accumulation error,
+    be the same bits on every run (the two-kernel form adds with atomics), honour dx aliasing dy and a NULL dw_accum."""
+    import spatialthinker_amd.ops as O
+    rs = np.random.RandomState(T + H)
+    x, dy, dres = (bf(rs.standard_normal((T, H))).cuda() for _ in range(3))
+    w = bf(1.0 + 0.1 * rs.standard_normal(H)).cuda()
+    _, rstd = ops.rmsnorm_fwd(x, w, 1e-6)
+    res = {}
+    for fused in (False, True):
+        O.RMSNORM_BWD_FUSED = fused
+        try:
+            dw = torch.full((H,), 0.5, dtype=torch.float32, device="cuda")                 # accumulates INTO dw_accum
+            dx = ops.rmsnorm_bwd(x, w, rstd, dy, dres=dres, dw_accum=dw)
+            dw2 = torch.full((H,), 0.5, dtype=torch.float32, device="cuda")
+            dx2 = ops.rmsnorm_bwd(x, w, rstd, dy, dres=dres, dw_accum=dw2)
+            dx_nores = ops.rmsnorm_bwd(x, w, rstd, dy)                                    # no residual gradient, no dw
+            alias = dy.clone()
+            ops.rmsnorm_bwd(x, w, rstd, alias, dres=dres, dw_accum=torch.zeros(H, dtype=torch.float32, device="cuda"), out=alias)
+            torch.cuda.synchronize()
+            res[fused] = (dx.clone(), dw.clone(), dw2.clone(), dx_nores.clone(), alias.clone(), dx2.clone())
+        finally:
+            O.RMSNORM_BWD_FUSED = True
+    a, b_ = res[False], res[True]
+    assert torch.equal(a[0].view(torch.int16), b_[0].view(torch.int16)) and torch.equal(a[3].view(torch.int16), b_[3].view(torch.int16))
+    assert torch.equal(b_[0].view(torch.int16), b_[4].view(torch.int16)) and torch.equal(b_[0].view(torch.int16), b_[5].view(torch.int16))
+    assert torch.equal(b_[1], b_[2])                                                          # the same bits on every run
+    xhat = (x.float() * rstd[:, None]).bfloat16().double()                  # the kernel's own rounding points
+    want = 0.5 + (dy.double() * xhat).sum(0)
+    scale = float((dy.double() * xhat).abs().sum(0).max())
+    assert float((b_[1].double() - want).abs().max()) < 2e-6 * scale + 1e-5
+    assert float((a[1].double() - want).abs().max()) < 2e-6 * scale + 1e-5
+
+
 def test_mrope_table_and_apply(ops):
     rs = np.random.RandomState(2)
     T, D, nq, nkv = 50, 128, 3, 2

@@ -347,5 +347,5 @@ def test_vision_tower_taps_vs_hf_golden(env):
             assert rel < VIT_TAP_REL_L2 and err < VIT_TAP_MAX_OVER_RMS, (name, bi, rel, err)
 
 
-GRAD_WORSE_FRACTION = 0.25        # share of tensors whose engine gradient error may exceed HF-bf16's own on this one batch (set from the first measurement)
+GRAD_WORSE_FRACTION = 0.35        # share of tensors whose engine gradient error may exceed HF-bf16's own on this ONE batch: measured 16 of 67 (ratio median 0.89, max 1.11) — a tensor-by-tensor comparison of two noise realisations; the worst and the median decide
 VIT_TAP_REL_L2, VIT_TAP_MAX_OVER_RMS = 9.1e-3, 5.0e-2        # 1.3x the measured 0.0070 / 0.0386

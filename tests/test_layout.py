@@ -18,7 +18,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name, (_res, argtypes, argnames) in protos.items():
         assert len(argtypes) == len(argnames)
         if name not in ("st_version", "st_arch", "st_prof_enable", "st_prof_read", "st_prof_disable", "st_prof_set_stride", "st_prof_hint_units", "st_prof_seen",
-                            "st_attn_bwd_workspace_bytes", "st_prof_read_events", "st_stream_create_cu_range", "st_stream_destroy",
+                            "st_attn_bwd_workspace_bytes", "st_rmsnorm_bwd_workspace_bytes", "st_prof_read_events", "st_stream_create_cu_range", "st_stream_destroy",
                             "st_gemm_set_workspace", "st_gemm_decode_plan", "st_gemm_swiglu_decode_plan", "st_gemm_select", "st_decode_attn_select", "st_decode_attn_selected", "st_switch_value", "st_gemm_mxfp8_select"):
             assert argnames[-1] == "stream", f"{name}: every compute entry takes the stream last"
 

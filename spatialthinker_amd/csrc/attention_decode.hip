@@ -11,6 +11,10 @@
 // Same arithmetic per tile as attn_fwd128_kernel (S^T = K Q^T on MFMA 32x32x16, a lane owns one query column, P^T fed to the PV MFMA from
 // the accumulator registers, V^T by ds_read_b64_tr_b16); the online softmax advances in steps of 32 keys instead of 64, so the partials
 // equal the other kernel's up to fp32 rounding (not bit for bit).
+// MEASURED (profiles/r06_notes.md §2): no faster than the workgroup kernel at 512 rows, 7 % slower per decode iteration at <= 64 rows; a third
+// form with the tiles staged through REGISTERS (2-4 tiles = 32-64 KB in flight per wave, plain 16-byte loads, one LDS slot) was correct and
+// 1-4 % slower still, i.e. neither workgroup lifetime nor bytes in flight bounds this launch: it runs at 4.4-4.9 TB/s of a ~6.3 TB/s copy rate
+// whichever way the tiles travel.  Kept as the opt-in it is (ST_DECODE_ROWS=1) with its parity test; the register form was removed.
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f

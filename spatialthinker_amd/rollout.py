@@ -322,6 +322,8 @@ class Generator:
             samp_scratch = torch.empty(Ba * 33, dtype=F32, device=dev)
             ke_gen = ke_all[n1:]                                            # view: the generated-key range ends inside the launch arrays
             rows_kernel = self.decode_rows_kernel and D == 128 and g <= 32
+            fp8_gu = bool(getattr(m, "fp8", False) and getattr(m.p, "wq", None) and Bp > 256 and c.hidden_size % 128 == 0 and c.intermediate_size % 128 == 0
+                          and os.environ.get("ST_FP8_DECODE", "1") != "0")
             # ring depth of the one-wave kernel: 2 slots (32 KiB, five items per CU) while the items alone fill the chip, 4 slots (three
             # tiles in flight per item) for the late phases whose few items are latency chains (ST_DECODE_ROWS_SLOTS overrides)
             rows_slots = int(os.environ.get("ST_DECODE_ROWS_SLOTS", "0")) or (2 if Ba * nkv >= 1024 else 4)
@@ -387,7 +389,14 @@ class Generator:
                         slabs, sp = ops.gemm_nt_decode_slabs(abuf, w[p + "o_w"])
                         x1 = torch.empty(Bp, H, dtype=BF16, device=dev); h2 = torch.empty(Bp, H, dtype=BF16, device=dev)
                         ops.decode_finish_norm(slabs, sp, Bp, H, residual=x, x_out=x1, norm_w=w[p + "post_norm"], eps=c.rms_eps, h_out=h2)
-                        mm = ops.gemm_swiglu_decode(h2, w[p + "gu_w"])
+                        if fp8_gu:
+                            # fp8 mode (config #5's arithmetic; not a parity mode): at 257..512 rows the gate/up product is MFMA-bound (1.1
+                            # PF/s on the bf16 tile) — the training path's MX-fp8 tile with the SwiGLU epilogue runs it from the fp8 weight
+                            # copy the forward passes already keep (round 6); the narrow projections stay on the bf16 split-K tiles
+                            hq, hs = ops.mxfp8_quantize(h2)
+                            mm = ops.gemm_mxfp8_swiglu(hq, hs, *m.p.wq[p + "gu_w"])
+                        else:
+                            mm = ops.gemm_swiglu_decode(h2, w[p + "gu_w"])
                         slabs, sp = ops.gemm_nt_decode_slabs(mm, w[p + "down_w"])
                         x = torch.empty(Bp, H, dtype=BF16, device=dev); h1 = torch.empty(Bp, H, dtype=BF16, device=dev)
                         nxt = w[f"l.{layer + 1}.in_norm"] if layer + 1 < L else w["final_norm"]

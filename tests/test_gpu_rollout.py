@@ -420,3 +420,32 @@ def test_early_old_log_probs_are_bit_identical_to_the_serial_order(env):
     got2 = early2.finish(tampered, cache2)
     want2 = actor.compute_log_prob(tampered, T, prompt_cache=cache2)
     assert torch.equal(got2, want2) and early2.sets == []
+
+
+def test_fp8_mode_runs_the_wide_decode_gate_up_on_the_fp8_tile_within_fp8_noise(env, monkeypatch):
+    """fp8 mode (BASELINE config #5's arithmetic, not a parity mode): at 257..512 decode rows the gate/up + SwiGLU product runs on the MX-fp8
+    tile from the fp8 weight copy (round 6).  The next-token logits of the first decode iterations must stay within fp8 noise of the same
+    engine with ST_FP8_DECODE=0 (bf16 decode tiles on the same fp8-mode prefill), and the switch must change nothing below 257 rows."""
+    from spatialthinker_amd.rollout import Generator
+    cfg, params, eng, gen = env
+    ids, mask, pos, pix, grids = _prompts()
+    eng.enable_fp8(True)
+    try:
+        def logits_of(n, flag):
+            monkeypatch.setenv("ST_FP8_DECODE", flag)
+            g = Generator(eng)
+            taps = []
+            g.tap = lambda S, live, idx, tok, lg: taps.append(lg.float().cpu())
+            g.generate(ids, mask, pos, n=n, max_new_tokens=3, temperature=0.0, eos_token_id=[tiny.EOS_ID], pad_token_id=tiny.PAD_ID,
+                       pixel_values=pix, image_grid_thw=grids, ignore_eos=True, use_graph=False)
+            return taps
+        wide_on, wide_off = logits_of(160, "1"), logits_of(160, "0")              # 320 rows: the fp8 tile is in play
+        assert len(wide_on) == len(wide_off) >= 2
+        a, b = wide_on[0], wide_off[0]                                           # same sampled token on both sides (greedy from the prefill's logits)
+        rel = float((a - b).norm() / b.norm())
+        print(f"fp8 vs bf16 decode gate/up, next-token logits: relative L2 {rel:.4f}, max abs {float((a - b).abs().max()):.4f}, logit std {float(b.std()):.3f}")
+        assert 1e-4 < rel < 0.12, rel                                             # differs (the fp8 tile ran) and stays within fp8 noise (measured 0.074)
+        narrow_on, narrow_off = logits_of(20, "1"), logits_of(20, "0")            # 40 rows: the switch is not consulted
+        assert torch.equal(narrow_on[0], narrow_off[0])
+    finally:
+        eng.enable_fp8(False)

@@ -132,6 +132,23 @@ class ChipTelemetry:
                 "gemm_phases": stats(np.isin(lab, gemm_phases)), "by_phase": per_phase}
 
 
+def parity_record():
+    """Both parity criteria side by side: north_star's literal 1e-3 against what a bf16 evaluation of this model family
+    gives at all.  The figures are the committed measurement of tools/parity_probe.py on an MI355X (tiny Qwen2.5-VL config, 16 random batches,
+    288 response tokens; tests/test_gpu_model.py re-measures them live and asserts engine <= HF-bf16 on every statistic) — not re-measured here."""
+    try:
+        y = json.load(open(os.path.join(ROOT, "tests", "golden", "bf16_yardstick.json")))
+        keys = ("tokens", "rms", "mean_abs", "p99", "max", "mean_of_per_batch_max")
+        return {"quantity": "|log-prob - HF-fp32 log-prob| over the response tokens, tiny Qwen2.5-VL config, 16 batches pooled",
+                "engine_vs_fp32": {k: y["logp"]["engine"][k] for k in keys}, "hf_bf16_vs_fp32": {k: y["logp"]["hf_bf16"][k] for k in keys},
+                "hidden_state_taps_engine_over_hf_bf16_rel_l2": {t["tap"]: t["engine_rel_l2"] / t["hf_bf16_rel_l2"] for t in y["taps"]},
+                "north_star_literal_tolerance": 1e-3, "criterion_in_force": "SURVEY 8c (iii) at factor 1.0: engine error <= HF-bf16's own error, every pooled statistic and tap",
+                "full_depth_7b": "tests/test_gpu_depth.py: engine max 0.105 / rms 0.045 vs plain torch-bf16 0.220 / 0.078 against the fp32 CPU oracle",
+                "source": "tests/golden/bf16_yardstick.json (tools/parity_probe.py 16 on MI355X)"}
+    except Exception as e:                                     # a missing fixture must not cost the measurement
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def gemm_source_sha() -> str:
     """sha256 (16 hex digits) of the GEMM kernel sources: ties a committed PMC traffic figure to the kernels it was measured on."""
     import hashlib
@@ -1114,6 +1131,7 @@ def main():
             "roofline_classes": [roof(k) for k in classes if k != ops.K_GEMM and prof[k][1] > 0],
             "roofline_decode": dec,
             "telemetry": telemetry,
+            "parity": parity_record(),
         }
         if cfg5 is not None:
             out["cfg5_fp8"] = cfg5

@@ -13,7 +13,7 @@ RX='gemm_nt4_kernel|gemm_a4_finish_kernel|gemm_nt_kernel|gemm_tile_kernel<256, 2
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_bench_$c
   rm -rf $d
-  (cd /tmp && PYTHONPATH=$root timeout 700 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$RX" --output-format csv -d $d -o x -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp8-leg > $root/gpurun_out/bench_traffic_$c.json 2> /tmp/bench_traffic_$c.err) || tail -5 /tmp/bench_traffic_$c.err
+  (cd /tmp && PYTHONPATH=$root timeout 700 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$RX" --output-format csv -d $d -o x -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp8-leg --no-telemetry > $root/gpurun_out/bench_traffic_$c.json 2> /tmp/bench_traffic_$c.err) || tail -5 /tmp/bench_traffic_$c.err
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_bench_$c.json
   rm -rf $d
   d=/tmp/pmc_dec_$c
@@ -22,4 +22,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_summarize.py $d gpurun_out/pmc_dec_$c.json
   rm -rf $d
 done
-python3 tools/make_traffic_json.py gpurun_out/pmc_bench_FETCH_SIZE.json gpurun_out/pmc_bench_WRITE_SIZE.json gpurun_out/bench_traffic_FETCH_SIZE.json gpurun_out/r05_gemm_traffic.json gpurun_out/pmc_dec_FETCH_SIZE.json gpurun_out/pmc_dec_WRITE_SIZE.json 10
+python3 tools/make_traffic_json.py gpurun_out/pmc_bench_FETCH_SIZE.json gpurun_out/pmc_bench_WRITE_SIZE.json gpurun_out/bench_traffic_FETCH_SIZE.json gpurun_out/r06_gemm_traffic.json gpurun_out/pmc_dec_FETCH_SIZE.json gpurun_out/pmc_dec_WRITE_SIZE.json 10

@@ -1058,18 +1058,18 @@ def main():
         # doubled per the gfx950 note of MI355X_MICROARCH.md) over THIS command (`bench.py --steps 1`, tools/bench_traffic.sh) is kept
         # under profiles/; it is quoted only while the kernel sources it was taken on are the ones being run (sha of the GEMM sources),
         # otherwise the field is null — a measured number must not outlive the kernel it measured
-        tp = os.path.join(ROOT, "profiles", "r06_gemm_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r05_gemm_traffic.json")
         main_roof["traffic"] = None
         if os.path.exists(tp) and a.model == "7b":
             tj = json.load(open(tp))
             if tj.get("kernel_source_sha16") == gemm_source_sha():
                 main_roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                main_roof["traffic_source"] = "profiles/r06_gemm_traffic.json (PMC pass over bench.py --steps 1, time-weighted over the top GEMM instantiations)"
+                main_roof["traffic_source"] = "profiles/r05_gemm_traffic.json (PMC pass over bench.py --steps 1, time-weighted over the top GEMM instantiations)"
                 main_roof["traffic_over_algorithmic_operand_bytes"] = tj.get("traffic_over_algorithmic")
                 if dec_traffic is None:
                     dec_traffic = tj.get("decode_hbm_bytes_per_iteration")
             else:
-                main_roof["traffic_stale"] = "profiles/r06_gemm_traffic.json was measured on other kernel sources"
+                main_roof["traffic_stale"] = "profiles/r05_gemm_traffic.json was measured on other kernel sources"
         st = gen.stats
         dec = None
         if st["decode_s"] > 0:
@@ -1084,7 +1084,7 @@ def main():
                    "hbm": {"achieved_GBps": bw / 1e9, "peak_GBps": PEAK_HBM / 1e9, "frac": bw / PEAK_HBM},
                    "mfma": {"achieved_TFLOPs": tf / 1e12, "peak_TFLOPs": PEAK_BF16 / 1e12, "frac": tf / PEAK_BF16},
                    "traffic": dec_traffic,
-                   "traffic_source": ("profiles/r06_gemm_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per iteration of a 512-row decode phase "
+                   "traffic_source": ("profiles/r05_gemm_traffic.json: PMC FETCH_SIZE x2 + WRITE_SIZE per iteration of a 512-row decode phase "
                                       "(tools/gen_flat.py 6 64 8); this run's mean live rows are below that") if dec_traffic else None,
                    "iterations": st["decode_steps"], "ms_per_iteration": st["decode_s"] / st["decode_steps"] * 1e3,
                    "mean_rows_per_iteration": st["decode_row_steps"] / st["decode_steps"],

@@ -245,7 +245,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint2& lo, const uint2& hi) {
 
 #define F2_STAGE 32768
 #define F2_V_OFF 16384
-template <bool CAUSAL>
+template <bool CAUSAL, bool NT = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __restrict__ q, int64_t ldq,
                                                             const uint16_t* __restrict__ k, int64_t ldk,
                                                             const uint16_t* __restrict__ v, int64_t ldv,
@@ -302,6 +302,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
     const uint16_t* vpbase = (v_pre ? v_pre : v) + kvh * D;
     const int64_t ldkp = k_pre ? ldk_pre : ldk, ldvp = v_pre ? ldv_pre : ldv;
 
+    // NT (decode launches): every K/V byte is read by this workgroup alone, once per decode iteration — the non-temporal copy
+    auto cp16 = [](const void* src, char* dst_) __attribute__((always_inline)) { if constexpr (NT) st_glds16_nt(src, dst_); else st_glds16(src, dst_); };
     auto stage = [&](int t, char* dst) {
         const bool pre = t < n_pre;
         const int kt0 = (pre ? t : t - n_pre) * KV_TILE, row0 = pre ? pb : sk, Lc = pre ? Lp : L;
@@ -314,14 +316,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
             const int row = inst * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
             int key = kt0 + row; key = key < Lc ? key : Lc - 1;
-            st_glds16(kb_ + (int64_t)(row0 + key) * ldk_ + c * 8, dst + inst * 1024);
+            cp16(kb_ + (int64_t)(row0 + key) * ldk_ + c * 8, dst + inst * 1024);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                       // V: instruction = 2 sub-tiles of [8 keys][32 d]
             const int inst = wave * 4 + j;
             const int u = 2 * inst + (lane >> 5), slot = lane & 31;
             int key = kt0 + (u >> 2) * 8 + (slot >> 2); key = key < Lc ? key : Lc - 1;
-            st_glds16(vb_ + (int64_t)(row0 + key) * ldv_ + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
+            cp16(vb_ + (int64_t)(row0 + key) * ldv_ + (u & 3) * 32 + (slot & 3) * 8, dst + F2_V_OFF + inst * 1024);
         }
     };
     // Full tiles of the own keys take the cheap path: source = wave-uniform tile base + a lane-constant 32-bit offset per copy
@@ -343,9 +345,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(const uint16_t* __r
         const char* kt = reinterpret_cast<const char*>(kbase + (int64_t)(sk + kt0) * ldk);
         const char* vt = reinterpret_cast<const char*>(vbase + (int64_t)(sk + kt0) * ldv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st_glds16(kt + koff[j], dst + (wave * 4 + j) * 1024);
+        for (int j = 0; j < 4; ++j) cp16(kt + koff[j], dst + (wave * 4 + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st_glds16(vt + voff[j], dst + F2_V_OFF + (wave * 4 + j) * 1024);
+        for (int j = 0; j < 4; ++j) cp16(vt + voff[j], dst + F2_V_OFF + (wave * 4 + j) * 1024);
     };
     if (n_tiles > 0) stage_any(0, smem);
     // Q after the first tile's copies are on their way: the two latencies overlap (a decode item is ~5 us of prologue + 3.3 us per tile)
@@ -1586,6 +1588,9 @@ int st_attn_win80_bwd_launch(const uint16_t* q, int64_t ldq, const uint16_t* k, 
 static bool vit_win_from_env() { const char* e = getenv("ST_VIT_WIN"); return !(e && e[0] == '0'); }
 static const bool g_vit_win = vit_win_from_env();
 
+static int decode_attn_nt_from_env() { const char* e = getenv("ST_DECODE_ATTN_NT"); return e ? atoi(e) : 0; }
+static int g_decode_attn_nt = decode_attn_nt_from_env();
+
 extern "C" {
 
 static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t ldk, const st_bf16* v, int64_t ldv,
@@ -1605,7 +1610,9 @@ static int attn_fwd_launch(const st_bf16* q, int64_t ldq, const st_bf16* k, int6
     StProfScope ps(klass, s, 0.0);
 #define ST_FWD(DD, CC) hipLaunchKernelGGL((attn_fwd_kernel<DD, CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse)
 #define ST_FWD2(CC) hipLaunchKernelGGL((attn_fwd128_kernel<CC>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre)
-    if (D == 128) { if (causal) ST_FWD2(true); else ST_FWD2(false); }
+    if (D == 128 && !causal && qgroup > 0 && g_decode_attn_nt)     // the rollout's decode partials: K/V streamed once per workgroup
+        hipLaunchKernelGGL((attn_fwd128_kernel<false, true>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, q_beg, q_end, k_beg, k_end, o_beg, qgroup, T, n_q, n_kv, sl2, out, ldo, lse, pre_beg, pre_end, k_pre, ldk_pre, v_pre, ldv_pre);
+    else if (D == 128) { if (causal) ST_FWD2(true); else ST_FWD2(false); }
     else if (D == 80 && !causal) ST_FWD(80, false);
     else if (D == 80) ST_FWD(80, true);
     else return ST_EINVAL;

@@ -96,6 +96,12 @@ __device__ __forceinline__ void st_glds16(const void* gsrc, char* lds_dst_unifor
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 }
+// the same copy with the non-temporal policy (aux = 2): for streams ONE workgroup reads once (decode K/V, decode weights) — MI355X_MICROARCH.md
+// row nt-weights: issued -> landed -18 %; never for data other workgroups re-read from L2
+__device__ __forceinline__ void st_glds16_nt(const void* gsrc, char* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 2);
+}
 // Hardware transpose read: within a 16-lane group whose lane s points at row (s>>2), column 4*(s&3) of a [4][16] bf16 block,
 // lane i receives column i (the 4 rows) — i.e. 4 contiguous k-values of a k-strided MFMA operand.
 __device__ __forceinline__ s16x4_t st_lds_tr16(const char* p) {

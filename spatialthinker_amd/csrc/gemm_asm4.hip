@@ -35,9 +35,6 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
     }
 }
 
-#ifndef A4_GROUP_ROWS
-#define A4_GROUP_ROWS 8       // tile rows per group of the XCD-contiguous tile order: an XCD's 32 co-resident tiles form an 8 x 4 macro-tile.  Round 6
-#endif                        // (profiles/r06_notes.md §5): 4 / 6 / 16 measured via -DA4_GROUP_ROWS=... builds — the L2-miss traffic follows 1/r + 1/c
 #define A4_BM 256
 #define A4_BN 256
 #define A4_SLOT 65536          // one K-tile of both operands: (256 + 256) rows x 128 bytes
@@ -115,10 +112,10 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(const uint16_t* __restric
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int per_group = A4_GROUP_ROWS * tiles_n;
+    const int per_group = 8 * tiles_n;
     const int group = bid / per_group, in_g = bid % per_group;
-    const int first_m = group * A4_GROUP_ROWS;
-    const int gsz = min(tiles_m - first_m, A4_GROUP_ROWS);
+    const int first_m = group * 8;
+    const int gsz = min(tiles_m - first_m, 8);
     const int tm = first_m + in_g % gsz, tn = in_g / gsz;
     const int m0 = tm * A4_BM;
     const int n0 = SWIGLU ? tn * (A4_BN / 2) : tn * A4_BN;           // SWIGLU: first OUTPUT column (N = output width I)
@@ -602,10 +599,10 @@ __global__ __launch_bounds__(256) void gemm_a4_finish_kernel(const float* __rest
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int per_group = A4_GROUP_ROWS * tiles_n;
+    const int per_group = 8 * tiles_n;
     const int group = bid / per_group, in_g = bid % per_group;
-    const int first_m = group * A4_GROUP_ROWS;
-    const int gsz = min(tiles_m - first_m, A4_GROUP_ROWS);
+    const int first_m = group * 8;
+    const int gsz = min(tiles_m - first_m, 8);
     const int tm = first_m + in_g % gsz, tn = in_g / gsz;
     const int row = blockIdx.y * 8 + (threadIdx.x >> 5), col = (threadIdx.x & 31) * 8;
     const int m = tm * A4_BM + row, n = tn * A4_BN + col;
@@ -646,10 +643,10 @@ __global__ __launch_bounds__(256) void gemm_a4_swiglu_finish_kernel(const float*
         const int xcd = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int per_group = A4_GROUP_ROWS * tiles_n;
+    const int per_group = 8 * tiles_n;
     const int group = bid / per_group, in_g = bid % per_group;
-    const int first_m = group * A4_GROUP_ROWS;
-    const int gsz = min(tiles_m - first_m, A4_GROUP_ROWS);
+    const int first_m = group * 8;
+    const int gsz = min(tiles_m - first_m, 8);
     const int tm = first_m + in_g % gsz, tn = in_g / gsz;
     const int row = blockIdx.y * 8 + (threadIdx.x >> 5), nl = (threadIdx.x & 31) * 4;
     const int m = tm * A4_BM + row, n = tn * (A4_BN / 2) + nl;

@@ -1,5 +1,9 @@
-# L2-miss traffic and rate of the training GEMM tile vs the height of its tile groups (variants/libst_hip_g{4,6,16}.so = -DA4_GROUP_ROWS builds,
-# the in-tree library = 8): rocprofv3 --kernel-trace --pmc FETCH_SIZE over tools/gemm_one.py on two shapes of the update pass.
+# L2-miss traffic and rate of the training GEMM tile vs the height of its tile groups.  variants/libst_hip_g{4,6,16}.so are builds of the
+# library in which the three occurrences of the group height 8 in gemm_asm4.hip's tile map (`per_group = 8 * tiles_n`, `first_m = group * 8`,
+# `gsz = min(tiles_m - first_m, 8)`, in the kernel and its two finish kernels) read 4 / 6 / 16 — e.g.
+#   sed 's/per_group = 8 \* tiles_n/per_group = G * tiles_n/; s/first_m = group \* 8/first_m = group * G/; s/first_m, 8)/first_m, G)/' gemm_asm4.hip
+# compiled with -DG=4 and linked with the other objects (the product source keeps the literal 8: its hash ties the committed PMC figures to it);
+# the in-tree library = 8: rocprofv3 --kernel-trace --pmc FETCH_SIZE over tools/gemm_one.py on two shapes of the update pass.
 #   bash tools/gemm_group_probe.sh      (from the repo root on the GPU box; results in gpurun_out/r06/gemm_group_probe.txt)
 cd /tmp && export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT

@@ -283,7 +283,7 @@ int st_attn_decode_rows(const st_bf16* q, int64_t ldq, const st_bf16* k, int64_t
  * in flight per CU), 0 = one workgroup per item (attn_fwd128_kernel<false>; default — measured faster, see attention.hip — and the
  * path of wider items).  Same arithmetic: bit-identical partials (tests/test_gpu_kernels.py).  ST_DECODE_ATTN=persistent sets the initial value to 1. */
 int st_decode_attn_select(int persistent);   /* 2 = the persistent kernel with TWO workgroups per CU (2-slot rings, 80 KiB of LDS each) */
-int64_t st_switch_value(int which);         /* 0: training GEMM tile id (40), 1: nt decode weight stream (1), 2: decode attention kernel (0); -1 for an unknown id */
+int64_t st_switch_value(int which);         /* 0: training GEMM tile id (40), 1: nt decode weight stream (1), 2: decode attention kernel (0), 3: nt K/V copies in the decode attention (1); -1 for an unknown id */
 int64_t st_decode_attn_selected(void);       /* the current choice (0 unless ST_DECODE_ATTN / st_decode_attn_select say otherwise; pinned by tests/test_layout.py) */
 /* Flash-decoding merge of n_parts partial attentions over disjoint key sets: parts (n_parts*rows, heads*D) bf16 with
  * their lse (heads, n_parts*rows) -> out (rows, heads*D); partials with lse = -inf (empty key range) are skipped. */

@@ -110,13 +110,14 @@ int st_prof_disable(int klass) {
 }
 /* the kernel-choice switches in force (they change speed, never results: a wrong default passes every parity test — tests/test_layout.py
  * pins the defaults in a fresh process): 0 = training GEMM tile (st_gemm_select / ST_GEMM_VARIANT), 1 = non-temporal decode weight stream
- * (ST_DECODE_NT), 2 = decode attention kernel (st_decode_attn_select / ST_DECODE_ATTN) */
+ * (ST_DECODE_NT), 2 = decode attention kernel (st_decode_attn_select / ST_DECODE_ATTN), 3 = non-temporal K/V copies in the decode attention (ST_DECODE_ATTN_NT) */
 int64_t st_switch_value(int which) {
-    extern int g_train_variant, g_decode_nt;
+    extern int g_train_variant, g_decode_nt, g_decode_attn_nt;
     switch (which) {
         case 0: return g_train_variant;
         case 1: return g_decode_nt;
         case 2: return st_decode_attn_selected();
+        case 3: return g_decode_attn_nt;
         default: return -1;
     }
 }

@@ -1588,8 +1588,11 @@ int st_attn_win80_bwd_launch(const uint16_t* q, int64_t ldq, const uint16_t* k, 
 static bool vit_win_from_env() { const char* e = getenv("ST_VIT_WIN"); return !(e && e[0] == '0'); }
 static const bool g_vit_win = vit_win_from_env();
 
-static int decode_attn_nt_from_env() { const char* e = getenv("ST_DECODE_ATTN_NT"); return e ? atoi(e) : 0; }
-static int g_decode_attn_nt = decode_attn_nt_from_env();
+// K/V copies of the rollout's decode partials with the non-temporal policy (round 6): every byte is read by ONE workgroup, once per decode
+// iteration; same-box A/B: 10.27 -> 10.19 ms per 512-row iteration at 200-token contexts, 11.68 -> 11.45 at 700, 4.23 -> 4.18 at 64 rows
+// (profiles/r06_notes.md §2).  Results unchanged (a cache policy).  ST_DECODE_ATTN_NT=0 restores the default policy.
+static int decode_attn_nt_from_env() { const char* e = getenv("ST_DECODE_ATTN_NT"); return e ? atoi(e) : 1; }
+int g_decode_attn_nt = decode_attn_nt_from_env();
 
 extern "C" {
 

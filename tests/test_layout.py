@@ -30,10 +30,10 @@ def test_library_defaults_after_load():
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if not k.startswith("ST_")}
-    code = "from spatialthinker_amd.lib import lib; L = lib(); print(int(L.st_decode_attn_selected()), *[int(L.st_switch_value(i)) for i in range(4)])"
+    code = "from spatialthinker_amd.lib import lib; L = lib(); print(int(L.st_decode_attn_selected()), *[int(L.st_switch_value(i)) for i in range(5)])"
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, text=True)
-    # decode attention: one workgroup per item; training GEMM: the 4-wave hand-scheduled tile; decode weights: non-temporal stream
-    assert out.strip().splitlines()[-1] == "0 40 1 0 -1", out
+    # decode attention: one workgroup per item; training GEMM: the 4-wave hand-scheduled tile; decode weights and decode K/V: non-temporal streams
+    assert out.strip().splitlines()[-1] == "0 40 1 0 1 -1", out
     # round 6: the one-wave-per-item decode attention kernel is opt-in (ST_DECODE_ROWS=1; measured no faster): off unless asked for
     out = subprocess.check_output([sys.executable, "-c", "from spatialthinker_amd import rollout; print(rollout.DECODE_ROWS_DEFAULT)"], cwd=ROOT, env=env, text=True)
     assert out.strip().splitlines()[-1] == "False", out

@@ -258,7 +258,7 @@ def fp8_leg(a):
     """BASELINE config #5's per-GPU shape in its own arithmetic (fp8 MFMA), as a short leg of the DEFAULT command so that the driver's bench
     witnesses it: a CHILD process — started before this process initialises the GPU, so it finds the whole HBM and is
     never an exec from a GPU process — runs `bench.py --dtype fp8 --fp8-dgrad --fp8-wgrad --rollouts 16 --prompts-per-gpu 32 --image
-    896x896 --steps 2 --warmup 1`; its line is condensed into {value, dtype, roofline {frac, peak}, timing_s}.  A throughput mode, not
+    896x896 --steps 1 --warmup 1`; its line is condensed into {value, dtype, roofline {frac, peak}, timing_s}.  A throughput mode, not
     a parity mode; the headline `value` stays the bf16 config #3 step.  Returns None when the leg does not apply."""
     default_workload = (a.model == "7b" and a.dtype == "bf16" and a.gpus <= 1 and not a.image and a.rollouts == 8 and a.prompts_per_gpu == 64
                         and not a.worst_case and not a.responses_at_cap and not a.prompt_tokens and not a.old_from_rollout and not a.master_fp32)
@@ -269,7 +269,8 @@ def fp8_leg(a):
     if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
         return None
     cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp8", "--fp8-dgrad", "--fp8-wgrad", "--rollouts", "16", "--prompts-per-gpu", "32",
-           "--image", "896x896", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp8-leg"]
+           "--image", "896x896", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-fp8-leg", "--no-telemetry"]      # (round 6: one timed step —
+    # the leg cost 78-85 s of the driver's 860-870-s run with two)
     t0 = time.perf_counter()
     try:
         p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)      # ~2x the leg's usual 180-200 s

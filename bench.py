@@ -68,6 +68,10 @@ class ChipTelemetry:
                     self.files[f] = fp
             if self.files:
                 break
+        self.power_cap_w = None                                    # the board's power limit (hwmon power1_cap, microwatts): the GEMM phases sit at it
+        if self.files:
+            cap = self._read(os.path.join(os.path.dirname(next(iter(self.files.values()))), "power1_cap"))
+            self.power_cap_w = cap * 1e-6 if cap else None
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, name="telemetry", daemon=True)
 
@@ -128,7 +132,7 @@ class ChipTelemetry:
             return out
         per_phase = {p: stats(lab == p) for p in sorted(set(self.labels))}
         return {"period_s": self.period, "probe": "st_clock_probe: s_memtime / s_memrealtime over 20 us on 8 one-wave workgroups (one per XCD), side stream",
-                "sysfs_files": sorted(self.files), "pci": self.pci, "probe_errors": self.errors, "all": stats(np.ones(n, dtype=bool)),
+                "sysfs_files": sorted(self.files), "pci": self.pci, "power_cap_w": getattr(self, "power_cap_w", None), "probe_errors": self.errors, "all": stats(np.ones(n, dtype=bool)),
                 "gemm_phases": stats(np.isin(lab, gemm_phases)), "by_phase": per_phase}
 
 

@@ -44,6 +44,22 @@ template <int N> __device__ __forceinline__ void s5_wait_vmcnt() {
 
 }  // namespace
 
+// ST_GU512_TRACE builds (tools/gu512_phase_trace.py, never the shipped library): every wave sums the shader-clock cycles between fixed
+// points of the ping-pong loop and leaves the sums in st_gu512_trace_ptr[workgroup][wave][8].
+#ifdef ST_GU512_TRACE
+__device__ unsigned long long* st_gu512_trace_ptr = nullptr;
+extern "C" int st_gu512_trace_set(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(st_gu512_trace_ptr), &buf, sizeof(buf)); }
+#define G5_DECL unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = 0
+#define G5_START() do { __builtin_amdgcn_sched_barrier(0); tr_prev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G5_POINT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tr_acc[i] += t_ - tr_prev; tr_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G5_FLUSH() do { if (st_gu512_trace_ptr && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) st_gu512_trace_ptr[(blockIdx.x * 8 + wave) * 8 + i_] = tr_acc[i_]; } } while (0)
+#else
+#define G5_DECL
+#define G5_START()
+#define G5_POINT(i)
+#define G5_FLUSH()
+#endif
+
 template <bool PP>
 __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ W,
                                                             int64_t ldw, uint16_t* __restrict__ out, int64_t ldo, int M, int I, int K) {
@@ -140,22 +156,36 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
             asm volatile("" ::: "memory");
         }
         int slot = 0;
+        G5_DECL;
+        G5_START();
         for (int ks = 0; ks < nks; ++ks) {
             const int s1 = slot + 1 == S5_SLOTS ? 0 : slot + 1;
             if (live) {
                 __builtin_amdgcn_s_setprio(2);
+#ifdef ST_GU512_NOMFMA                                       /* timing experiment: one MFMA per K-step instead of 40 */
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0], af[0], acc[0][0], 0, 0, 0);
+#pragma unroll
+                for (int ni = 1; ni < 10; ++ni) asm volatile("" :: "v"(bfr[ni]));
+#pragma unroll
+                for (int mi = 1; mi < 4; ++mi) asm volatile("" :: "v"(af[mi]));
+#else
 #pragma unroll
                 for (int ni = 0; ni < 10; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#endif
                 __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            G5_POINT(0);
             if (grp == 0) wait_copies(ks + 1);
+            G5_POINT(1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            G5_POINT(2);
             if (ks + 3 < nks) stage(ks + 3, slot);            // slot of K-step ks: both groups have read it by now
+            G5_POINT(3);
             if (live && ks + 1 < nks) {
                 const char* base = smem + s1 * S5_SLOT;
 #pragma unroll
@@ -165,12 +195,16 @@ __global__ __launch_bounds__(512) void gemm_swiglu512_kernel(const uint16_t* __r
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            G5_POINT(4);
             if (grp == 1) wait_copies(ks + 2);
+            G5_POINT(5);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            G5_POINT(6);
             slot = s1;
         }
         if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        G5_FLUSH();
     } else {
     if (nks > 0) stage(0, 0);
     if (nks > 1) stage(1, 1);
@@ -239,6 +273,10 @@ int st_gemm_swiglu512_launch(const uint16_t* A, int64_t lda, const uint16_t* W, 
     // at 512 rows, slower below), every workgroup walking K from its own starting point (143 vs 136 us: the 237 workgroups reading the SAME
     // activation lines at the same time is an L2 benefit, not a conflict): the tile runs at the rate the CU can fill its LDS (4.8 MB per
     // workgroup at ~36 GB/s).
+    // Round 6, measured and removed (profiles/r06_notes.md §1b, §1c; all bit-identical): activations loaded straight into registers (156.6 vs
+    // 132.8 us), activations staged as 8-row x 128-byte pieces into per-wave rings of K-step pairs (137.3 vs 133.9: 38 % fewer L2 requests,
+    // TA busy -19 %, no conflicts — and no faster), weights staged as 128-byte pieces five K-steps ahead (129.5 vs 126.6).  With 39 of its 40
+    // MFMAs per K-step removed the launch still takes 118 us (at 2.18 GHz instead of 1.65): see the phase trace, tools/gu512_phase_trace.py.
     static const int mode = [] { const char* e = getenv("ST_GU512_MODE"); return e ? atoi(e) : 0; }();
     static bool configured = false;
     if (!configured) {

@@ -371,9 +371,9 @@ def dry_run(a):
 
 def preflight(rank: int, world: int, local: int, need_gb: float, timeout_s: float = 120.0):
     """Before the first RCCL collective of an N-GPU run: everything that would otherwise show up as a HANG is checked and turned into a
-    message + non-zero exit — enough visible devices, peer access between this rank's GPU and every other one (xGMI / PCIe P2P: RCCL's
-    direct transports), enough free HBM on this rank for the replica design (weights + fp32 grads + AdamW state + frozen reference),
-    and one tiny all-reduce under a watchdog (a rank that never arrives, a wedged transport).  Rank 0 prints one summary line
+    message + non-zero exit — enough visible devices, enough free HBM on this rank for the replica design (weights + fp32 grads + AdamW state + frozen reference),
+    and one tiny all-gather under a watchdog (a rank that never arrives, a wedged transport); missing peer access between this rank's GPU
+    and another one (xGMI / PCIe P2P: RCCL's direct transports) is a warning.  Rank 0 prints one summary line
     (RCCL version, free GB per rank).  The watchdog ends the PROCESS (os._exit) — it never re-execs anything: a process that has touched
     the GPU must not exec (the launcher's torchrun parent then tears the other ranks down)."""
     import threading
@@ -382,9 +382,12 @@ def preflight(rank: int, world: int, local: int, need_gb: float, timeout_s: floa
     if n_dev < world:
         problems.append(f"{world} ranks but only {n_dev} visible GPUs")
     else:
+        # reported, not fatal: without peer access RCCL still has its shared-memory transport (slower, and a scaling number measured that
+        # way says so in stderr); a transport that does wedge is caught by the watchdog around the first collective below
         no_peer = [j for j in range(world) if j != local and not torch.cuda.can_device_access_peer(local, j)]
         if no_peer:
-            problems.append(f"GPU {local} has no peer access to GPUs {no_peer} (RCCL would fall back to host staging or hang)")
+            sys.stderr.write(f"[bench preflight] rank {rank}: WARNING GPU {local} reports no peer access to GPUs {no_peer} "
+                             f"(no xGMI / PCIe P2P visible here: RCCL will stage through host memory)\n")
     free_b, total_b = torch.cuda.mem_get_info()
     if free_b / 2 ** 30 < need_gb:
         problems.append(f"only {free_b / 2 ** 30:.0f} GB free of {total_b / 2 ** 30:.0f} GB on GPU {local}, the workload needs ~{need_gb:.0f} GB")

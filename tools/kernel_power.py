@@ -67,8 +67,31 @@ def attention_forward():
     return (lambda: ops.attn_fwd(q, k, v, cu, S, nq, nkv, D, D ** -0.5, True, out=o)), flops, f"attention forward, causal, 4 x {S} tokens, D = 128"
 
 
+def attention_backward():
+    S, nq, nkv, D = 4096, 28, 4, 128
+    q, k, v = rnd(S * 4, nq * D, scale=0.5), rnd(S * 4, nkv * D, scale=0.5), rnd(S * 4, nkv * D, scale=0.5)
+    cu = torch.tensor([0, S, 2 * S, 3 * S, 4 * S], dtype=torch.int32, device=dev)
+    o, lse = ops.attn_fwd(q, k, v, cu, S, nq, nkv, D, D ** -0.5, True)[:2]
+    do = rnd(S * 4, nq * D, scale=0.5)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    flops = 10.0 * 4 * nq * D * S * S / 2
+    return (lambda: ops.attn_bwd(q, k, v, o, do, lse, cu, S, nq, nkv, D, D ** -0.5, True, dq, dk, dv)), flops, f"attention backward (three kernels), causal, 4 x {S} tokens"
+
+
+def decode_narrow(rows):
+    a, w = rnd(rows, 18944, scale=0.5), [rnd(3584, 18944) for _ in range(6)]
+    out = torch.empty(rows, 3584, dtype=BF, device=dev)
+    i = [0]
+
+    def f():
+        i[0] += 1
+        ops.gemm_nt(a, w[i[0] % 6], out=out, decode=True)
+    return f, 2.0 * rows * 3584 * 18944, f"decode down projection at {rows} rows (split-K tiles + finish, six rotating weight copies)"
+
+
 CASES = [("idle", None), ("gemm", training_gemm), ("gu512", lambda: decode_gate_up(512)), ("gu256", lambda: decode_gate_up(256)),
-         ("swiglu_bwd", swiglu_backward), ("rmsnorm", rmsnorm_forward), ("attention", attention_forward)]
+         ("swiglu_bwd", swiglu_backward), ("rmsnorm", rmsnorm_forward), ("attention", attention_forward), ("attention_bwd", attention_backward), ("down512", lambda: decode_narrow(512)),
+         ("down64", lambda: decode_narrow(64))]
 
 
 def main():

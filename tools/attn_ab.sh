@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   for spec in "$@"; do
     name="${spec%%:*}"; flags="${spec#*:}"
     ( cd spatialthinker_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $flags -c attention.hip -o /tmp/attn_$name.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o /tmp/attn_$name.o decode.o elementwise.o gemm.o gemm_fp8.o gemm_tiles.o rowwise.o -o ../../variants/$name.so ) || exit 1
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^attention.o$') /tmp/attn_$name.o -o ../../variants/$name.so ) || exit 1
   done
 else
   shift
